@@ -1,0 +1,133 @@
+// engine.h - host-side bookkeeping shared by the DRCT and DRN engines: a parameter table that
+// maps the reference's state-dict names onto offsets in a caller-owned device arena, the packed
+// layer descriptors, a bump allocator for the per-call workspace, and hipGraph replay.
+#pragma once
+#include "srad_common.h"
+#include <string>
+#include <vector>
+
+#define SRAD_TRY(expr)            \
+  do {                            \
+    int _rc = (expr);             \
+    if (_rc) return _rc;          \
+  } while (0)
+
+struct ParamEntry {
+  std::string name;
+  int64_t numel;     // elements of the fp32 source tensor
+  size_t off;        // byte offset in the arena
+  int packed;        // 1: GEMM weight packed by srad_launch_pack_weight, 0: raw fp32 copy
+  int n, cin, ntaps; // packed geometry
+};
+
+struct ConvW {       // one Linear / conv layer
+  int w = -1, b = -1;      // indices into the parameter table (-1: no bias)
+  int n = 0, cin = 0, ntaps = 1;
+};
+
+struct ParamTable {
+  std::vector<ParamEntry> entries;
+  size_t bytes = 0;
+  int prec = SRAD_PREC_F32;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+
+  int add_raw(const std::string& name, int64_t numel) {
+    ParamEntry e{name, numel, bytes, 0, 0, 0, 0};
+    bytes += srad_align_up((size_t)numel * 4, 256);
+    entries.push_back(e);
+    return (int)entries.size() - 1;
+  }
+  int add_packed(const std::string& name, int n, int cin, int ntaps) {
+    ParamEntry e{name, (int64_t)n * cin * ntaps, bytes, 1, n, cin, ntaps};
+    bytes += srad_align_up(srad_packed_bytes(prec, n, cin, ntaps), 256);
+    entries.push_back(e);
+    return (int)entries.size() - 1;
+  }
+  ConvW add_layer(const std::string& prefix, int n, int cin, int ntaps, bool bias) {
+    ConvW c;
+    c.n = n; c.cin = cin; c.ntaps = ntaps;
+    c.w = add_packed(prefix + ".weight", n, cin, ntaps);
+    if (bias) c.b = add_raw(prefix + ".bias", n);
+    return c;
+  }
+  int find(const char* name) const {
+    for (size_t i = 0; i < entries.size(); ++i)
+      if (entries[i].name == name) return (int)i;
+    return -1;
+  }
+  const void* ptr(int idx) const { return idx < 0 ? nullptr : arena + entries[idx].off; }
+  const float* fptr(int idx) const { return reinterpret_cast<const float*>(ptr(idx)); }
+
+  int set(const char* name, const float* src, int64_t numel, hipStream_t s) {
+    if (!arena) return srad_set_error(SRAD_ERR_STATE, "set_param(%s): no arena bound", name);
+    const int i = find(name);
+    if (i < 0) return srad_set_error(SRAD_ERR_ARG, "set_param: unknown parameter '%s'", name);
+    const ParamEntry& e = entries[i];
+    if (numel != e.numel)
+      return srad_set_error(SRAD_ERR_ARG, "set_param(%s): got %lld elements, expected %lld", name, (long long)numel,
+                            (long long)e.numel);
+    if (e.packed) return srad_launch_pack_weight(prec, src, arena + e.off, e.n, e.cin, e.ntaps, s);
+    SRAD_CHECK_HIP(hipMemcpyAsync(arena + e.off, src, (size_t)numel * 4, hipMemcpyDeviceToDevice, s));
+    return SRAD_OK;
+  }
+};
+
+struct Bump {
+  char* base;
+  size_t cap, used = 0;
+  Bump(void* b, size_t c) : base(reinterpret_cast<char*>(b)), cap(c) {}
+  float* take(size_t floats) {
+    const size_t off = used;
+    used += srad_align_up(floats * 4, 256);
+    return reinterpret_cast<float*>(base + off);       // base may be null when only sizing
+  }
+};
+
+// hipGraph replay of a fixed launch sequence keyed on the call's pointers and shape.
+struct GraphCache {
+  hipGraphExec_t exec = nullptr;
+  hipGraph_t graph = nullptr;
+  const void* key[3] = {nullptr, nullptr, nullptr};
+  int shape[3] = {0, 0, 0};
+  int seen = 0;   // eager runs with the current key (the first call runs eagerly, the second captures)
+  bool matches(const void* a, const void* b, const void* c, int B, int H, int W) const {
+    return key[0] == a && key[1] == b && key[2] == c && shape[0] == B && shape[1] == H && shape[2] == W;
+  }
+  void reset() {
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    exec = nullptr; graph = nullptr; seen = 0;
+  }
+  void rekey(const void* a, const void* b, const void* c, int B, int H, int W) {
+    reset();
+    key[0] = a; key[1] = b; key[2] = c; shape[0] = B; shape[1] = H; shape[2] = W;
+  }
+};
+
+// Run `body(stream)` eagerly the first time a (pointers, shape) key is seen, capture it into a
+// hipGraph the second time, and replay the graph afterwards.
+template <class F>
+int srad_run_with_graph(GraphCache& gc, bool enable, const void* a, const void* b, const void* c, int B, int H, int W,
+                        hipStream_t stream, F&& body) {
+  if (!enable || stream == nullptr) return body(stream);   // the legacy default stream cannot be captured
+  if (!gc.matches(a, b, c, B, H, W)) gc.rekey(a, b, c, B, H, W);
+  if (gc.exec) {
+    SRAD_CHECK_HIP(hipGraphLaunch(gc.exec, stream));
+    return SRAD_OK;
+  }
+  if (gc.seen == 0) {
+    gc.seen = 1;
+    return body(stream);
+  }
+  SRAD_CHECK_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+  const int rc = body(stream);
+  hipGraph_t g = nullptr;
+  const hipError_t e = hipStreamEndCapture(stream, &g);
+  if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (e != hipSuccess) return srad_set_error(SRAD_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  gc.graph = g;
+  SRAD_CHECK_HIP(hipGraphInstantiate(&gc.exec, g, nullptr, nullptr, 0));
+  SRAD_CHECK_HIP(hipGraphLaunch(gc.exec, stream));
+  return SRAD_OK;
+}

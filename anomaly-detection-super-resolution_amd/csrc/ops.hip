@@ -1,0 +1,60 @@
+// ops.hip - operator-level C ABI: the single kernels behind the engines, exposed so that each
+// row of SURVEY.md §8(a) (A4-A7, A9, B3-B6) can be parity-tested on its own against the oracle.
+#include "engine.h"
+#include "../../include/srad.h"
+
+extern "C" {
+
+// Linear / 1x1 conv / 3x3 conv with the fused prologue+epilogue of kernels_gemm.hip.
+//   x      : [M_in rows][ldx] fp32 NHWC activations
+//   w      : PyTorch-layout fp32 weight [N][Cin][taps] (device), packed into `scratch` first
+//   conv   : ntaps = 9 -> 3x3 pad 1 with the given stride over an (B, Hi, Wi) image; ntaps = 1 and
+//            stride 1 -> rows are used as they are
+//   ln_g/b : optional LayerNorm over the Cin channels of each row (eps 1e-5), ntaps = 1 only
+//   epilogue: + bias -> act (0 none, 1 GELU-erf, 2 LeakyReLU(slope), 3 ReLU) -> * alpha -> + r
+//   ps     : 0 plain rows [M][ldy] at column yoff; 2 = PixelShuffle(2) scatter
+int srad_op_gemm(int precision, const float* x, int ldx, int B, int Hi, int Wi, int Cin, const float* w, int N,
+                 int ntaps, int stride, const float* bias, const float* ln_g, const float* ln_b, int act, float slope,
+                 float alpha, const float* r, int ldr, float* y, int ldy, int yoff, int ps, void* scratch,
+                 size_t scratch_bytes, void* stream) {
+  SRAD_REQUIRE(x && w && y && scratch, "op_gemm: null argument");
+  SRAD_REQUIRE(ntaps == 1 || ntaps == 9, "op_gemm: ntaps must be 1 or 9");
+  SRAD_REQUIRE(stride == 1 || stride == 2, "op_gemm: stride must be 1 or 2");
+  const size_t need = srad_packed_bytes(precision, N, Cin, ntaps);
+  SRAD_REQUIRE(scratch_bytes >= need, "op_gemm: scratch %zu bytes, %zu needed", scratch_bytes, need);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  SRAD_TRY(srad_launch_pack_weight(precision, w, scratch, N, Cin, ntaps, s));
+  GemmParams p{};
+  const int pad = ntaps == 9 ? 1 : 0, k = ntaps == 9 ? 3 : 1;
+  p.Hi = Hi; p.Wi = Wi;
+  p.Ho = (Hi + 2 * pad - k) / stride + 1;
+  p.Wo = (Wi + 2 * pad - k) / stride + 1;
+  p.stride = stride;
+  p.X = x; p.ldx = ldx; p.M = B * p.Ho * p.Wo; p.Cin = Cin; p.Cp = srad_cp(Cin); p.ntaps = ntaps;
+  p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = 1e-5f;
+  p.Wp = scratch; p.N = N; p.bias = bias;
+  p.act = act; p.slope = slope; p.alpha = alpha;
+  p.R = r; p.ldr = ldr; p.Y = y; p.ldy = ldy; p.yoff = yoff; p.ps = ps; p.pool = nullptr;
+  return srad_launch_gemm(precision, p, s);
+}
+
+size_t srad_op_gemm_scratch_bytes(int precision, int N, int Cin, int ntaps) {
+  return srad_packed_bytes(precision, N, Cin, ntaps);
+}
+
+// WindowAttention core (reference src/drct.py:281-299 plus the roll/partition/reverse around it):
+// qkv [B*H*W][3d] -> out [B*H*W][d], raster token order.
+int srad_op_window_attn(int precision, const float* qkv, float* out, const float* table, int B, int H, int W, int ws,
+                        int shift, int d, int heads, void* stream) {
+  SRAD_REQUIRE(qkv && out && table, "op_window_attn: null argument");
+  AttnParams a{qkv, out, table, B, H, W, ws, shift, d, heads};
+  return srad_launch_window_attn(precision, a, reinterpret_cast<hipStream_t>(stream));
+}
+
+int srad_op_layernorm(const float* x, int ldx, float* y, int ldy, int rows, int C, const float* g, const float* b,
+                      void* stream) {
+  SRAD_REQUIRE(x && y && g && b, "op_layernorm: null argument");
+  return srad_launch_layernorm(x, ldx, y, ldy, rows, C, g, b, 1e-5f, reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

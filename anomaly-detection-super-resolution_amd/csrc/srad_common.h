@@ -1,0 +1,118 @@
+// srad_common.h - shared declarations for the gfx950 (CDNA4 / MI355X) kernels of libsrad.
+// Written for wave64 + MFMA only; there is no other target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define SRAD_OK 0
+#define SRAD_ERR_ARG 1
+#define SRAD_ERR_STATE 2
+#define SRAD_ERR_HIP 3
+#define SRAD_ERR_NOMEM 4
+
+enum { SRAD_PREC_F32 = 0, SRAD_PREC_BF16 = 1 };
+enum { SRAD_ACT_NONE = 0, SRAD_ACT_GELU = 1, SRAD_ACT_LRELU = 2, SRAD_ACT_RELU = 3 };
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+int srad_set_error(int code, const char* fmt, ...);
+#define SRAD_CHECK_HIP(expr)                                                              \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess)                                                                 \
+      return srad_set_error(SRAD_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr,    \
+                            hipGetErrorString(_e));                                       \
+  } while (0)
+#define SRAD_REQUIRE(cond, ...)                                                           \
+  do {                                                                                    \
+    if (!(cond)) return srad_set_error(SRAD_ERR_ARG, __VA_ARGS__);                        \
+  } while (0)
+
+static inline size_t srad_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int srad_round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------------
+// Row-gather GEMM:  Y[m][n] = epi( sum_{tap,c} A(m,tap,c) * W[n][tap*Cp + c] + bias[n] )
+//   * Linear / 1x1 conv : ntaps = 1, A(m,0,c) = X[m*ldx + c]
+//   * 3x3 conv (pad 1)  : ntaps = 9, A(m,tap,c) = X[pix(m,tap)*ldx + c] (0 outside the image),
+//                         stride 1 or 2; activations are NHWC so c is contiguous
+//   * optional LayerNorm over the Cin channels of each row fused into the A staging
+//   * epilogue: +bias -> activation -> *alpha -> +R[m*ldr+n] -> store (plain / pixel-shuffle 2x)
+// Weights are pre-packed by pack_weight_kernel: [Np][ntaps*Cp], zero padded, bf16 or fp32.
+// ------------------------------------------------------------------------------------------
+struct GemmParams {
+  const float* X;
+  int ldx;
+  int M;
+  int Cin;
+  int Cp;
+  int ntaps;
+  int Hi, Wi, Ho, Wo, stride;
+  const float* ln_g;
+  const float* ln_b;
+  float ln_eps;
+  const void* Wp;
+  int N;
+  const float* bias;
+  int act;
+  float slope;
+  float alpha;
+  const float* R;
+  int ldr;
+  float* Y;
+  int ldy;
+  int yoff;
+  int ps;          // 0: plain store, 2: PixelShuffle(2) scatter (N = 4 * ldy-channels)
+  float* pool;     // optional [B][N] per-image column sums of the stored values (atomicAdd)
+};
+
+int srad_launch_gemm(int prec, const GemmParams& p, hipStream_t stream);
+
+// Packed weight geometry shared by the packer and the GEMM
+static inline int srad_cp(int cin) { return srad_round_up(cin, 32); }
+static inline int srad_np(int n) { return srad_round_up(n, 64); }
+static inline size_t srad_packed_bytes(int prec, int n, int cin, int ntaps) {
+  return (size_t)srad_np(n) * ntaps * srad_cp(cin) * (prec == SRAD_PREC_BF16 ? 2 : 4);
+}
+// src: PyTorch layout [N][Cin][kh][kw] (kh*kw = ntaps) or [N][Cin] for Linear
+int srad_launch_pack_weight(int prec, const float* src, void* dst, int n, int cin, int ntaps,
+                            hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------
+// Window attention (DRCT): qkv [T][3d] -> out [T][d], tokens in raster order per image.
+// ------------------------------------------------------------------------------------------
+struct AttnParams {
+  const float* qkv;   // [T][3*d]
+  float* out;         // [T][d]
+  const float* table; // [(2ws-1)^2][heads]
+  int B, H, W, ws, shift, d, heads;
+};
+int srad_launch_window_attn(int prec, const AttnParams& p, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------
+// misc kernels
+// ------------------------------------------------------------------------------------------
+int srad_launch_layernorm(const float* x, int ldx, float* y, int ldy, int rows, int C,
+                          const float* g, const float* b, float eps, hipStream_t stream);
+// NCHW -> NHWC with (x - mean[c]) * scale ; NHWC -> NCHW with x * scale + mean[c]
+int srad_launch_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W,
+                             const float* mean3, float scale, hipStream_t stream);
+int srad_launch_nhwc_to_nchw(const float* x, int ldx, float* y, int B, int C, int H, int W,
+                             const float* mean3, float scale, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------
+// Optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline
+// numbers).  Off by default; never active while a stream is being captured.
+// ------------------------------------------------------------------------------------------
+enum {
+  SRAD_K_GEMM_64x64 = 0, SRAD_K_GEMM_128x32, SRAD_K_GEMM_128x16, SRAD_K_ATTN, SRAD_K_LAYERNORM,
+  SRAD_K_LAYOUT, SRAD_K_PACK, SRAD_K_SCORE, SRAD_K_MISC, SRAD_K_COUNT
+};
+struct SradProfScope {
+  hipStream_t s; int active;
+  SradProfScope(hipStream_t stream, int cls, double flops, double bytes);
+  ~SradProfScope();
+};

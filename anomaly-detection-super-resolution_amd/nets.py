@@ -1,0 +1,354 @@
+"""Host-side mirrors of the reference networks: ``DRCT`` (reference src/drct.py:716-898) and
+``DRN`` (src/drn.py:160-270).  They are ``torch.nn.Module``s only for what PyTorch is used for
+here - owning device memory for parameters under the reference's state-dict names, streams, and
+``torch.distributed``; ``forward`` enqueues the hand-written HIP engine through the C ABI
+(include/srad.h).  There is no eager / CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import spec as S
+
+
+# ------------------------------------------------------------------ parameter tree
+class _Node(nn.Module):
+    """Plain container so that parameters live under dotted reference names."""
+
+
+def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor, is_param: bool) -> None:
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Node())
+        mod = mod._modules[p]
+    if is_param:
+        mod.register_parameter(parts[-1], nn.Parameter(tensor))
+    else:
+        mod.register_buffer(parts[-1], tensor)
+
+
+def _trunc_normal_(t: torch.Tensor, std: float, a: float = -2.0, b: float = 2.0) -> None:
+    """Same distribution as the reference's trunc_normal_ (src/drct.py:32-93)."""
+    nn.init.trunc_normal_(t, mean=0.0, std=std, a=a, b=b)
+
+
+def _reference_init(name: str, kind: str, shape, cfg) -> torch.Tensor:
+    """Initial values with the reference's distributions: Linear weights
+    trunc-N(0,.02), Linear bias 0, LayerNorm (1,0), bias table trunc-N(.02); convolutions keep
+    PyTorch's default (kaiming-uniform(a=sqrt 5) weight, U(+-1/sqrt(fan_in)) bias)."""
+    if kind in ("index", "mask", "meanshift_w", "meanshift_b_sub", "meanshift_b_add"):
+        return torch.from_numpy(S.synth_tensor(name, shape, kind, cfg=cfg))
+    t = torch.empty(shape, dtype=torch.float32)
+    if kind == "lin_w":
+        _trunc_normal_(t, 0.02)
+    elif kind == "lin_b" or kind == "ln_b":
+        t.zero_()
+    elif kind == "ln_w":
+        t.fill_(1.0)
+    elif kind == "table":
+        _trunc_normal_(t, 0.02)
+    elif kind == "conv_w":
+        nn.init.kaiming_uniform_(t, a=math.sqrt(5))
+    elif kind == "conv_b":
+        # fan_in is not recoverable from the bias alone; callers patch conv biases afterwards
+        t.zero_()
+    else:
+        raise ValueError(kind)
+    return t
+
+
+class _EngineModule(nn.Module):
+    """Shared plumbing: parameter tree, weight arena, change tracking, workspace cache."""
+
+    _prefix = ""            # C symbol prefix: srad_drct / srad_drn
+
+    def _init_engine(self, spec, cfg, precision: str, use_graph: bool):
+        self._spec = spec
+        self._cfg = cfg
+        self.precision = precision
+        self.use_graph = bool(use_graph)
+        self._handle = None
+        self._arena = None
+        self._packed_versions: Dict[str, tuple] = {}
+        self._ws: Dict[tuple, torch.Tensor] = {}
+        self._static_io: Dict[tuple, tuple] = {}
+        self._side_stream = None
+        conv_fan = {}
+        for name, (shape, kind) in spec.items():
+            t = _reference_init(name, kind, shape, cfg)
+            if kind == "conv_w":
+                conv_fan[name[:-len("weight")]] = int(np.prod(shape[1:]))
+            _attach(self, name, t, is_param=kind not in ("index", "mask"))
+        with torch.no_grad():
+            for name, (shape, kind) in spec.items():
+                if kind == "conv_b":
+                    bound = 1.0 / math.sqrt(conv_fan[name[:-len("bias")]])
+                    self.get_parameter(name).uniform_(-bound, bound)
+
+    # -- C handle -------------------------------------------------------------------------
+    def _fn(self, suffix):
+        return getattr(L.lib(), f"{self._prefix}_{suffix}")
+
+    def _make_handle(self):
+        raise NotImplementedError
+
+    def _ensure_handle(self, device):
+        if self._handle is not None:
+            return
+        self._handle = self._make_handle()
+        nbytes = C.c_size_t()
+        L.check(self._fn("arena_bytes")(self._handle, C.byref(nbytes)), "arena_bytes")
+        self._arena = torch.zeros(nbytes.value + 256, dtype=torch.uint8, device=device)
+        off = (-self._arena.data_ptr()) % 256
+        self._arena_ptr = self._arena.data_ptr() + off
+        L.check(self._fn("bind_arena")(self._handle, C.c_void_p(self._arena_ptr), C.c_size_t(nbytes.value)), "bind_arena")
+        n = self._fn("num_params")(self._handle)
+        self._engine_params = []
+        name = C.c_char_p()
+        numel = C.c_int64()
+        for i in range(n):
+            L.check(self._fn("param_info")(self._handle, i, C.byref(name), C.byref(numel)), "param_info")
+            self._engine_params.append((name.value.decode(), numel.value))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) is not None:
+                self._fn("destroy")(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    def _sync_weights(self, device):
+        """(Re)pack every parameter whose storage or version changed since the last forward
+        (optimizer steps and load_state_dict bump ``_version``)."""
+        self._ensure_handle(device)
+        stream = L.current_stream_ptr()
+        for name, numel in self._engine_params:
+            p = self.get_parameter(name)
+            if p.device != device or p.dtype != torch.float32:
+                raise RuntimeError(f"{name}: parameters must be fp32 on {device} (got {p.dtype} on {p.device})")
+            tag = (p.data_ptr(), p._version)
+            if self._packed_versions.get(name) == tag:
+                continue
+            src = p.detach()
+            if not src.is_contiguous():
+                src = src.contiguous()
+            L.check(self._fn("set_param")(self._handle, name.encode(), L.dptr(src), C.c_int64(src.numel()), stream),
+                    f"set_param({name})")
+            self._packed_versions[name] = tag
+
+    def _workspace(self, B, H, W, device) -> torch.Tensor:
+        key = (B, H, W)
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = C.c_size_t()
+            L.check(self._fn("workspace_bytes")(self._handle, B, H, W, C.byref(nbytes)), "workspace_bytes")
+            ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=device)
+            self._ws = {key: ws}          # keep one shape resident
+        return ws
+
+    def _run(self, fn):
+        """Run ``fn()`` (which enqueues on the current stream).  With graph replay enabled the work
+        goes to a private non-default stream (the legacy default stream cannot be captured),
+        ordered after / before the caller's stream with events."""
+        if not self.use_graph:
+            return fn()
+        cur = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=cur.device)
+        self._side_stream.wait_stream(cur)
+        with torch.cuda.stream(self._side_stream):
+            out = fn()
+        cur.wait_stream(self._side_stream)
+        for t in (out if isinstance(out, (list, tuple)) else [out]):
+            t.record_stream(cur)           # allocated on the side stream, consumed on the caller's
+        return out
+
+    @staticmethod
+    def _aligned(t: torch.Tensor):
+        off = (-t.data_ptr()) % 256
+        return C.c_void_p(t.data_ptr() + off), C.c_size_t(t.numel() - off)
+
+    def _check_input(self, x: torch.Tensor, channels: int):
+        if not isinstance(x, torch.Tensor) or x.dim() != 4:
+            raise ValueError("expected a [B, C, H, W] tensor")
+        if x.shape[1] != channels:
+            raise ValueError(f"expected {channels} channels, got {x.shape[1]}")
+        if not x.is_cuda:
+            raise RuntimeError("srad_amd runs on the GPU only (HIP engine); got a CPU tensor - there is no CPU fallback")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise NotImplementedError("the HIP backward pass is not built yet: call under torch.no_grad() / .eval()")
+        return x.detach().to(torch.float32).contiguous()
+
+    def flops(self, B: int, H: int, W: int) -> float:
+        dev = next(self.parameters()).device
+        self._ensure_handle(dev)
+        f = C.c_double()
+        L.check(self._fn("flops")(self._handle, B, H, W, C.byref(f)), "flops")
+        return f.value
+
+
+# ------------------------------------------------------------------ DRCT
+class DRCT(_EngineModule):
+    """Drop-in for reference ``src.drct.DRCT(opt)``: same ``opt`` fields, same state-dict, same
+    ``forward(x)`` contract (fp32 NCHW in [0, rgb_range] -> [B, C, H*s, W*s])."""
+
+    _prefix = "srad_drct"
+
+    def __init__(self, opt, precision: Optional[str] = None, use_graph: Optional[bool] = None):
+        super().__init__()
+        depths = tuple(getattr(opt, "depths", (6,) * 12))
+        heads = getattr(opt, "num_heads", 6)
+        heads = heads[0] if isinstance(heads, (tuple, list)) else heads
+        cfg = S.DRCTConfig(in_chans=opt.n_colors, img_size=opt.img_size, window_size=opt.window_size,
+                           upscale=opt.upscale, embed_dim=getattr(opt, "embed_dim", 180), n_rdg=len(depths),
+                           num_heads=heads, mlp_ratio=float(getattr(opt, "mlp_ratio", 2)),
+                           img_range=float(getattr(opt, "img_range", 1.0)),
+                           depth_per_rdg=depths[0] if depths else 6)
+        if getattr(opt, "upsampler", "pixelshuffle") != "pixelshuffle":
+            raise ValueError("only upsampler='pixelshuffle' is supported (the reference CLI never selects another)")
+        if getattr(opt, "resi_connection", "1conv") != "1conv":
+            raise ValueError("only resi_connection='1conv' is supported")
+        self.cfg = cfg
+        self.window_size = cfg.window_size
+        self.upscale = cfg.upscale
+        self.img_range = cfg.img_range
+        prec = precision or getattr(opt, "precision", "fp32")
+        graph = getattr(opt, "use_graph", True) if use_graph is None else use_graph
+        self._init_engine(S.drct_spec(cfg), cfg, prec, graph)
+
+    def _make_handle(self):
+        c = self.cfg
+        cc = L.DrctConfig(c.in_chans, c.img_size, c.window_size, c.upscale, c.embed_dim, c.n_rdg, c.num_heads, c.gc,
+                          c.num_feat, c.mlp_ratio, c.img_range, L.PRECISIONS[self.precision], int(self.use_graph))
+        h = C.c_void_p()
+        L.check(L.lib().srad_drct_create(C.byref(cc), C.byref(h)), "drct_create")
+        return h
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = self._check_input(x, self.cfg.in_chans)
+        dev = x.device
+        B, _, H, W = x.shape
+        if H % self.window_size or W % self.window_size:
+            raise ValueError(f"input {H}x{W} must be a multiple of the window size {self.window_size}")
+        self._sync_weights(dev)
+        ws = self._workspace(B, H, W, dev)
+        s = self.upscale
+        if self.use_graph:
+            key = (B, H, W)
+            if key not in self._static_io:
+                self._static_io = {key: (torch.empty_like(x), torch.empty(B, self.cfg.in_chans, H * s, W * s,
+                                                                          dtype=torch.float32, device=dev))}
+            xin, yout = self._static_io[key]
+        else:
+            xin = x
+            yout = torch.empty(B, self.cfg.in_chans, H * s, W * s, dtype=torch.float32, device=dev)
+        wp, wb = self._aligned(ws)
+
+        def launch():
+            if self.use_graph:
+                xin.copy_(x)
+            L.check(L.lib().srad_drct_forward(self._handle, L.dptr(xin), B, H, W, L.dptr(yout), wp, wb,
+                                              L.current_stream_ptr()), "drct_forward")
+            return yout.clone() if self.use_graph else yout
+        return self._run(launch)
+
+
+# ------------------------------------------------------------------ DRN
+class DRN(_EngineModule):
+    """Drop-in for reference ``src.drn.DRN(opt)``; ``forward`` returns the list of phase+1 images,
+    coarse -> fine (src/drn.py:258-270)."""
+
+    _prefix = "srad_drn"
+
+    def __init__(self, opt, precision: Optional[str] = None, use_graph: Optional[bool] = None):
+        super().__init__()
+        scales = opt.scale if isinstance(opt.scale, (list, tuple)) else [opt.scale]
+        cfg = S.DRNConfig(n_colors=opt.n_colors, scale=max(scales), n_blocks=opt.n_blocks, n_feats=opt.n_feats,
+                          negval=float(opt.negval), rgb_range=float(opt.rgb_range))
+        self.cfg = cfg
+        self.scale = list(scales)
+        self.phase = cfg.phase
+        prec = precision or getattr(opt, "precision", "fp32")
+        graph = getattr(opt, "use_graph", True) if use_graph is None else use_graph
+        self._init_engine(S.drn_spec(cfg), cfg, prec, graph)
+
+    def _make_handle(self):
+        c = self.cfg
+        cc = L.DrnConfig(c.n_colors, c.scale, c.n_blocks, c.n_feats, c.negval, c.rgb_range,
+                         L.PRECISIONS[self.precision], int(self.use_graph))
+        h = C.c_void_p()
+        L.check(L.lib().srad_drn_create(C.byref(cc), C.byref(h)), "drn_create")
+        return h
+
+    def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
+        x = self._check_input(x, self.cfg.n_colors)
+        dev = x.device
+        B, Cc, H, W = x.shape
+        self._sync_weights(dev)
+        ws = self._workspace(B, H, W, dev)
+        key = (B, H, W)
+        if self.use_graph:
+            if key not in self._static_io:
+                outs = [torch.empty(B, Cc, H * 2 ** i, W * 2 ** i, dtype=torch.float32, device=dev)
+                        for i in range(self.phase + 1)]
+                self._static_io = {key: (torch.empty_like(x), outs)}
+            xin, outs = self._static_io[key]
+        else:
+            xin = x
+            outs = [torch.empty(B, Cc, H * 2 ** i, W * 2 ** i, dtype=torch.float32, device=dev)
+                    for i in range(self.phase + 1)]
+        ptrs = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+        wp, wb = self._aligned(ws)
+
+        def launch():
+            if self.use_graph:
+                xin.copy_(x)
+            L.check(L.lib().srad_drn_forward(self._handle, L.dptr(xin), B, H, W, ptrs, len(outs), wp, wb,
+                                             L.current_stream_ptr()), "drn_forward")
+            return [o.clone() for o in outs] if self.use_graph else outs
+        return self._run(launch)
+
+
+class DownBlock(nn.Module):
+    """Dual regression model, drop-in for reference ``src.model.DownBlock(opt, 2)``
+    (src/model.py:8-44): conv3x3 s2 (no bias) + LeakyReLU(negval) + conv3x3 (no bias)."""
+
+    def __init__(self, opt, scale: int = 2, precision: Optional[str] = None):
+        super().__init__()
+        if scale != 2:
+            raise ValueError("the reference only builds dual models with scale 2")
+        self.n_colors, self.n_feats, self.negval = opt.n_colors, opt.n_feats, float(opt.negval)
+        self.precision = precision or getattr(opt, "precision", "fp32")
+        w0 = torch.empty(self.n_feats, self.n_colors, 3, 3)
+        w1 = torch.empty(self.n_colors, self.n_feats, 3, 3)
+        nn.init.kaiming_uniform_(w0, a=math.sqrt(5))
+        nn.init.kaiming_uniform_(w1, a=math.sqrt(5))
+        _attach(self, "dual_module.0.0.weight", w0, True)
+        _attach(self, "dual_module.1.weight", w1, True)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("srad_amd runs on the GPU only (HIP engine)")
+        x = x.detach().to(torch.float32).contiguous()
+        B, Cc, H, W = x.shape
+        y = torch.empty(B, Cc, (H + 1) // 2, (W + 1) // 2, dtype=torch.float32, device=x.device)
+        nbytes = C.c_size_t()
+        L.check(L.lib().srad_dual_workspace_bytes(B, Cc, H, W, self.n_feats, C.byref(nbytes)), "dual_workspace_bytes")
+        ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=x.device)
+        wp, wb = _EngineModule._aligned(ws)
+        w0 = self.get_parameter("dual_module.0.0.weight").detach().contiguous()
+        w1 = self.get_parameter("dual_module.1.weight").detach().contiguous()
+        L.check(L.lib().srad_dual_forward(L.dptr(w0), L.dptr(w1), Cc, self.n_feats, self.negval, L.dptr(x), B, H, W,
+                                          L.dptr(y), wp, wb, L.PRECISIONS[self.precision], L.current_stream_ptr()),
+                "dual_forward")
+        return y

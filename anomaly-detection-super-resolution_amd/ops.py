@@ -1,0 +1,74 @@
+"""Single-operator bindings (C ABI ``srad_op_*``).  Activations are NHWC / token-major fp32
+tensors on the GPU; weights are given in PyTorch layout and packed by the library."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("srad_amd ops run on the GPU only (HIP); there is no CPU fallback")
+
+
+def gemm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, B: int = 1, H: int = 0,
+         W: int = 0, stride: int = 1, ln: Optional[tuple] = None, act: int = L.ACT_NONE, slope: float = 0.0,
+         alpha: float = 1.0, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+         out_offset: int = 0, pixel_shuffle: bool = False, precision: str = "fp32") -> torch.Tensor:
+    """x: [rows, Cin] (row stride = x.stride(0)); weight: [N, Cin] or [N, Cin, 3, 3].
+    For a 3x3 / strided conv pass the image geometry (B, H, W) of the NHWC input rows."""
+    _need_cuda(x, weight)
+    assert x.dim() == 2 and (x.stride(1) == 1 or x.shape[1] == 1) and x.dtype == torch.float32
+    ldx = x.stride(0) if x.shape[0] > 1 else x.shape[1]
+    ntaps = 9 if weight.dim() == 4 and weight.shape[-1] == 3 else 1
+    N, Cin = weight.shape[0], weight.shape[1]
+    assert x.shape[1] >= Cin
+    w = weight.detach().reshape(N, Cin, ntaps).contiguous().float()
+    if ntaps == 1 and stride == 1:
+        B, H, W = 1, 1, x.shape[0]
+    pad, k = (1, 3) if ntaps == 9 else (0, 1)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    M = B * Ho * Wo
+    if out is None:
+        if pixel_shuffle:
+            out = torch.empty(M * 4, N // 4, dtype=torch.float32, device=x.device)
+        else:
+            out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    prec = L.PRECISIONS[precision]
+    nbytes = L.lib().srad_op_gemm_scratch_bytes(prec, N, Cin, ntaps)
+    scratch = torch.empty(nbytes + 256, dtype=torch.uint8, device=x.device)
+    off = (-scratch.data_ptr()) % 256
+    g, b_ = (ln if ln is not None else (None, None))
+    L.check(L.lib().srad_op_gemm(prec, L.dptr(x), ldx, B, H, W, Cin, L.dptr(w), N, ntaps, stride,
+                                 L.dptr(bias), L.dptr(g), L.dptr(b_), act, slope, alpha, L.dptr(residual),
+                                 0 if residual is None else residual.stride(0), L.dptr(out), out.stride(0),
+                                 out_offset, 2 if pixel_shuffle else 0, C.c_void_p(scratch.data_ptr() + off),
+                                 C.c_size_t(nbytes), L.current_stream_ptr()), "op_gemm")
+    return out
+
+
+def window_attention(qkv: torch.Tensor, table: torch.Tensor, B: int, H: int, W: int, ws: int, shift: int,
+                     heads: int, precision: str = "fp32") -> torch.Tensor:
+    """qkv: [B*H*W, 3d] raster-ordered tokens -> [B*H*W, d]."""
+    _need_cuda(qkv, table)
+    assert qkv.is_contiguous() and qkv.shape[0] == B * H * W
+    d = qkv.shape[1] // 3
+    out = torch.empty(qkv.shape[0], d, dtype=torch.float32, device=qkv.device)
+    L.check(L.lib().srad_op_window_attn(L.PRECISIONS[precision], L.dptr(qkv), L.dptr(out),
+                                        L.dptr(table.contiguous()), B, H, W, ws, shift, d, heads,
+                                        L.current_stream_ptr()), "op_window_attn")
+    return out
+
+
+def layernorm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _need_cuda(x, g, b)
+    assert x.dim() == 2 and x.stride(1) == 1
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    L.check(L.lib().srad_op_layernorm(L.dptr(x), x.stride(0), L.dptr(y), y.stride(0), x.shape[0], x.shape[1],
+                                      L.dptr(g), L.dptr(b), L.current_stream_ptr()), "op_layernorm")
+    return y

@@ -1,0 +1,131 @@
+/* srad.h - C ABI of libsrad, the MI355X (gfx950) engine for the SR forward / scorer hot path of
+ * Benedict3007/anomaly-detection-super-resolution.
+ *
+ * The reference has no FFI layer; its seam for this path is Python (`make_model(opt)` /
+ * `Model.forward`, reference src/model.py:46-52,95-100; `ssim_numpy`/`psnr_numpy`,
+ * src/metrics.py:15-67; `roc_auc_score` call sites src/evaluate.py:245,263-265).  Each entry
+ * point below names the reference interface it stands in for.  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; `srad_last_error()` gives the
+ *     thread-local message.  Nothing aborts.
+ *   - all pointers named `dev_*`, `x`, `y`, `workspace`, `arena` are DEVICE pointers owned by the
+ *     caller (e.g. PyTorch's caching allocator).  The library allocates no device memory.
+ *   - `stream` is a `hipStream_t` passed as `void*`; all work is enqueued on it asynchronously.
+ *     Functions that return host scalars say so and synchronise that stream.
+ *   - a handle is not thread-safe: one per process / rank.
+ *   - images are fp32 NCHW in [0, rgb_range], exactly what the reference modules take/return.
+ */
+#ifndef SRAD_H
+#define SRAD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRAD_PRECISION_F32 0  /* v_mfma_f32_16x16x4_f32: exact fp32, the parity mode            */
+#define SRAD_PRECISION_BF16 1 /* v_mfma_f32_16x16x32_bf16, fp32 accumulate, fp32 residual stream */
+
+const char* srad_last_error(void);
+int srad_version(void);
+
+/* ------------------------------------------------------------------ DRCT-L (src/drct.py:716-898) */
+typedef struct srad_drct srad_drct_t;
+typedef struct {
+  int32_t in_chans;    /* opt.n_colors                          */
+  int32_t img_size;    /* opt.img_size (LR side built for)      */
+  int32_t window_size; /* opt.window_size = img_size // 4       */
+  int32_t upscale;     /* opt.upscale (2^n)                     */
+  int32_t embed_dim;   /* 180                                   */
+  int32_t n_rdg;       /* len(opt.depths) = 12                  */
+  int32_t num_heads;   /* 6                                     */
+  int32_t gc;          /* 32                                    */
+  int32_t num_feat;    /* 64                                    */
+  float mlp_ratio;     /* 2                                     */
+  float img_range;     /* 1.0                                   */
+  int32_t precision;   /* SRAD_PRECISION_*                      */
+  int32_t use_graph;   /* replay the forward from a hipGraph when shapes/pointers repeat */
+} srad_drct_config;
+
+/* DRCT.__init__ (src/drct.py:718-849) */
+int srad_drct_create(const srad_drct_config* cfg, srad_drct_t** out);
+void srad_drct_destroy(srad_drct_t* h);
+/* packed-weight arena the caller must provide before loading parameters */
+int srad_drct_arena_bytes(const srad_drct_t* h, size_t* bytes);
+int srad_drct_bind_arena(srad_drct_t* h, void* arena, size_t bytes);
+/* state_dict surface: fp32 tensors in the reference's key names (src/model.py:114-116,155-170) */
+int srad_drct_num_params(const srad_drct_t* h);
+int srad_drct_param_info(const srad_drct_t* h, int idx, const char** name, int64_t* numel);
+int srad_drct_set_param(srad_drct_t* h, const char* name, const float* dev_src, int64_t numel, void* stream);
+int srad_drct_workspace_bytes(const srad_drct_t* h, int B, int H, int W, size_t* bytes);
+/* DRCT.forward (src/drct.py:886-898): x [B,C,H,W] -> y [B,C,H*s,W*s]; H, W multiples of the window */
+int srad_drct_forward(srad_drct_t* h, const float* x, int B, int H, int W, float* y, void* workspace,
+                      size_t workspace_bytes, void* stream);
+/* FLOPs (2 per MAC) of one forward at this shape, for roofline accounting */
+int srad_drct_flops(const srad_drct_t* h, int B, int H, int W, double* flops);
+
+/* ------------------------------------------------------------------ DRN-L (src/drn.py:160-270) */
+typedef struct srad_drn srad_drn_t;
+typedef struct {
+  int32_t n_colors;  /* opt.n_colors                */
+  int32_t scale;     /* max(opt.scale): 2, 4 or 8   */
+  int32_t n_blocks;  /* opt.n_blocks                */
+  int32_t n_feats;   /* opt.n_feats                 */
+  float negval;      /* opt.negval = 0.2            */
+  float rgb_range;   /* opt.rgb_range = 255         */
+  int32_t precision;
+  int32_t use_graph;
+} srad_drn_config;
+
+int srad_drn_create(const srad_drn_config* cfg, srad_drn_t** out);
+void srad_drn_destroy(srad_drn_t* h);
+int srad_drn_arena_bytes(const srad_drn_t* h, size_t* bytes);
+int srad_drn_bind_arena(srad_drn_t* h, void* arena, size_t bytes);
+int srad_drn_num_params(const srad_drn_t* h);
+int srad_drn_param_info(const srad_drn_t* h, int idx, const char** name, int64_t* numel);
+int srad_drn_set_param(srad_drn_t* h, const char* name, const float* dev_src, int64_t numel, void* stream);
+int srad_drn_workspace_bytes(const srad_drn_t* h, int B, int H, int W, size_t* bytes);
+/* DRN.forward (src/drn.py:241-270): returns phase+1 images coarse -> fine; ys[i] is the device
+ * pointer of output i with shape [B, C, H*2^i*..]: ys[0] = LR size, ys[phase] = H*scale. */
+int srad_drn_forward(srad_drn_t* h, const float* x, int B, int H, int W, float* const* ys, int n_out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+int srad_drn_flops(const srad_drn_t* h, int B, int H, int W, double* flops);
+
+/* Dual regression model DownBlock(opt, 2) (src/model.py:8-44,78-82): two bias-free 3x3 convs,
+ * the first stride 2 + LeakyReLU(negval).  w0 [n_feats,C,3,3], w1 [C,n_feats,3,3] fp32 device.
+ * x [B,C,H,W] -> y [B,C,H/2,W/2].  workspace >= srad_dual_workspace_bytes. */
+int srad_dual_workspace_bytes(int B, int C, int H, int W, int n_feats, size_t* bytes);
+int srad_dual_forward(const float* w0, const float* w1, int C, int n_feats, float negval, const float* x, int B,
+                      int H, int W, float* y, void* workspace, size_t workspace_bytes, int precision, void* stream);
+
+/* ------------------------------------------------------------------ scorer (src/evaluate.py:204-265) */
+/* `mul(255/range).clamp(0,255).byte()` TRUNCATING u8 conversion + NCHW->HWC (evaluate.py:214-215). */
+int srad_to_u8_hwc(const float* x, int B, int C, int H, int W, float rgb_range, uint8_t* out, void* stream);
+/* quantize (src/trainer.py:45-47): mul, clamp, round-half-even, div; in-place allowed */
+int srad_quantize(const float* x, float* y, int64_t n, float rgb_range, void* stream);
+/* Per-pair scores for `n_img` u8 HWC image pairs (sr, hr, each [n_img,H,W,C]):
+ *   ssim_out[i*n_ws + j] = ssim_numpy(hr_i/255, sr_i/255, ws[j])   (src/metrics.py:26-67)
+ *   mse_out[i] = mean((sr_i/255 - hr_i/255)^2), psnr_out[i] = psnr_numpy (inf when mse == 0)
+ * Outputs are DEVICE double arrays; workspace >= srad_score_workspace_bytes. */
+int srad_score_workspace_bytes(int n_img, int H, int W, size_t* bytes);
+int srad_score_pairs(const uint8_t* sr, const uint8_t* hr, int n_img, int H, int W, int C, const int32_t* ws_host,
+                     int n_ws, double* ssim_out, double* mse_out, double* psnr_out, void* workspace,
+                     size_t workspace_bytes, void* stream);
+/* Validation metrics of Trainer.test (src/metrics.py:70-108) on fp32 NCHW tensors, one value per
+ * image, device double outputs; reproduces the zero padding, 4-px shave and the 255^2 constants. */
+int srad_val_metrics(const float* sr, const float* hr, int B, int C, int H, int W, float rgb_range,
+                     double* psnr_out, double* ssim_out, void* workspace, size_t workspace_bytes, void* stream);
+/* Binary ROC-AUC == sklearn.metrics.roc_auc_score (ties count one half).  labels/scores are HOST
+ * arrays (n is the number of test images, a few hundred); returns non-zero if one class is absent. */
+int srad_roc_auc(const int32_t* labels, const double* scores, int n, double* auc);
+
+/* mean |a-b| (nn.L1Loss, src/loss.py:84) -> device double */
+int srad_l1_loss(const float* a, const float* b, int64_t n, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRAD_H */

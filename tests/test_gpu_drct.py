@@ -1,0 +1,93 @@
+"""GPU: DRCT forward through the C ABI against (a) the golden fixtures the reference produced and
+(b) the oracle, in both precisions.  Bars: fp32 mode <= 1e-3 relative (north_star), measured
+~1e-5; bf16 mode: max error <= 3% of the output range, PSNR vs the fp32 result >= 35 dB."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import DRCT_CASES, drct_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+class Opt:
+    def __init__(self, cfg, precision, use_graph=False):
+        self.n_colors, self.img_size, self.window_size, self.upscale = cfg.in_chans, cfg.img_size, cfg.window_size, cfg.upscale
+        self.embed_dim, self.depths, self.num_heads = cfg.embed_dim, (6,) * cfg.n_rdg, (cfg.num_heads,) * cfg.n_rdg
+        self.mlp_ratio, self.img_range = cfg.mlp_ratio, cfg.img_range
+        self.upsampler, self.resi_connection = "pixelshuffle", "1conv"
+        self.precision, self.use_graph = precision, use_graph
+
+
+def build(cfg, sd, precision, use_graph=False):
+    from srad_amd.nets import DRCT
+    m = DRCT(Opt(cfg, precision, use_graph)).cuda().eval()
+    missing = m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    return m
+
+
+@pytest.mark.parametrize("name", DRCT_CASES)
+def test_drct_fp32_matches_reference_golden(sr_golden, name):
+    cfg, sd, x, y = drct_case(sr_golden, name)
+    m = build(cfg, sd, "fp32")
+    with torch.no_grad():
+        out = m(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert out.shape == y.shape
+    assert rel_err(out, y) < 1e-3, rel_err(out, y)
+    assert rel_err(out, y) < 2e-4          # what the exact-fp32 MFMA path actually achieves
+
+
+@pytest.mark.parametrize("name", ["drct_full_gray_x4", "drct_r2_rgb_x4", "drct_r2_gray_x4_dyn64"])
+def test_drct_bf16_close_to_reference(sr_golden, name):
+    cfg, sd, x, y = drct_case(sr_golden, name)
+    m = build(cfg, sd, "bf16")
+    with torch.no_grad():
+        out = m(torch.from_numpy(x).cuda()).cpu().numpy()
+    rng = float(y.max() - y.min())
+    err = np.abs(out - y)
+    psnr = 10 * np.log10(rng ** 2 / np.mean(err.astype(np.float64) ** 2))
+    print(name, "bf16 max err / range", err.max() / rng, "psnr", psnr)
+    assert err.max() / rng < 3e-2
+    assert psnr > 35.0
+
+
+def test_drct_graph_replay_and_weight_update(sr_golden):
+    cfg, sd, x, y = drct_case(sr_golden, "drct_r2_rgb_x4")
+    m = build(cfg, sd, "fp32", use_graph=True)
+    xt = torch.from_numpy(x).cuda()
+    with torch.no_grad():
+        outs = [m(xt).cpu().numpy() for _ in range(4)]        # eager, capture, replay, replay
+    for o in outs:
+        assert rel_err(o, y) < 2e-4
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])
+    # a parameter update must reach the packed arena (and the captured graph)
+    with torch.no_grad():
+        m.get_parameter("conv_last.bias").add_(5.0)
+        o2 = m(xt).cpu().numpy()
+    assert abs(float((o2 - outs[0]).mean()) - 5.0) < 1e-3
+
+
+def test_drct_oracle_random_batch():
+    """Config C2 shape (batch 4, 32x32 LR gray) against the oracle with fresh synthetic weights."""
+    from oracle import sr_ref as R
+    from srad_amd import spec as S
+    cfg = S.DRCTConfig(n_rdg=3)
+    sd = S.synth_state(S.drct_spec(cfg), seed=77, cfg=cfg)
+    x = S.synth_image("c2", (4, 1, 32, 32), seed=1)
+    with torch.no_grad():
+        ref = R.drct_forward(sd, torch.from_numpy(x), cfg).numpy()
+        out = build(cfg, sd, "fp32")(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert rel_err(out, ref) < 2e-4
+
+
+def test_drct_errors():
+    from srad_amd import spec as S
+    cfg = S.DRCTConfig(n_rdg=1)
+    sd = S.synth_state(S.drct_spec(cfg), seed=1, cfg=cfg)
+    m = build(cfg, sd, "fp32")
+    with pytest.raises(ValueError, match="multiple of the window"):
+        m(torch.zeros(1, 1, 30, 32, device="cuda"))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m(torch.zeros(1, 1, 32, 32))
+    with pytest.raises(ValueError, match="channels"):
+        m(torch.zeros(1, 3, 32, 32, device="cuda"))

@@ -1,0 +1,134 @@
+"""GPU: each hand-written kernel on its own against a torch fp32 statement of the same op
+(SURVEY.md §8(a) rows A4-A7, A9, B3, B5).  Tolerances: fp32 mode 1e-4 relative (exact-fp32 MFMA,
+only summation order differs); bf16 mode 3e-2 relative (8-bit mantissa inputs, fp32 accumulate)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp32": 1e-4, "bf16": 3e-2}
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,K,N", [(4096, 180, 540), (1000, 212, 32), (77, 308, 180), (256, 488, 244), (130, 36, 3)])
+def test_linear_variants(dev, prec, M, K, N):
+    from srad_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + K + N)
+    x = torch.randn(M, K + 12, generator=g).to(dev)[:, :K]          # row stride != K
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    r = torch.randn(M, N, generator=g).to(dev)
+    y = ops.gemm(x, w, b, precision=prec)
+    assert _rel(y, F.linear(x, w, b)) < TOL[prec]
+    y = ops.gemm(x, w, b, act=1, precision=prec)                     # GELU
+    assert _rel(y, F.gelu(F.linear(x, w, b))) < TOL[prec]
+    y = ops.gemm(x, w, b, act=2, slope=0.2, alpha=0.2, residual=r, precision=prec)
+    assert _rel(y, F.leaky_relu(F.linear(x, w, b), 0.2) * 0.2 + r) < TOL[prec]
+    # LayerNorm prologue + offset store into a wider buffer
+    lg, lb = torch.randn(K, generator=g).to(dev), torch.randn(K, generator=g).to(dev)
+    out = torch.zeros(M, N + 40, device=dev)
+    ops.gemm(x, w, b, ln=(lg, lb), out=out, out_offset=8, precision=prec)
+    ref = F.linear(F.layer_norm(x, (K,), lg, lb, 1e-5), w, b)
+    assert _rel(out[:, 8:8 + N], ref) < TOL[prec]
+    assert float(out[:, :8].abs().max()) == 0 and float(out[:, 8 + N:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(2, 32, 32, 180, 64, 1), (1, 17, 23, 1, 180, 1), (2, 16, 12, 3, 20, 1),
+                                                   (1, 32, 32, 20, 20, 2), (1, 15, 11, 40, 80, 2), (3, 8, 8, 64, 1, 1)])
+def test_conv3x3(dev, prec, B, H, W, Cin, Cout, stride):
+    from srad_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(B * H + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    xn = x.permute(0, 2, 3, 1).reshape(-1, Cin).clone(memory_format=torch.contiguous_format)
+    y = ops.gemm(xn, w, b, B=B, H=H, W=W, stride=stride, act=3, precision=prec)
+    ref = F.relu(F.conv2d(x, w, b, stride=stride, padding=1))
+    Ho, Wo = ref.shape[-2:]
+    assert y.shape == (B * Ho * Wo, Cout)
+    assert _rel(y, ref.permute(0, 2, 3, 1).reshape(-1, Cout)) < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_conv_pixel_shuffle(dev, prec):
+    from srad_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    B, H, W, Cin = 2, 12, 10, 64
+    x = torch.randn(B, Cin, H, W, generator=g).to(dev)
+    w = (torch.randn(256, Cin, 3, 3, generator=g) / 24).to(dev)
+    b = torch.randn(256, generator=g).to(dev)
+    xn = x.permute(0, 2, 3, 1).reshape(-1, Cin).clone(memory_format=torch.contiguous_format)
+    y = ops.gemm(xn, w, b, B=B, H=H, W=W, pixel_shuffle=True, precision=prec)
+    ref = F.pixel_shuffle(F.conv2d(x, w, b, padding=1), 2).permute(0, 2, 3, 1).reshape(-1, 64)
+    assert _rel(y, ref) < TOL[prec]
+
+
+def _attn_ref(qkv, table, B, H, W, ws, shift, heads):
+    from oracle import sr_ref as R
+    d = qkv.shape[1] // 3
+    N = ws * ws
+    x = qkv.view(B, H, W, 3 * d)
+    if shift:
+        x = torch.roll(x, (-shift, -shift), (1, 2))
+    xw = R.window_partition(x, ws).view(-1, N, 3, heads, d // heads).permute(2, 0, 3, 1, 4)
+    q, k, v = xw[0] * (d // heads) ** -0.5, xw[1], xw[2]
+    a = q @ k.transpose(-2, -1)
+    bias = table[R.rel_pos_index(ws).view(-1)].view(N, N, -1).permute(2, 0, 1)
+    a = a + bias.unsqueeze(0)
+    if shift:
+        m = R.calculate_mask(H, W, ws, shift)
+        nW = m.shape[0]
+        a = (a.view(B, nW, heads, N, N) + m.unsqueeze(1).unsqueeze(0)).view(-1, heads, N, N)
+    o = (torch.softmax(a, -1) @ v).transpose(1, 2).reshape(-1, ws, ws, d)
+    o = R.window_reverse(o, ws, H, W)
+    if shift:
+        o = torch.roll(o, (shift, shift), (1, 2))
+    return o.reshape(B * H * W, d)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("B,H,W,ws,shift,d,heads", [
+    (2, 32, 32, 8, 0, 180, 6), (2, 32, 32, 8, 4, 212, 4), (1, 32, 32, 8, 0, 244, 2), (1, 32, 32, 8, 4, 276, 6),
+    (1, 32, 32, 8, 0, 308, 4), (1, 64, 32, 8, 4, 212, 4), (2, 16, 16, 4, 2, 180, 6), (1, 8, 8, 2, 1, 212, 4),
+    (1, 64, 64, 16, 8, 276, 6), (1, 48, 24, 24, 12, 60, 2)])
+def test_window_attention(dev, prec, B, H, W, ws, shift, d, heads):
+    from srad_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(ws * 100 + d)
+    qkv = torch.randn(B * H * W, 3 * d, generator=g)
+    qkv[:, :2 * d] *= 1.5                                           # make softmax peaky
+    table = torch.randn((2 * ws - 1) ** 2, heads, generator=g)
+    ref = _attn_ref(qkv, table, B, H, W, ws, shift, heads)
+    out = ops.window_attention(qkv.to(dev), table.to(dev), B, H, W, ws, shift, heads, precision=prec)
+    assert _rel(out.cpu(), ref) < TOL[prec]
+
+
+def test_layernorm(dev):
+    from srad_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = (torch.randn(1000, 308, generator=g) * 3 + 1).to(dev)[:, :180]
+    w, b = torch.randn(180, generator=g).to(dev), torch.randn(180, generator=g).to(dev)
+    assert _rel(ops.layernorm(x, w, b), F.layer_norm(x, (180,), w, b, 1e-5)) < 1e-5
+
+
+def test_bad_arguments_raise(dev):
+    from srad_amd import ops
+    qkv = torch.zeros(30 * 30, 3 * 12, device=dev)
+    with pytest.raises(RuntimeError, match="multiple of window"):
+        ops.window_attention(qkv, torch.zeros(225, 2, device=dev), 1, 30, 30, 8, 0, 2)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.layernorm(torch.zeros(4, 8), torch.zeros(8), torch.zeros(8))
