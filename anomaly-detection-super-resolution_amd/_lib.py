@@ -81,9 +81,14 @@ _SIG = {
     "srad_op_gemm": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int,
                                _P, _P, _P, C.c_int, C.c_float, C.c_float, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int,
                                _P, C.c_size_t, _P]),
+    "srad_bench_gemm": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int,
+                                  _P, _P, _P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t,
+                                  C.c_int, C.POINTER(C.c_float), _P]),
+    "srad_bench_window_attn": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
     "srad_op_gemm_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "srad_op_window_attn": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                      C.c_int, _P]),
+                                      C.c_int, C.c_int, _P]),
     "srad_op_layernorm": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
 }
 

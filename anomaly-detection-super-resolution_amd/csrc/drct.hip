@@ -22,6 +22,8 @@ struct SwinW {
 
 }  // namespace
 
+static inline int hdp_of(int d, int heads) { return srad_round_up(d / heads, 4); }
+
 struct srad_drct {
   srad_drct_config cfg;
   ParamTable pt;
@@ -29,7 +31,7 @@ struct srad_drct {
   std::vector<ConvW> up;
   int pe_g, pe_b, norm_g, norm_b;
   std::vector<SwinW> blocks;      // n_rdg * 5
-  int dmax, hmax;                 // widest block dim / hidden
+  int dmax, hmax, qkvmax;         // widest block dim / hidden / head-padded qkv row
   GraphCache gc;
 };
 
@@ -61,11 +63,11 @@ DrctWs plan_ws(const srad_drct* h, int B, int H, int W, void* base, size_t cap) 
   const int E = c.embed_dim, D = E + 4 * c.gc;
   Bump bp(base, cap);
   DrctWs w;
-  w.xin = bp.take(T * c.in_chans);
+  w.xin = bp.take(T * SRAD_IMG_CPAD);
   w.feat0 = bp.take(T * E);
   w.dense0 = bp.take(T * D);
   w.dense1 = bp.take(T * D);
-  w.qkv = bp.take(T * 3 * h->dmax);
+  w.qkv = bp.take(T * h->qkvmax);
   w.attn = bp.take(T * h->dmax);
   w.x1 = bp.take(T * h->dmax);
   w.hid = bp.take(T * h->hmax);
@@ -90,11 +92,15 @@ int forward_body(srad_drct* h, const float* x, int B, int H, int W, float* y, co
   const int E = c.embed_dim, D = E + 4 * c.gc;
   const float mean3[3] = {c.in_chans == 3 ? 0.4488f : 0.f, c.in_chans == 3 ? 0.4371f : 0.f, c.in_chans == 3 ? 0.4040f : 0.f};
 
+  // pad columns of the head-padded q|k|v rows are multiplied by 0 in the attention kernel: keep them
+  // finite whatever the caller's workspace held
+  SRAD_CHECK_HIP(hipMemsetAsync(w.qkv, 0, (size_t)T * h->qkvmax * sizeof(float), s));
   // (x - mean) * img_range, NCHW -> NHWC            (drct.py:887-888)
-  SRAD_TRY(srad_launch_nchw_to_nhwc(x, w.xin, B, c.in_chans, H, W, mean3, c.img_range, s));
+  SRAD_TRY(srad_launch_nchw_to_nhwc(x, w.xin, B, c.in_chans, SRAD_IMG_CPAD, H, W, mean3, c.img_range, s));
   // conv_first                                       (drct.py:892)
   {
-    GemmParams p = base_gemm(h, h->conv_first, w.xin, c.in_chans, T, w.feat0, E);
+    GemmParams p = base_gemm(h, h->conv_first, w.xin, SRAD_IMG_CPAD, T, w.feat0, E);
+    p.Cin = SRAD_IMG_CPAD;                 // padded image channels; the packed weight is zero there
     conv_geom(p, H, W);
     SRAD_TRY(srad_launch_gemm(prec, p, s));
   }
@@ -109,13 +115,16 @@ int forward_body(srad_drct* h, const float* x, int B, int H, int W, float* y, co
       const int d = sw.d;
       // norm1 + qkv                                   (drct.py:477, 278)
       {
-        GemmParams p = base_gemm(h, sw.qkv, cur, D, T, w.qkv, 3 * d);
+        const int hdp = hdp_of(d, sw.heads);
+        GemmParams p = base_gemm(h, sw.qkv, cur, D, T, w.qkv, 3 * sw.heads * hdp);
+        p.hsplit_hd = d / sw.heads; p.hsplit_hdp = hdp;      // head-padded q|k|v rows for the attention kernel
         p.ln_g = h->pt.fptr(sw.n1g); p.ln_b = h->pt.fptr(sw.n1b);
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
       // shifted-window attention                      (drct.py:481-504, 281-299)
       {
-        AttnParams a{w.qkv, w.attn, h->pt.fptr(sw.table), B, H, W, c.window_size, sw.shift, d, sw.heads};
+        AttnParams a{w.qkv, w.attn, h->pt.fptr(sw.table), B, H, W, c.window_size, sw.shift, d, sw.heads,
+                     hdp_of(d, sw.heads)};
         SRAD_TRY(srad_launch_window_attn(prec, a, s));
       }
       // proj + shortcut                               (drct.py:300, 509)
@@ -210,7 +219,7 @@ int srad_drct_create(const srad_drct_config* cfg, srad_drct_t** out) {
   h->conv_first = h->pt.add_layer("conv_first", E, C, 9, true);
   h->pe_g = h->pt.add_raw("patch_embed.norm.weight", E);
   h->pe_b = h->pt.add_raw("patch_embed.norm.bias", E);
-  h->dmax = 0; h->hmax = 0;
+  h->dmax = 0; h->hmax = 0; h->qkvmax = 0;
   for (int i = 0; i < cfg->n_rdg; ++i) {
     for (int k = 0; k < 5; ++k) {
       SwinW sw;
@@ -234,6 +243,7 @@ int srad_drct_create(const srad_drct_config* cfg, srad_drct_t** out) {
       sw.fc2 = h->pt.add_layer(p + "mlp.fc2", sw.d, sw.hidden, 1, true);
       sw.adjust = h->pt.add_layer("layers." + std::to_string(i) + ".adjust" + std::to_string(k + 1), k < 4 ? cfg->gc : E, sw.d, 1, true);
       if (sw.d > h->dmax) h->dmax = sw.d;
+      if (3 * sw.heads * hdp_of(sw.d, sw.heads) > h->qkvmax) h->qkvmax = 3 * sw.heads * hdp_of(sw.d, sw.heads);
       if (sw.hidden > h->hmax) h->hmax = sw.hidden;
       h->blocks.push_back(sw);
     }

@@ -3,13 +3,18 @@
 //  cyclic shift 482-504, calculate_mask 449-470, relative_position_index 250-260).
 //
 // One workgroup (4 waves) = one (window, head, 64-query tile).  It gathers the window's tokens
-// straight from the raster-ordered qkv tensor (cyclic shift and window partition are index
+// straight from the raster-ordered q/k/v tensor (cyclic shift and window partition are index
 // arithmetic, never copies), streams the window's keys in chunks of 64 with an online softmax
 // (so N = ws^2 of 4 ... 4096 tokens all take the same path), adds the relative-position bias
 // and the 0/-100 shift mask computed on the fly, and scatters P.V back to raster order.
 //   S = (q*scale) k^T : MFMA, A = Q tile in LDS, B = K chunk in LDS (both head-dim contiguous)
 //   softmax           : C-layout registers, 16-lane xor-shuffle row reductions
-//   O += P V          : P through LDS (per-wave 16-row slab), V chunk staged transposed
+//   O += P V          : P through LDS (per-wave 16-row slab); V stays row-major in LDS and is read
+//                       as the MFMA B operand with ds_read_b64_tr_b16 (hardware transpose read)
+//
+// Input layout ("head-padded"): row t = [q | k | v], each [heads][hdp] floats, hdp = head_dim
+// rounded up to a multiple of 4 so every (token, head) slice is float4-addressable.  The QKV GEMM
+// epilogue writes this layout directly (GemmParams::hsplit_*); pad columns are never used as data.
 #include "srad_common.h"
 
 namespace {
@@ -18,22 +23,31 @@ template <int PREC> struct AT;
 template <> struct AT<SRAD_PREC_BF16> { using type = __bf16; static constexpr int PAD = 8; };
 template <> struct AT<SRAD_PREC_F32>  { using type = float;  static constexpr int PAD = 4; };
 
-struct WinGeom {
-  int b, wy, wx;
-};
+template <int PREC>
+__device__ __forceinline__ void store4(typename AT<PREC>::type* dst, f32x4 v) {
+  if constexpr (PREC == SRAD_PREC_BF16) {
+    bf16x4 h;
+    h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+    *reinterpret_cast<bf16x4*>(dst) = h;
+  } else {
+    *reinterpret_cast<f32x4*>(dst) = v;
+  }
+}
 
 template <int PREC, int NT_O>
 __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p, const int tbl_in_lds) {
   using T = typename AT<PREC>::type;
   constexpr int PAD = AT<PREC>::PAD;
   constexpr int HDP = NT_O * 16;
-  constexpr int HS = HDP + PAD;      // Q/K row stride (elements)
-  constexpr int KS = 64 + PAD;       // Vt / P row stride
+  constexpr int HS = HDP + PAD;      // Q/K/V row stride (elements)
+  constexpr int KS = 64 + PAD;       // P row stride
+  constexpr int V4R = HDP / 4;       // float4 per staged row
+  constexpr int NLV = 64 * V4R / 256;  // float4 per thread per 64-row tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* Qs = reinterpret_cast<T*>(smem);
   T* Ks = Qs + 64 * HS;
-  T* Vt = Ks + 64 * HS;
-  T* Ps = Vt + HDP * KS;
+  T* Vs = Ks + 64 * HS;
+  T* Ps = Vs + 64 * HS;
   int* tokq = reinterpret_cast<int*>(Ps + 64 * KS);
   int* tokk = tokq + 64;
   int* infq = tokk + 64;             // packed (region << 16) | (py << 8) | px
@@ -42,7 +56,8 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p, co
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const int ws = p.ws, N = ws * ws, d = p.d, heads = p.heads, hd = d / heads;
+  const int ws = p.ws, N = ws * ws, d = p.d, heads = p.heads, hd = d / heads, hdp = p.hdp;
+  const int ldq = 3 * heads * hdp;
   const int h = blockIdx.y;
   const int nWx = p.W / ws, nW = (p.H / ws) * nWx;
   const int win = blockIdx.z;
@@ -63,22 +78,46 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p, co
     inf = ((rh * 3 + rw) << 16) | (py << 8) | px;
   };
 
-  if (tid < 64) {
+  // tokens of the query tile (threads 0..63) and of the first key chunk (threads 64..127)
+  if (tid < 128) {
+    const int pos = tid < 64 ? q0 + tid : tid - 64;
     int tok = 0, inf = 0;
-    if (q0 + tid < N) token_info(q0 + tid, tok, inf);
-    tokq[tid] = tok; infq[tid] = inf;
+    if (pos < N) token_info(pos, tok, inf);
+    if (tid < 64) { tokq[tid] = tok; infq[tid] = inf; }
+    else { tokk[tid - 64] = tok; infk[tid - 64] = inf; }
   }
   if (tbl_in_lds)
     for (int i = tid; i < tw * tw; i += 256) tbl[i] = p.table[(size_t)i * heads + h];
   __syncthreads();
 
-  // ---- stage Q (scaled) ----
-  for (int idx = tid; idx < 64 * HDP; idx += 256) {
-    const int row = idx / HDP, c = idx - row * HDP;
-    float v = 0.f;
-    if (c < hd && q0 + row < N) v = p.qkv[(size_t)tokq[row] * (3 * d) + h * hd + c] * scale;
-    Qs[row * HS + c] = (T)v;
-  }
+  // All global loads are unconditional on clamped addresses and masked by a multiply afterwards:
+  // a load inside a per-element branch is waited for before the next one issues.
+  f32x4 qv[NLV], kv[NLV], vv[NLV];
+  auto load_tile = [&](const int* toks, int which, f32x4 (&dst)[NLV]) {
+#pragma unroll
+    for (int i = 0; i < NLV; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx / V4R, c = (idx - row * V4R) * 4;
+      dst[i] = *reinterpret_cast<const f32x4*>(p.qkv + (size_t)toks[row] * ldq + (which * heads + h) * hdp + min(c, hdp - 4));
+    }
+  };
+  auto store_tile = [&](T* base, int first, float mul, const f32x4 (&src)[NLV]) {
+#pragma unroll
+    for (int i = 0; i < NLV; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx / V4R, c = (idx - row * V4R) * 4;
+      const float rk = (first + row < N) ? mul : 0.f;
+      f32x4 m;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = (c + e < hd) ? rk : 0.f;
+      store4<PREC>(base + row * HS + c, src[i] * m);
+    }
+  };
+
+  load_tile(tokq, 0, qv);
+  load_tile(tokk, 1, kv);
+  load_tile(tokk, 2, vv);
+  store_tile(Qs, q0, scale, qv);
 
   f32x4 o[NT_O];
 #pragma unroll
@@ -91,24 +130,19 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p, co
   const int nchunk = (N + 63) / 64;
   for (int kc = 0; kc < nchunk; ++kc) {
     const int k0 = kc * 64;
-    __syncthreads();                       // previous chunk fully consumed (and Q staged)
-    if (tid < 64) {
-      int tok = 0, inf = 0;
-      if (k0 + tid < N) token_info(k0 + tid, tok, inf);
-      tokk[tid] = tok; infk[tid] = inf;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 64 * HDP; idx += 256) {
-      const int row = idx / HDP, c = idx - row * HDP;
-      float kv = 0.f, vv = 0.f;
-      if (c < hd && k0 + row < N) {
-        const float* src = p.qkv + (size_t)tokk[row] * (3 * d) + h * hd + c;
-        kv = src[d];
-        vv = src[2 * d];
+    if (kc > 0) {
+      __syncthreads();                     // previous chunk fully consumed
+      if (tid < 64) {
+        int tok = 0, inf = 0;
+        if (k0 + tid < N) token_info(k0 + tid, tok, inf);
+        tokk[tid] = tok; infk[tid] = inf;
       }
-      Ks[row * HS + c] = (T)kv;
-      Vt[c * KS + row] = (T)vv;
+      __syncthreads();
+      load_tile(tokk, 1, kv);
+      load_tile(tokk, 2, vv);
     }
+    store_tile(Ks, k0, 1.f, kv);
+    store_tile(Vs, k0, 1.f, vv);
     __syncthreads();
 
     // ---- S = Q K^T for this wave's 16 query rows x 64 keys ----
@@ -128,14 +162,12 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p, co
     } else {
 #pragma unroll
       for (int kk = 0; kk < HDP; kk += 16) {
-        const float4 a = *reinterpret_cast<const float4*>(Qs + (wave * 16 + fr) * HS + kk + 4 * fq);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(Qs + (wave * 16 + fr) * HS + kk + 4 * fq);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float4 bb = *reinterpret_cast<const float4*>(Ks + (j * 16 + fr) * HS + kk + 4 * fq);
-          s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bb.x, s[j], 0, 0, 0);
-          s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bb.y, s[j], 0, 0, 0);
-          s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bb.z, s[j], 0, 0, 0);
-          s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bb.w, s[j], 0, 0, 0);
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(Ks + (j * 16 + fr) * HS + kk + 4 * fq);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bb[e], s[j], 0, 0, 0);
         }
       }
     }
@@ -188,32 +220,42 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p, co
 
     // ---- O += P V ----
     if constexpr (PREC == SRAD_PREC_BF16) {
+      // B operand (V[key][col], key = 8*fq + 0..7 contiguous per lane) comes from the row-major V tile
+      // through two transposing reads: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3
+      // of a 4x16 block and receives column (lane&15) of its 4 rows.
+      const int tq = fr >> 2, tp = fr & 3;
 #pragma unroll
       for (int kk = 0; kk < 64; kk += 32) {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ps + (wave * 16 + fr) * KS + kk + 8 * fq);
 #pragma unroll
         for (int j = 0; j < NT_O; ++j) {
-          const bf16x8 bb = *reinterpret_cast<const bf16x8*>(Vt + (j * 16 + fr) * KS + kk + 8 * fq);
+          typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+          const T* r0 = Vs + (kk + 8 * fq + tq) * HS + j * 16 + 4 * tp;
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0 + 4 * HS));
+          bf16x8 bb;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { bb[e] = lo[e]; bb[4 + e] = hi[e]; }
           o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, o[j], 0, 0, 0);
         }
       }
     } else {
 #pragma unroll
       for (int kk = 0; kk < 64; kk += 16) {
-        const float4 a = *reinterpret_cast<const float4*>(Ps + (wave * 16 + fr) * KS + kk + 4 * fq);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(Ps + (wave * 16 + fr) * KS + kk + 4 * fq);
 #pragma unroll
         for (int j = 0; j < NT_O; ++j) {
-          const float4 bb = *reinterpret_cast<const float4*>(Vt + (j * 16 + fr) * KS + kk + 4 * fq);
-          o[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bb.x, o[j], 0, 0, 0);
-          o[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bb.y, o[j], 0, 0, 0);
-          o[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bb.z, o[j], 0, 0, 0);
-          o[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bb.w, o[j], 0, 0, 0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float bv = Vs[(kk + 4 * fq + e) * HS + j * 16 + fr];
+            o[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bv, o[j], 0, 0, 0);
+          }
         }
       }
     }
   }
 
-  // ---- normalise and scatter back to raster order ----
+  // ---- normalise and scatter back to raster order ([T][d], plain head-major columns) ----
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int row = wave * 16 + fq * 4 + e;
@@ -235,7 +277,7 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
   constexpr int HDP = NT_O * 16, HS = HDP + PAD, KS = 64 + PAD;
   const int N = p.ws * p.ws;
   const int tw = 2 * p.ws - 1;
-  size_t base = (size_t)(2 * 64 * HS + HDP * KS + 64 * KS) * sizeof(T) + 4 * 64 * sizeof(int);
+  size_t base = (size_t)(3 * 64 * HS + 64 * KS) * sizeof(T) + 4 * 64 * sizeof(int);
   base = srad_align_up(base, 16);
   const int tbl_in_lds = (base + (size_t)tw * tw * 4) <= 150 * 1024 ? 1 : 0;
   const size_t lds = base + (tbl_in_lds ? (size_t)tw * tw * 4 : 0);
@@ -271,5 +313,7 @@ int srad_launch_window_attn(int prec, const AttnParams& p, hipStream_t stream) {
   SRAD_REQUIRE(p.H % p.ws == 0 && p.W % p.ws == 0, "window_attn: %dx%d not a multiple of window %d", p.H, p.W, p.ws);
   SRAD_REQUIRE(p.d % p.heads == 0, "window_attn: dim %d not divisible by heads %d", p.d, p.heads);
   SRAD_REQUIRE(p.shift >= 0 && p.shift < p.ws, "window_attn: shift %d must be in [0, ws)", p.shift);
+  SRAD_REQUIRE(p.hdp >= p.d / p.heads && p.hdp % 4 == 0 && ((uintptr_t)p.qkv & 15) == 0,
+               "window_attn: head-padded layout needs hdp %% 4 == 0 and hdp >= head_dim (hdp=%d)", p.hdp);
   return prec == SRAD_PREC_BF16 ? launch_attn_prec<SRAD_PREC_BF16>(p, stream) : launch_attn_prec<SRAD_PREC_F32>(p, stream);
 }

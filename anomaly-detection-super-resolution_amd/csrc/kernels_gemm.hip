@@ -14,159 +14,243 @@
 namespace {
 
 template <int PREC> struct PrecT;
-template <> struct PrecT<SRAD_PREC_BF16> { using type = __bf16; static constexpr int STRIDE = 40; };
-template <> struct PrecT<SRAD_PREC_F32>  { using type = float;  static constexpr int STRIDE = 36; };
+template <> struct PrecT<SRAD_PREC_BF16> { using type = __bf16; static constexpr int PAD = 8; };
+template <> struct PrecT<SRAD_PREC_F32>  { using type = float;  static constexpr int PAD = 4; };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <int PREC, int BM, int BN, int WAVES_M, int WAVES_N>
+// CPS = 32-wide K chunks per stage.  A whole stage (up to CPS*32 columns of K for the BM rows of A
+// and the BN rows of W) is loaded with every load in flight at once, written to LDS, and consumed by
+// the MFMAs while the next stage's loads are already in flight in registers.  At these sizes
+// (K = 180..1728, operands L2/MALL resident) the kernel is latency bound, so the stage is made as
+// deep as LDS allows instead of looping over 32-wide slices.
+//
+// Rules this kernel is written to (each one measured on MI355X; DESIGN.md "GEMM: what made it slow"):
+//   * every global load is UNCONDITIONAL on a clamped, always-valid address.  A load inside a
+//     per-element branch is waited for before the next one issues.
+//   * every independent load (first A/W stage, bias, residual, LayerNorm gamma/beta) is issued at the
+//     top of the kernel, so a workgroup pays ONE memory latency, not one per phase.
+//   * nothing consumes a loaded register inside load_*(): LayerNorm / conv zero-fill are applied when
+//     the registers are written to LDS, so the loads stay in flight across the MFMAs.
+//   * LayerNorm statistics come from the A registers themselves (the 8 lanes that share a row hold
+//     its whole K <= 320), not from a second pass over memory.
+//   * mode switches (LayerNorm, conv gather, special epilogues) are template parameters.
+//   * the kernel is VALU-issue bound (one wave per SIMD, ~4 cycles per instruction), so addresses are
+//     uniform 64-bit bases (SALU) plus per-thread 32-bit byte offsets computed once; K padding is not
+//     masked at all (the packed weight is zero there and the clamped A values are finite).
+//   * activations always have a channel count / row stride that is a multiple of 4 floats.
+// SPECIAL = pixel-shuffle scatter / head-padded columns / pooled sums in the epilogue.
+template <int PREC, int BM, int BN, int WAVES_M, int WAVES_N, int CPS, bool LN, bool CONV, bool SPECIAL>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
-  constexpr int BK = 32;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MT = WM / 16, NT = WN / 16;
   constexpr int RPT = BM / 32;                       // A rows staged per thread
+  constexpr int CPA = LN ? CPS + (PREC == SRAD_PREC_BF16 ? 2 : 6) : CPS;   // LN: the whole K (<= 320) stays resident
   using T = typename PrecT<PREC>::type;
-  constexpr int ST = PrecT<PREC>::STRIDE;
+  constexpr int PADE = PrecT<PREC>::PAD;
+  constexpr int STA = CPA * 32 + PADE;               // LDS row stride of A (elements)
+  constexpr int STW = CPS * 32 + PADE;               // LDS row stride of W
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  static_assert(!(LN && CONV), "LayerNorm fusion is for row-identity A only");
+  static_assert(!LN || CPA * 32 >= 320, "LayerNorm variants keep K <= 320 resident");
 
-  __shared__ __attribute__((aligned(16))) T As[BM * ST];
-  __shared__ __attribute__((aligned(16))) T Ws[BN * ST];
-  __shared__ float s_mean[BM];
-  __shared__ float s_rstd[BM];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* As = reinterpret_cast<T*>(smem);
+  T* Ws = As + BM * STA;
+  float* s_g = reinterpret_cast<float*>(Ws + BN * STW);   // LN only: [CPA*32] gamma, [CPA*32] beta
+  float* s_b = s_g + CPA * 32;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm0 = (wave / WAVES_N) * WM;
   const int wn0 = (wave % WAVES_N) * WN;
-  const int m0 = blockIdx.y * BM;
-  const int n0 = blockIdx.x * BN;
-
-  const bool conv = (p.ntaps == 9) || (p.stride != 1);
-  const bool vec = ((p.Cin & 3) == 0) && ((p.ldx & 3) == 0);
+  // XCD-aware tile mapping: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so
+  // linear id L runs on XCD L % 8.  Give every XCD a contiguous range of (m-tile, n-tile) pairs with
+  // n fastest: all N-tiles of one row-tile then share one L2 and the A rows are fetched from the
+  // Infinity Cache once instead of once per N-tile.  Pure speed: any placement is still correct.
+  int m_tile, n_tile;
+  {
+    const int nx = gridDim.x, total = gridDim.x * gridDim.y;
+    const int L = blockIdx.x + nx * blockIdx.y;
+    const int xcd = L & 7, slot = L >> 3;
+    const int q = total >> 3, r = total & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    m_tile = t / nx;
+    n_tile = t - m_tile * nx;
+  }
+  const int m0 = m_tile * BM;
+  const int n0 = n_tile * BN;
   const int Kp = p.ntaps * p.Cp;
+  const char* const Xb = reinterpret_cast<const char*>(p.X);
+  const int fr = lane & 15, fq = lane >> 4;
 
-  // ---- per-thread A row bookkeeping (rows tid/8 + 32*i, float4 column tid%8) ----
+  // ---- per-thread A bookkeeping: rows tid/8 + 32*i, float4 column tid%8 of each 32-wide chunk.
+  //      a_off[i] = byte offset of (row / centre pixel, column tid%8 * 4) from X, computed once. ----
   const int col4 = tid & 7;
-  int r_b[RPT], r_oy[RPT], r_ox[RPT];
-  bool r_ok[RPT];
+  unsigned a_off[RPT];
+  [[maybe_unused]] int r_iy[RPT], r_ix[RPT];         // conv: top-left input coordinate of the 3x3 window
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
-    const int m = m0 + (tid >> 3) + 32 * i;
-    r_ok[i] = m < p.M;
-    if (conv) {
+    const int mm = min(m0 + (tid >> 3) + 32 * i, p.M - 1);
+    if constexpr (CONV) {
       const int hw = p.Ho * p.Wo;
-      const int mm = r_ok[i] ? m : 0;
-      r_b[i] = mm / hw;
-      const int rem = mm - r_b[i] * hw;
-      r_oy[i] = rem / p.Wo;
-      r_ox[i] = rem - r_oy[i] * p.Wo;
+      const int bb = mm / hw;
+      const int rem = mm - bb * hw;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const int pad = p.ntaps == 9 ? 1 : 0;
+      r_iy[i] = oy * p.stride - pad;
+      r_ix[i] = ox * p.stride - pad;
+      a_off[i] = (unsigned)(((bb * p.Hi + oy * p.stride) * p.Wi + ox * p.stride) * p.ldx + col4 * 4) * 4u;
     } else {
-      r_b[i] = r_ok[i] ? m : 0; r_oy[i] = 0; r_ox[i] = 0;
+      a_off[i] = (unsigned)(mm * p.ldx + col4 * 4) * 4u;
     }
   }
 
-  // ---- optional LayerNorm statistics for this tile's rows (two-pass, biased variance) ----
-  const bool ln = p.ln_g != nullptr;
-  if (ln) {
-    constexpr int TPR = 256 / BM;                    // threads per row (4 or 2)
-    const int row = tid / TPR, sub = tid % TPR;
-    const int m = m0 + row;
-    float s = 0.f;
-    const float* xr = p.X + (size_t)(m < p.M ? m : 0) * p.ldx;
-    for (int c = sub; c < p.Cin; c += TPR) s += xr[c];
-#pragma unroll
-    for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o);
-    const float mean = s / (float)p.Cin;
-    float v = 0.f;
-    for (int c = sub; c < p.Cin; c += TPR) { const float d = xr[c] - mean; v += d * d; }
-#pragma unroll
-    for (int o = 1; o < TPR; o <<= 1) v += __shfl_xor(v, o);
-    if (sub == 0) { s_mean[row] = mean; s_rstd[row] = rsqrtf(v / (float)p.Cin + p.ln_eps); }
-    __syncthreads();
-  }
-
-  const int nchunk_c = p.Cp / BK;
+  const int nchunk_c = p.Cp / 32;
   const int nchunks = p.ntaps * nchunk_c;
+  const int nstages = (nchunks + CPS - 1) / CPS;
 
-  float4 a_reg[RPT];
-  constexpr int W_SEGS = (PREC == SRAD_PREC_BF16) ? 4 : 8;      // 16-byte segments per W row chunk
-  constexpr int W_PT = (BN * W_SEGS + 255) / 256;
-  uint4 w_reg[W_PT];
+  f32x4 a_reg[RPT][CPA];
+  [[maybe_unused]] unsigned a_ok = 0u;                         // conv: bit (i*CPS + j) = tap inside the image
+  constexpr int W_SEGS = 32 * (int)sizeof(T) / 16;           // 16-byte segments per chunk per W row
+  static_assert(CPS * W_SEGS == 32, "W stage rows are 32 x 16 bytes");
+  constexpr int W_PT = BN / 8;                                // rows tid/32 + 8*j, segment tid%32
+  u32x4 w_reg[W_PT];
+  const int w_seg = tid & 31;
+  const unsigned w_off0 = (unsigned)((tid >> 5) * Kp) * (unsigned)sizeof(T);
+  const char* const Wb = reinterpret_cast<const char*>(p.Wp) + (size_t)n0 * Kp * sizeof(T);
+  [[maybe_unused]] int ld_tap = 0, ld_c0 = 0;                  // conv: running (tap, channel) of the next chunk
 
-  auto load_chunk = [&](int ch) {
-    const int tap = ch / nchunk_c;
-    const int c0 = (ch - tap * nchunk_c) * BK;
-    const int ky = tap / 3, kx = tap - ky * 3;
-    const int c = c0 + col4 * 4;
+  auto load_a = [&](int st) {
+    const int ch0 = st * CPS;
+    if constexpr (CONV) a_ok = 0u;
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      bool ok = r_ok[i];
-      size_t pix;
-      if (conv) {
-        const int iy = r_oy[i] * p.stride + (p.ntaps == 9 ? ky - 1 : 0);
-        const int ix = r_ox[i] * p.stride + (p.ntaps == 9 ? kx - 1 : 0);
-        ok = ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-        pix = ((size_t)r_b[i] * p.Hi + (ok ? iy : 0)) * p.Wi + (ok ? ix : 0);
+    for (int j = 0; j < CPA; ++j) {
+      if constexpr (CONV) {
+        const int ky = ld_tap / 3, kx = ld_tap - ky * 3;                 // ld_tap <= 8: cheap scalar math
+        const int dy = p.ntaps == 9 ? ky : 0, dx = p.ntaps == 9 ? kx : 0;
+        const int pad = p.ntaps == 9 ? 1 : 0;
+        const int delta = (((dy - pad) * p.Wi + (dx - pad)) * p.ldx + ld_c0) * 4;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+          const int iy = r_iy[i] + dy, ix = r_ix[i] + dx;
+          const bool ok = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+          const unsigned off = a_off[i] + (unsigned)(ok ? delta : ld_c0 * 4);   // centre pixel when outside
+          a_reg[i][j] = *reinterpret_cast<const f32x4*>(Xb + off);
+          a_ok |= (ok ? 1u : 0u) << (i * CPS + j);
+        }
+        if (ch0 + j + 1 < nchunks) {                                       // clamp: never step past the end
+          ld_c0 += 32;
+          if (ld_c0 == p.Cp) { ld_c0 = 0; ++ld_tap; }
+        }
       } else {
-        pix = (size_t)r_b[i];
+        const char* sb = Xb + (size_t)min(ch0 + j, nchunks - 1) * 128;    // uniform base, SALU
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) a_reg[i][j] = *reinterpret_cast<const f32x4*>(sb + a_off[i]);
       }
-      if (ok) {
-        const float* src = p.X + pix * p.ldx + c;
-        if (vec) {
-          if (c < p.Cin) v = *reinterpret_cast<const float4*>(src);
+    }
+  };
+  auto load_w = [&](int st) {
+    const int ch0 = st * CPS;
+    const int nch = min(CPS, nchunks - ch0);
+    const unsigned woff = w_off0 + (unsigned)((w_seg < nch * W_SEGS ? w_seg : 0) * 16);
+    const char* wb = Wb + (size_t)ch0 * 32 * sizeof(T);
+#pragma unroll
+    for (int j = 0; j < W_PT; ++j)
+      w_reg[j] = *reinterpret_cast<const u32x4*>(wb + (size_t)j * 8 * Kp * sizeof(T) + woff);
+  };
+  [[maybe_unused]] float ln_mu[RPT], ln_rs[RPT];
+  auto store_a = [&]() {
+#pragma unroll
+    for (int j = 0; j < CPA; ++j) {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        f32x4 v = a_reg[i][j];
+        if constexpr (LN) {
+          const f32x4 g4 = *reinterpret_cast<const f32x4*>(s_g + j * 32 + col4 * 4);
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(s_b + j * 32 + col4 * 4);
+          v = (v - ln_mu[i]) * ln_rs[i] * g4 + b4;               // gamma = beta = 0 in the K padding
+        }
+        if constexpr (CONV) {
+          const bool ok = (a_ok >> (i * CPS + j)) & 1u;
+          v = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        T* dst = As + row * STA + j * 32 + col4 * 4;
+        if constexpr (PREC == SRAD_PREC_BF16) {
+          bf16x4 h;
+          h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+          *reinterpret_cast<bf16x4*>(dst) = h;
         } else {
-          if (c + 0 < p.Cin) v.x = src[0];
-          if (c + 1 < p.Cin) v.y = src[1];
-          if (c + 2 < p.Cin) v.z = src[2];
-          if (c + 3 < p.Cin) v.w = src[3];
-        }
-        if (ln) {
-          const int row = (tid >> 3) + 32 * i;
-          const float mu = s_mean[row], rs = s_rstd[row];
-          if (c + 0 < p.Cin) v.x = (v.x - mu) * rs * p.ln_g[c + 0] + p.ln_b[c + 0];
-          if (c + 1 < p.Cin) v.y = (v.y - mu) * rs * p.ln_g[c + 1] + p.ln_b[c + 1];
-          if (c + 2 < p.Cin) v.z = (v.z - mu) * rs * p.ln_g[c + 2] + p.ln_b[c + 2];
-          if (c + 3 < p.Cin) v.w = (v.w - mu) * rs * p.ln_g[c + 3] + p.ln_b[c + 3];
+          *reinterpret_cast<f32x4*>(dst) = v;
         }
       }
-      a_reg[i] = v;
     }
-    const char* wbase = reinterpret_cast<const char*>(p.Wp);
+  };
+  auto store_w = [&]() {
+    char* wdst = reinterpret_cast<char*>(Ws) + ((tid >> 5) * STW) * (int)sizeof(T) + w_seg * 16;
 #pragma unroll
-    for (int j = 0; j < W_PT; ++j) {
-      const int idx = tid + 256 * j;
-      if (idx < BN * W_SEGS) {
-        const int row = idx / W_SEGS, seg = idx - row * W_SEGS;
-        const size_t off = ((size_t)(n0 + row) * Kp + (size_t)ch * BK) * sizeof(T) + (size_t)seg * 16;
-        w_reg[j] = *reinterpret_cast<const uint4*>(wbase + off);
-      }
-    }
+    for (int j = 0; j < W_PT; ++j) *reinterpret_cast<u32x4*>(wdst + j * 8 * STW * (int)sizeof(T)) = w_reg[j];
   };
 
-  auto store_chunk = [&]() {
+  // ---- issue every independent load now: first A/W stage, LN gamma/beta, bias, residual ----
+  load_a(0);
+  load_w(0);
+  [[maybe_unused]] float lg = 0.f, lb = 0.f;
+  if constexpr (LN) {
+    // threads 0 .. CPA*32-1 fetch one gamma/beta each (clamped; zero beyond Cin so K padding stays 0)
+    const int c = min(tid, p.Cin - 1);
+    lg = p.ln_g[c];
+    lb = p.ln_b[c];
+  }
+  int ncol[NT];
+  float bv[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { ncol[j] = n0 + wn0 + j * 16 + fr; bv[j] = 0.f; }
+  if (p.bias) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bv[j] = p.bias[min(ncol[j], p.N - 1)];
+  }
+  float rv[MT][4][NT];
+  if (p.R) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned rrow = (unsigned)(min(m0 + wm0 + i * 16 + fq * 4 + e, p.M - 1) * p.ldr);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) rv[i][e][j] = p.R[rrow + (unsigned)min(ncol[j], p.N - 1)];
+      }
+  }
+
+  if constexpr (LN) {
+    static_assert(CPA * 32 <= 512, "gamma/beta staging uses one or two elements per thread");
+    for (int c = tid; c < CPA * 32; c += 256) {
+      float g = lg, bb = lb;
+      if (c >= 256) { const int cc = min(c, p.Cin - 1); g = p.ln_g[cc]; bb = p.ln_b[cc]; }
+      s_g[c] = c < p.Cin ? g : 0.f;
+      s_b[c] = c < p.Cin ? bb : 0.f;
+    }
+    // row statistics from the registers: the 8 lanes tid%8 of a row hold all of its K
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-      const int row = (tid >> 3) + 32 * i;
-      T* dst = As + row * ST + col4 * 4;
-      if constexpr (PREC == SRAD_PREC_BF16) {
-        bf16x4 h;
-        h[0] = (__bf16)a_reg[i].x; h[1] = (__bf16)a_reg[i].y; h[2] = (__bf16)a_reg[i].z; h[3] = (__bf16)a_reg[i].w;
-        *reinterpret_cast<bf16x4*>(dst) = h;
-      } else {
-        *reinterpret_cast<float4*>(dst) = a_reg[i];
-      }
-    }
+      float s = 0.f, ss = 0.f;
 #pragma unroll
-    for (int j = 0; j < W_PT; ++j) {
-      const int idx = tid + 256 * j;
-      if (idx < BN * W_SEGS) {
-        const int row = idx / W_SEGS, seg = idx - row * W_SEGS;
-        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Ws + row * ST) + seg * 16) = w_reg[j];
+      for (int j = 0; j < CPA; ++j) {
+        const float w = (j * 32 + col4 * 4) < p.Cin ? 1.f : 0.f;     // Cin % 4 == 0: whole float4 in or out
+        const f32x4 vw = a_reg[i][j] * w;
+        s += (vw[0] + vw[1]) + (vw[2] + vw[3]);
+        ss += (vw[0] * vw[0] + vw[1] * vw[1]) + (vw[2] * vw[2] + vw[3] * vw[3]);
       }
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+      const float mean = s / (float)p.Cin;
+      ln_mu[i] = mean;
+      ln_rs[i] = rsqrtf(fmaxf(ss / (float)p.Cin - mean * mean, 0.f) + p.ln_eps);
     }
-  };
+    __syncthreads();                                 // gamma/beta visible
+  }
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -174,84 +258,129 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int fr = lane & 15, fq = lane >> 4;
+  const T* const a_rd = As + (wm0 + fr) * STA + (PREC == SRAD_PREC_BF16 ? 8 : 4) * fq;
+  const T* const w_rd = Ws + (wn0 + fr) * STW + (PREC == SRAD_PREC_BF16 ? 8 : 4) * fq;
 
-  load_chunk(0);
-  for (int ch = 0; ch < nchunks; ++ch) {
-    store_chunk();
+  for (int st = 0; st < nstages; ++st) {
+    if (!LN || st == 0) store_a();
+    store_w();
     __syncthreads();
-    if (ch + 1 < nchunks) load_chunk(ch + 1);
-    if constexpr (PREC == SRAD_PREC_BF16) {
-      bf16x8 a[MT], b[NT];
+    if (st + 1 < nstages) {
+      if constexpr (!LN) load_a(st + 1);
+      load_w(st + 1);
+    }
+    const int nch = min(CPS, nchunks - st * CPS);
+    const T* a_st = a_rd + (LN ? st * CPS * 32 : 0);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const bf16x8*>(As + (wm0 + i * 16 + fr) * ST + 8 * fq);
+    for (int cc = 0; cc < CPS; ++cc) {
+      if (cc < nch) {
+        if constexpr (PREC == SRAD_PREC_BF16) {
+          bf16x8 a[MT], b[NT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const bf16x8*>(Ws + (wn0 + j * 16 + fr) * ST + 8 * fq);
+          for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const bf16x8*>(a_st + i * 16 * STA + cc * 32);
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+          for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const bf16x8*>(w_rd + j * 16 * STW + cc * 32);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    } else {
+          for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        float4 a[MT], b[NT];
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        } else {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const float4*>(As + (wm0 + i * 16 + fr) * ST + ks * 16 + 4 * fq);
+          for (int ks = 0; ks < 2; ++ks) {
+            f32x4 a[MT], b[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const float4*>(Ws + (wn0 + j * 16 + fr) * ST + ks * 16 + 4 * fq);
+            for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(a_st + i * 16 * STA + cc * 32 + ks * 16);
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+            for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4*>(w_rd + j * 16 * STW + cc * 32 + ks * 16);
 #pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            // lane group g holds k = 16*ks + 4*g + e: the e-th MFMA sums k over the four groups,
-            // so e = 0..3 together cover all 16 k of the step (same permutation on A and B).
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j) {
+                // lane group g holds k = 16*ks + 4*g + e: the e-th MFMA sums k over the four groups,
+                // so e = 0..3 together cover all 16 k of the step (same permutation on A and B).
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+              }
           }
+        }
       }
     }
     __syncthreads();
   }
 
   // ---- epilogue: C layout col = lane&15, row = (lane>>4)*4 + e ----
-  const int hw_o = p.Ho * p.Wo;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] += bv[j];
+  if (p.act == SRAD_ACT_GELU) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = gelu_erf(acc[i][j][e]);
+  } else if (p.act == SRAD_ACT_LRELU) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = acc[i][j][e] > 0.f ? acc[i][j][e] : acc[i][j][e] * p.slope;
+  } else if (p.act == SRAD_ACT_RELU) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = fmaxf(acc[i][j][e], 0.f);
+  }
+  unsigned ycol[NT];                                  // element offset of column j inside an output row
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = ncol[j];
+    ycol[j] = (unsigned)n;
+    if constexpr (SPECIAL) {
+      if (p.ps == 2) {
+        const int c = n >> 2, dy = (n >> 1) & 1, dx = n & 1;
+        ycol[j] = (unsigned)((dy * (2 * p.Wo) + dx) * p.ldy + c);
+      } else if (p.hsplit_hd > 0) {
+        const int hh = n / p.hsplit_hd;
+        ycol[j] = (unsigned)(hh * p.hsplit_hdp + (n - hh * p.hsplit_hd));
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int m = m0 + wm0 + i * 16 + fq * 4 + e;
-      if (m >= p.M) continue;
-      size_t ybase;
-      int pb = 0;
-      if (p.ps == 2) {
-        pb = m / hw_o;
-        const int rem = m - pb * hw_o;
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        ybase = ((size_t)pb * (2 * p.Ho) + 2 * oy) * (2 * p.Wo) + 2 * ox;    // output pixel (dy=dx=0)
-      } else {
-        ybase = (size_t)m * p.ldy + p.yoff;
-        if (p.pool) pb = m / hw_o;
+      const bool m_ok = m < p.M;
+      const int mc = m_ok ? m : 0;
+      unsigned yrow = (unsigned)(mc * p.ldy + p.yoff);
+      [[maybe_unused]] int pb = 0;
+      if constexpr (SPECIAL) {
+        if (p.ps == 2 || p.pool) {
+          const int hw_o = p.Ho * p.Wo;
+          pb = mc / hw_o;
+          if (p.ps == 2) {
+            const int rem = mc - pb * hw_o;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            yrow = (unsigned)(((pb * (2 * p.Ho) + 2 * oy) * (2 * p.Wo) + 2 * ox) * p.ldy + p.yoff);
+          }
+        }
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const int n = n0 + wn0 + j * 16 + fr;
-        if (n >= p.N) continue;
-        float v = acc[i][j][e];
-        if (p.bias) v += p.bias[n];
-        if (p.act == SRAD_ACT_GELU) v = gelu_erf(v);
-        else if (p.act == SRAD_ACT_LRELU) v = v > 0.f ? v : v * p.slope;
-        else if (p.act == SRAD_ACT_RELU) v = fmaxf(v, 0.f);
-        v *= p.alpha;
-        if (p.R) v += p.R[(size_t)m * p.ldr + n];
-        if (p.ps == 2) {
-          const int c = n >> 2, dy = (n >> 1) & 1, dx = n & 1;
-          p.Y[(ybase + (size_t)dy * (2 * p.Wo) + dx) * p.ldy + p.yoff + c] = v;
-        } else {
-          p.Y[ybase + n] = v;
+        float v = acc[i][j][e] * p.alpha;
+        if (p.R) v += rv[i][e][j];
+        if (m_ok && ncol[j] < p.N) {
+          p.Y[yrow + ycol[j]] = v;
+          if constexpr (SPECIAL) {
+            if (p.pool) atomicAdd(p.pool + (size_t)pb * p.N + ncol[j], v);
+          }
         }
-        if (p.pool) atomicAdd(p.pool + (size_t)pb * p.N + n, v);
       }
     }
   }
@@ -273,24 +402,63 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, void* __restri
   }
 }
 
-template <int PREC, int BM, int BN, int WMV, int WNV>
-int launch_cfg(const GemmParams& p, hipStream_t s) {
+template <int PREC, int BM, int BN, int WMV, int WNV, bool LN, bool CONV, bool SPECIAL>
+int launch_one(const GemmParams& p, hipStream_t s) {
+  constexpr int CPS = PREC == SRAD_PREC_BF16 ? 8 : 4;
+  constexpr int CPA = LN ? CPS + (PREC == SRAD_PREC_BF16 ? 2 : 6) : CPS;
+  using T = typename PrecT<PREC>::type;
+  constexpr size_t lds = ((size_t)BM * (CPA * 32 + PrecT<PREC>::PAD) + (size_t)BN * (CPS * 32 + PrecT<PREC>::PAD)) * sizeof(T) +
+                         (LN ? 2 * (size_t)CPA * 32 * sizeof(float) : 0);
+  auto kern = gemm_kernel<PREC, BM, BN, WMV, WNV, CPS, LN, CONV, SPECIAL>;
+  static bool configured = false;
+  if (!configured) {
+    SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
-  const int cls = BN == 64 ? SRAD_K_GEMM_64x64 : (BN == 32 ? SRAD_K_GEMM_128x32 : SRAD_K_GEMM_128x16);
+  const int cls = BN == 64 ? SRAD_K_GEMM_BN64 : (BN == 32 ? SRAD_K_GEMM_BN32 : SRAD_K_GEMM_BN16);
   // algorithmic work: 2*M*N*K flops; bytes = A rows once + packed W once + Y once (+ residual)
   const double K = (double)p.ntaps * p.Cin;
   const double wbytes = (double)p.N * K * (PREC == SRAD_PREC_BF16 ? 2 : 4);
   const double abytes = 4.0 * (p.ntaps == 9 ? (double)p.M * p.stride * p.stride : (double)p.M) * p.Cin;
   SradProfScope prof(s, cls, 2.0 * p.M * p.N * K, abytes + wbytes + 4.0 * p.M * p.N * (p.R ? 2 : 1));
-  hipLaunchKernelGGL((gemm_kernel<PREC, BM, BN, WMV, WNV>), grid, dim3(256), 0, s, p);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
   return SRAD_OK;
 }
 
+template <int PREC, int BM, int BN, int WMV, int WNV>
+int launch_cfg(const GemmParams& p, hipStream_t s) {
+  const bool conv = p.ntaps == 9 || p.stride != 1;
+  const bool special = p.ps == 2 || p.hsplit_hd > 0 || p.pool != nullptr;
+  if (conv) {
+    return special ? launch_one<PREC, BM, BN, WMV, WNV, false, true, true>(p, s)
+                   : launch_one<PREC, BM, BN, WMV, WNV, false, true, false>(p, s);
+  }
+  if (p.ln_g) {
+    if constexpr (BM <= 64) {
+      return special ? launch_one<PREC, BM, BN, WMV, WNV, true, false, true>(p, s)
+                     : launch_one<PREC, BM, BN, WMV, WNV, true, false, false>(p, s);
+    } else {
+      return srad_set_error(SRAD_ERR_ARG, "gemm: LayerNorm fusion needs N > 32");
+    }
+  }
+  return special ? launch_one<PREC, BM, BN, WMV, WNV, false, false, true>(p, s)
+                 : launch_one<PREC, BM, BN, WMV, WNV, false, false, false>(p, s);
+}
+
+// Tile choice: the problems are small (M = B*H*W rows, a few thousand), so prefer the largest tile
+// that still yields >= ~1.5 workgroups per CU.
 template <int PREC>
 int launch_prec(const GemmParams& p, hipStream_t s) {
-  if (p.N <= 16) return launch_cfg<PREC, 128, 16, 4, 1>(p, s);
-  if (p.N <= 32) return launch_cfg<PREC, 128, 32, 4, 1>(p, s);
-  return launch_cfg<PREC, 64, 64, 2, 2>(p, s);
+  auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  if (!p.ln_g) {
+    if (p.N <= 16 && tiles(128, 16) >= 384) return launch_cfg<PREC, 128, 16, 4, 1>(p, s);
+    if (p.N <= 32 && tiles(128, 32) >= 384) return launch_cfg<PREC, 128, 32, 4, 1>(p, s);
+  }
+  if (p.N <= 32) return launch_cfg<PREC, 32, 32, 2, 2>(p, s);
+  if (tiles(64, 64) >= 384) return launch_cfg<PREC, 64, 64, 2, 2>(p, s);
+  if (tiles(32, 64) >= 384) return launch_cfg<PREC, 32, 64, 2, 2>(p, s);
+  return launch_cfg<PREC, 32, 32, 2, 2>(p, s);
 }
 
 }  // namespace
@@ -301,6 +469,12 @@ int srad_launch_gemm(int prec, const GemmParams& p, hipStream_t stream) {
   SRAD_REQUIRE(p.ntaps == 1 || p.ntaps == 9, "gemm: ntaps must be 1 or 9 (got %d)", p.ntaps);
   SRAD_REQUIRE(p.ps == 0 || (p.ps == 2 && p.N % 4 == 0), "gemm: pixel-shuffle needs N %% 4 == 0");
   SRAD_REQUIRE(!(p.ln_g && (p.ntaps != 1 || p.stride != 1)), "gemm: LayerNorm fusion only for row-identity A");
+  SRAD_REQUIRE(!(p.ln_g && p.Cin > 320), "gemm: fused LayerNorm supports up to 320 channels (got %d); run srad_launch_layernorm first", p.Cin);
+  SRAD_REQUIRE((double)p.M * (p.ntaps == 9 || p.stride != 1 ? p.stride * p.stride : 1) * p.ldx * 4.0 < 4.0e9 &&
+                   (double)p.M * (p.ps == 2 ? 4 : 1) * p.ldy < 4.0e9,
+               "gemm: tensors above 4 GB are not addressable with the 32-bit offsets this kernel uses");
+  SRAD_REQUIRE((p.Cin & 3) == 0 && (p.ldx & 3) == 0 && ((uintptr_t)p.X & 15) == 0,
+               "gemm: activations need a channel count and row stride that are multiples of 4 floats (Cin=%d ldx=%d)", p.Cin, p.ldx);
   if (p.ntaps == 9 || p.stride != 1 || p.ps || p.pool)
     SRAD_REQUIRE(p.Ho > 0 && p.Wo > 0 && p.M % (p.Ho * p.Wo) == 0, "gemm: M=%d not a multiple of Ho*Wo=%d*%d", p.M, p.Ho, p.Wo);
   int rc = prec == SRAD_PREC_BF16 ? launch_prec<SRAD_PREC_BF16>(p, stream) : launch_prec<SRAD_PREC_F32>(p, stream);

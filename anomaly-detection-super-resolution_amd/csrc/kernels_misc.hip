@@ -31,7 +31,7 @@ struct Prof {
     return e;
   }
 } g_prof;
-const char* const kClassNames[SRAD_K_COUNT] = {"gemm_64x64", "gemm_128x32", "gemm_128x16", "window_attn", "layernorm",
+const char* const kClassNames[SRAD_K_COUNT] = {"gemm_bn64", "gemm_bn32", "gemm_bn16", "window_attn", "layernorm",
                                                "layout", "pack_weight", "score", "misc"};
 }  // namespace
 
@@ -95,16 +95,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   for (int c = lane; c < C; c += 64) yr[c] = (xr[c] - mean) * rstd * g[c] + b[c];
 }
 
-__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int HW,
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int Cpad, int HW,
                                     float m0, float m1, float m2, float scale) {
-  const size_t total = (size_t)B * C * HW;
+  const size_t total = (size_t)B * Cpad * HW;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const size_t pix = i / C;
+    const int c = (int)(i % Cpad);
+    const size_t pix = i / Cpad;
     const int bb = (int)(pix / HW);
     const int hw = (int)(pix - (size_t)bb * HW);
     const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
-    y[i] = (x[((size_t)bb * C + c) * HW + hw] - mean) * scale;
+    const float v = x[((size_t)bb * C + min(c, C - 1)) * HW + hw];
+    y[i] = c < C ? (v - mean) * scale : 0.f;       // channels [C, Cpad) are zero padding
   }
 }
 
@@ -137,13 +138,13 @@ int srad_launch_layernorm(const float* x, int ldx, float* y, int ldy, int rows, 
   return SRAD_OK;
 }
 
-int srad_launch_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, const float* mean3, float scale,
-                             hipStream_t stream) {
-  SRAD_REQUIRE(C >= 1 && C <= 3, "layout: channel count %d unsupported (1..3)", C);
-  const size_t total = (size_t)B * C * H * W;
+int srad_launch_nchw_to_nhwc(const float* x, float* y, int B, int C, int Cpad, int H, int W, const float* mean3,
+                             float scale, hipStream_t stream) {
+  SRAD_REQUIRE(C >= 1 && C <= 3 && Cpad >= C, "layout: channel count %d unsupported (1..3)", C);
+  const size_t total = (size_t)B * Cpad * H * W;
   SradProfScope prof(stream, SRAD_K_LAYOUT, 2.0 * total, 8.0 * total);
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, y, B, C, H * W, mean3[0],
-                     mean3[1], mean3[2], scale);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, y, B, C, Cpad, H * W,
+                     mean3[0], mean3[1], mean3[2], scale);
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
 }

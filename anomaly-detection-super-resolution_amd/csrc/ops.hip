@@ -35,7 +35,68 @@ int srad_op_gemm(int precision, const float* x, int ldx, int B, int Hi, int Wi, 
   p.Wp = scratch; p.N = N; p.bias = bias;
   p.act = act; p.slope = slope; p.alpha = alpha;
   p.R = r; p.ldr = ldr; p.Y = y; p.ldy = ldy; p.yoff = yoff; p.ps = ps; p.pool = nullptr;
+  p.hsplit_hd = 0; p.hsplit_hdp = 0;
   return srad_launch_gemm(precision, p, s);
+}
+
+// Diagnostic: launch the same GEMM `iters` times back to back on `stream` (weights packed once) and
+// return the average device time per launch in microseconds (HIP events; synchronises the stream).
+int srad_bench_gemm(int precision, const float* x, int ldx, int B, int Hi, int Wi, int Cin, const float* w, int N,
+                    int ntaps, int stride, const float* bias, const float* ln_g, const float* ln_b, int act,
+                    const float* r, int ldr, float* y, int ldy, int hsplit_hd, int hsplit_hdp, void* scratch,
+                    size_t scratch_bytes, int iters, float* us_out, void* stream) {
+  SRAD_REQUIRE(x && w && y && scratch && us_out && iters > 0, "bench_gemm: bad argument");
+  const size_t need = srad_packed_bytes(precision, N, Cin, ntaps);
+  SRAD_REQUIRE(scratch_bytes >= need, "bench_gemm: scratch %zu bytes, %zu needed", scratch_bytes, need);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  SRAD_TRY(srad_launch_pack_weight(precision, w, scratch, N, Cin, ntaps, s));
+  GemmParams p{};
+  const int pad = ntaps == 9 ? 1 : 0, k = ntaps == 9 ? 3 : 1;
+  p.Hi = Hi; p.Wi = Wi;
+  p.Ho = (Hi + 2 * pad - k) / stride + 1;
+  p.Wo = (Wi + 2 * pad - k) / stride + 1;
+  p.stride = stride;
+  p.X = x; p.ldx = ldx; p.M = B * p.Ho * p.Wo; p.Cin = Cin; p.Cp = srad_cp(Cin); p.ntaps = ntaps;
+  p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = 1e-5f;
+  p.Wp = scratch; p.N = N; p.bias = bias;
+  p.act = act; p.slope = 0.2f; p.alpha = 1.f;
+  p.R = r; p.ldr = ldr; p.Y = y; p.ldy = ldy; p.yoff = 0; p.ps = 0; p.pool = nullptr;
+  p.hsplit_hd = hsplit_hd; p.hsplit_hdp = hsplit_hdp;
+  for (int i = 0; i < 5; ++i) SRAD_TRY(srad_launch_gemm(precision, p, s));
+  hipEvent_t a, b;
+  SRAD_CHECK_HIP(hipEventCreate(&a));
+  SRAD_CHECK_HIP(hipEventCreate(&b));
+  SRAD_CHECK_HIP(hipEventRecord(a, s));
+  for (int i = 0; i < iters; ++i) SRAD_TRY(srad_launch_gemm(precision, p, s));
+  SRAD_CHECK_HIP(hipEventRecord(b, s));
+  SRAD_CHECK_HIP(hipEventSynchronize(b));
+  float ms = 0.f;
+  SRAD_CHECK_HIP(hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  *us_out = ms * 1e3f / iters;
+  return SRAD_OK;
+}
+
+int srad_bench_window_attn(int precision, const float* qkv, float* out, const float* table, int B, int H, int W, int ws,
+                           int shift, int d, int heads, int hdp, int iters, float* us_out, void* stream) {
+  SRAD_REQUIRE(qkv && out && table && us_out && iters > 0, "bench_window_attn: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  AttnParams a{qkv, out, table, B, H, W, ws, shift, d, heads, hdp};
+  for (int i = 0; i < 5; ++i) SRAD_TRY(srad_launch_window_attn(precision, a, s));
+  hipEvent_t e0, e1;
+  SRAD_CHECK_HIP(hipEventCreate(&e0));
+  SRAD_CHECK_HIP(hipEventCreate(&e1));
+  SRAD_CHECK_HIP(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) SRAD_TRY(srad_launch_window_attn(precision, a, s));
+  SRAD_CHECK_HIP(hipEventRecord(e1, s));
+  SRAD_CHECK_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  SRAD_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *us_out = ms * 1e3f / iters;
+  return SRAD_OK;
 }
 
 size_t srad_op_gemm_scratch_bytes(int precision, int N, int Cin, int ntaps) {
@@ -43,11 +104,12 @@ size_t srad_op_gemm_scratch_bytes(int precision, int N, int Cin, int ntaps) {
 }
 
 // WindowAttention core (reference src/drct.py:281-299 plus the roll/partition/reverse around it):
-// qkv [B*H*W][3d] -> out [B*H*W][d], raster token order.
+// qkv [B*H*W][3][heads][hdp] (head slices padded to hdp floats, hdp % 4 == 0, pad columns finite)
+// -> out [B*H*W][d], raster token order.
 int srad_op_window_attn(int precision, const float* qkv, float* out, const float* table, int B, int H, int W, int ws,
-                        int shift, int d, int heads, void* stream) {
+                        int shift, int d, int heads, int hdp, void* stream) {
   SRAD_REQUIRE(qkv && out && table, "op_window_attn: null argument");
-  AttnParams a{qkv, out, table, B, H, W, ws, shift, d, heads};
+  AttnParams a{qkv, out, table, B, H, W, ws, shift, d, heads, hdp};
   return srad_launch_window_attn(precision, a, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -17,6 +17,7 @@ enum { SRAD_ACT_NONE = 0, SRAD_ACT_GELU = 1, SRAD_ACT_LRELU = 2, SRAD_ACT_RELU =
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 int srad_set_error(int code, const char* fmt, ...);
 #define SRAD_CHECK_HIP(expr)                                                              \
@@ -66,6 +67,8 @@ struct GemmParams {
   int ldy;
   int yoff;
   int ps;          // 0: plain store, 2: PixelShuffle(2) scatter (N = 4 * ldy-channels)
+  int hsplit_hd;   // > 0: column n is stored at (n / hsplit_hd) * hsplit_hdp + n % hsplit_hd, i.e. every
+  int hsplit_hdp;  //      head's slice is padded to hsplit_hdp floats (the attention kernel's input layout)
   float* pool;     // optional [B][N] per-image column sums of the stored values (atomicAdd)
 };
 
@@ -85,10 +88,11 @@ int srad_launch_pack_weight(int prec, const float* src, void* dst, int n, int ci
 // Window attention (DRCT): qkv [T][3d] -> out [T][d], tokens in raster order per image.
 // ------------------------------------------------------------------------------------------
 struct AttnParams {
-  const float* qkv;   // [T][3*d]
+  const float* qkv;   // [T][3][heads][hdp] head-padded q | k | v
   float* out;         // [T][d]
   const float* table; // [(2ws-1)^2][heads]
   int B, H, W, ws, shift, d, heads;
+  int hdp;            // padded head_dim (multiple of 4, >= d / heads)
 };
 int srad_launch_window_attn(int prec, const AttnParams& p, hipStream_t stream);
 
@@ -97,8 +101,9 @@ int srad_launch_window_attn(int prec, const AttnParams& p, hipStream_t stream);
 // ------------------------------------------------------------------------------------------
 int srad_launch_layernorm(const float* x, int ldx, float* y, int ldy, int rows, int C,
                           const float* g, const float* b, float eps, hipStream_t stream);
-// NCHW -> NHWC with (x - mean[c]) * scale ; NHWC -> NCHW with x * scale + mean[c]
-int srad_launch_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W,
+// NCHW -> NHWC [pix][Cpad] with (x - mean[c]) * scale (channels >= C zero) ; NHWC -> NCHW with x * scale + mean[c]
+#define SRAD_IMG_CPAD 4   /* image tensors are kept with 4 channels so every row is float4-addressable */
+int srad_launch_nchw_to_nhwc(const float* x, float* y, int B, int C, int Cpad, int H, int W,
                              const float* mean3, float scale, hipStream_t stream);
 int srad_launch_nhwc_to_nchw(const float* x, int ldx, float* y, int B, int C, int H, int W,
                              const float* mean3, float scale, hipStream_t stream);
@@ -108,7 +113,7 @@ int srad_launch_nhwc_to_nchw(const float* x, int ldx, float* y, int B, int C, in
 // numbers).  Off by default; never active while a stream is being captured.
 // ------------------------------------------------------------------------------------------
 enum {
-  SRAD_K_GEMM_64x64 = 0, SRAD_K_GEMM_128x32, SRAD_K_GEMM_128x16, SRAD_K_ATTN, SRAD_K_LAYERNORM,
+  SRAD_K_GEMM_BN64 = 0, SRAD_K_GEMM_BN32, SRAD_K_GEMM_BN16, SRAD_K_ATTN, SRAD_K_LAYERNORM,
   SRAD_K_LAYOUT, SRAD_K_PACK, SRAD_K_SCORE, SRAD_K_MISC, SRAD_K_COUNT
 };
 struct SradProfScope {

@@ -28,7 +28,16 @@ def gemm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = N
     ntaps = 9 if weight.dim() == 4 and weight.shape[-1] == 3 else 1
     N, Cin = weight.shape[0], weight.shape[1]
     assert x.shape[1] >= Cin
-    w = weight.detach().reshape(N, Cin, ntaps).contiguous().float()
+    w = weight.detach().reshape(N, Cin, ntaps).float()
+    if Cin % 4 or ldx % 4 or x.data_ptr() % 16:
+        # the kernels address activations as float4: pad the channels (zeros) like the engines do
+        cpad = (Cin + 3) // 4 * 4
+        x = torch.nn.functional.pad(x[:, :Cin], (0, cpad - Cin)).contiguous()
+        w = torch.nn.functional.pad(w, (0, 0, 0, cpad - Cin))
+        if ln is not None:
+            raise ValueError("LayerNorm fusion needs a channel count that is a multiple of 4")
+        Cin, ldx = cpad, cpad
+    w = w.contiguous()
     if ntaps == 1 and stride == 1:
         B, H, W = 1, 1, x.shape[0]
     pad, k = (1, 3) if ntaps == 9 else (0, 1)
@@ -54,13 +63,19 @@ def gemm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = N
 
 def window_attention(qkv: torch.Tensor, table: torch.Tensor, B: int, H: int, W: int, ws: int, shift: int,
                      heads: int, precision: str = "fp32") -> torch.Tensor:
-    """qkv: [B*H*W, 3d] raster-ordered tokens -> [B*H*W, d]."""
+    """qkv: [B*H*W, 3d] raster-ordered tokens in the reference's column order (q | k | v, heads
+    contiguous) -> [B*H*W, d].  The kernel reads a head-padded layout (every head slice padded to a
+    multiple of 4 floats; the engine's QKV GEMM writes it directly), so this wrapper re-lays it out."""
     _need_cuda(qkv, table)
-    assert qkv.is_contiguous() and qkv.shape[0] == B * H * W
+    assert qkv.shape[0] == B * H * W
     d = qkv.shape[1] // 3
+    hd = d // heads
+    hdp = (hd + 3) // 4 * 4
+    padded = torch.nn.functional.pad(qkv.reshape(-1, 3 * heads, hd).float(), (0, hdp - hd)).reshape(-1, 3 * heads * hdp)
+    padded = padded.contiguous()
     out = torch.empty(qkv.shape[0], d, dtype=torch.float32, device=qkv.device)
-    L.check(L.lib().srad_op_window_attn(L.PRECISIONS[precision], L.dptr(qkv), L.dptr(out),
-                                        L.dptr(table.contiguous()), B, H, W, ws, shift, d, heads,
+    L.check(L.lib().srad_op_window_attn(L.PRECISIONS[precision], L.dptr(padded), L.dptr(out),
+                                        L.dptr(table.contiguous()), B, H, W, ws, shift, d, heads, hdp,
                                         L.current_stream_ptr()), "op_window_attn")
     return out
 
