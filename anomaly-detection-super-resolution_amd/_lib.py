@@ -70,7 +70,8 @@ _SIG = {
                                    _P, _P, _P, _P, C.c_size_t, _P]),
     "srad_val_metrics": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, C.c_size_t, _P]),
     "srad_roc_auc": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double)]),
-    "srad_l1_loss": (C.c_int, [_P, _P, C.c_int64, _P, _P]),
+    "srad_l1_workspace_bytes": (C.c_int, [C.POINTER(C.c_size_t)]),
+    "srad_l1_loss": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P]),
     # event profiler
     "srad_prof_enable": (C.c_int, [C.c_int]),
     "srad_prof_num_classes": (C.c_int, []),

@@ -1,0 +1,505 @@
+// drn.hip - DRN-L forward engine, the dual regression model, and their C ABI (include/srad.h).
+// Follows reference src/drn.py: DRN.forward 241-270, DownBlock 83-119, RCAB 143-158, CALayer 123-139,
+// Upsampler 55-81, MeanShift 44-52; src/model.py:8-44 (dual DownBlock).
+//
+// HBM layout: NHWC fp32 everywhere.  torch.cat((x, copies[..]), 1) (drn.py:263) is a buffer with
+// 2*c channels per pixel: the up-branch 1x1 conv writes channels [0, c), the down path wrote its
+// skip copy into channels [c, 2c) on the way down, and the next stage reads all 2c - no copy.
+// The MeanShift layers are 1x1 convs with TRAINABLE weights in the reference (the requires_grad
+// assignment there is a no-op), so they are applied as full CxC matrices, fused into the bicubic
+// upsampler (sub_mean) and into the NHWC->NCHW output kernel (add_mean).
+#include "engine.h"
+#include "../../include/srad.h"
+#include <math.h>
+#include <new>
+
+namespace {
+
+// ---- bicubic x scale (align_corners=False, A=-0.75, border clamp) + sub_mean, NCHW -> NHWC[4] ----
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+__global__ void bicubic_submean_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int H, int W,
+                                       int scale, const float* __restrict__ mw, const float* __restrict__ mb) {
+  const int Ho = H * scale, Wo = W * scale;
+  const size_t total = (size_t)B * Ho * Wo;
+  const float A = -0.75f, rs = 1.0f / (float)scale;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % Wo);
+    const int oy = (int)((i / Wo) % Ho);
+    const int b = (int)(i / ((size_t)Wo * Ho));
+    const float ry = rs * ((float)oy + 0.5f) - 0.5f, rx = rs * ((float)ox + 0.5f) - 0.5f;
+    const float fy = floorf(ry), fx = floorf(rx);
+    const int iy = (int)fy, ix = (int)fx;
+    const float ty = ry - fy, tx = rx - fx;
+    const float cy[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
+    const float cx[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
+    float v[3] = {0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) {
+      const float* pl = x + ((size_t)b * C + c) * H * W;
+      float acc = 0.f;
+      for (int k = 0; k < 4; ++k) {
+        const int yy = min(max(iy - 1 + k, 0), H - 1);
+        const float* row = pl + (size_t)yy * W;
+        const float r = row[min(max(ix - 1, 0), W - 1)] * cx[0] + row[min(max(ix, 0), W - 1)] * cx[1] +
+                        row[min(max(ix + 1, 0), W - 1)] * cx[2] + row[min(max(ix + 2, 0), W - 1)] * cx[3];
+        acc += r * cy[k];
+      }
+      v[c] = acc;
+    }
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int co = 0; co < C; ++co) {                 // sub_mean: 1x1 conv (drn.py:246)
+      float acc = mb[co];
+      for (int ci = 0; ci < C; ++ci) acc += mw[co * C + ci] * v[ci];
+      o[co] = acc;
+    }
+    *reinterpret_cast<float4*>(y + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// add_mean (1x1 conv CxC + bias) fused with NHWC -> NCHW           (drn.py:257,266)
+__global__ void affine_to_nchw_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int B, int C, int HW,
+                                      const float* __restrict__ mw, const float* __restrict__ mb) {
+  const size_t total = (size_t)B * HW;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / HW);
+    const int hw = (int)(i - (size_t)b * HW);
+    float v[3] = {0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) v[c] = x[i * ldx + c];
+    for (int co = 0; co < C; ++co) {
+      float acc = mb[co];
+      for (int ci = 0; ci < C; ++ci) acc += mw[co * C + ci] * v[ci];
+      y[((size_t)b * C + co) * HW + hw] = acc;
+    }
+  }
+}
+
+// channel-attention gate: sigmoid(W2 relu(W1 mean + b1) + b2), one workgroup per image (drn.py:128-139)
+__global__ __launch_bounds__(128) void ca_gate_kernel(const float* __restrict__ pool, float inv_hw, int C, int Cr,
+                                                      const float* __restrict__ w1, const float* __restrict__ b1,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2,
+                                                      float* __restrict__ gate) {
+  __shared__ float mean[512];
+  __shared__ float hid[64];
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) mean[c] = pool[(size_t)b * C + c] * inv_hw;
+  __syncthreads();
+  for (int j = threadIdx.x; j < Cr; j += blockDim.x) {
+    float acc = b1[j];
+    for (int c = 0; c < C; ++c) acc += w1[j * C + c] * mean[c];
+    hid[j] = fmaxf(acc, 0.f);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float acc = b2[c];
+    for (int j = 0; j < Cr; ++j) acc += w2[c * Cr + j] * hid[j];
+    gate[(size_t)b * C + c] = 1.0f / (1.0f + expf(-acc));
+  }
+}
+
+// out = r * gate[b] + x   (RCAB tail, drn.py:139,156-157), float4 over [T][C]
+__global__ void scale_add_kernel(const float* __restrict__ r, const float* __restrict__ gate, const float* __restrict__ x,
+                                 int ldx, float* __restrict__ y, size_t T, int C, int hw) {
+  const int c4n = C / 4;
+  const size_t total = T * c4n;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = i / c4n;
+    const int c = (int)(i - pix * c4n) * 4;
+    const int b = (int)(pix / hw);
+    const f32x4 rv = *reinterpret_cast<const f32x4*>(r + pix * C + c);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gate + (size_t)b * C + c);
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + pix * ldx + c);
+    *reinterpret_cast<f32x4*>(y + pix * C + c) = rv * g + xv;
+  }
+}
+
+inline int grid1d(size_t total) {
+  size_t b = (total + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+struct RcabW {
+  ConvW c0, c1;
+  int w1, b1, w2, b2;   // CA 1x1 convs, raw fp32
+  int ch;
+};
+
+}  // namespace
+
+struct srad_drn {
+  srad_drn_config cfg;
+  ParamTable pt;
+  int phase;
+  int sub_w, sub_b, add_w, add_b;
+  ConvW head;
+  std::vector<ConvW> down_s2, down_s1;          // per phase
+  std::vector<std::vector<RcabW>> rcab;         // [phase][n_blocks]
+  std::vector<ConvW> up_conv, up_1x1;           // per phase
+  std::vector<ConvW> tail;                      // phase + 1
+  GraphCache gc;
+};
+
+namespace {
+
+GemmParams conv_params(const srad_drn* h, const ConvW& c, const float* X, int ldx, int B, int Hi, int Wi, int stride,
+                       float* Y, int ldy, int yoff) {
+  GemmParams p{};
+  const int pad = c.ntaps == 9 ? 1 : 0, k = c.ntaps == 9 ? 3 : 1;
+  p.Hi = Hi; p.Wi = Wi;
+  p.Ho = (Hi + 2 * pad - k) / stride + 1;
+  p.Wo = (Wi + 2 * pad - k) / stride + 1;
+  p.stride = stride;
+  p.X = X; p.ldx = ldx; p.M = B * p.Ho * p.Wo; p.Cin = c.cin; p.Cp = srad_cp(c.cin); p.ntaps = c.ntaps;
+  p.ln_g = p.ln_b = nullptr; p.ln_eps = 1e-5f;
+  p.Wp = h->pt.ptr(c.w); p.N = c.n; p.bias = h->pt.fptr(c.b);
+  p.act = SRAD_ACT_NONE; p.slope = 0.f; p.alpha = 1.f;
+  p.R = nullptr; p.ldr = 0;
+  p.Y = Y; p.ldy = ldy; p.yoff = yoff; p.ps = 0; p.pool = nullptr;
+  p.hsplit_hd = 0; p.hsplit_hdp = 0;
+  return p;
+}
+
+struct DrnWs {
+  float* up0;                       // [T0][4]
+  std::vector<float*> cat;          // level L: [T_L][2 F 2^L]
+  float* deep;                      // [T_P][F 2^P]
+  float* dtmp;                      // down-block intermediate
+  float *ra, *rb, *rt, *rr;         // RCAB ping/pong, relu(conv), conv result
+  float* ups;                       // conv + pixel-shuffle output
+  float* timg;                      // tail conv output [T][C]
+  float* pool;                      // [n_rcab_total][B][chmax]
+  float* gate;                      // [B][chmax]
+  size_t pool_bytes;
+  size_t bytes;
+};
+
+DrnWs plan_ws(const srad_drn* h, int B, int H, int W, void* base, size_t cap) {
+  const srad_drn_config& c = h->cfg;
+  const int P = h->phase, F = c.n_feats, s = c.scale;
+  const size_t T0 = (size_t)B * H * s * W * s;
+  Bump bp(base, cap);
+  DrnWs w;
+  w.up0 = bp.take(T0 * SRAD_IMG_CPAD);
+  for (int L = 0; L < P; ++L) w.cat.push_back(bp.take((T0 >> (2 * L)) * 2 * F * (1 << L)));
+  const size_t TP = T0 >> (2 * P);
+  const int top = F << P;
+  w.deep = bp.take(TP * top);
+  w.dtmp = bp.take((T0 >> 2) * F);                    // largest: level 0 stride-2 output [T0/4][F]
+  // RCAB stacks: idx 0 at level P (top channels), idx >= 1 at level P-idx with 2 F 2^(P-idx) channels
+  size_t rmax = TP * top;
+  for (int idx = 1; idx < P; ++idx) {
+    const size_t e = (T0 >> (2 * (P - idx))) * 2 * F * (1 << (P - idx));
+    if (e > rmax) rmax = e;
+  }
+  w.ra = bp.take(rmax); w.rb = bp.take(rmax); w.rt = bp.take(rmax); w.rr = bp.take(rmax);
+  // Upsampler output (before the 1x1): 4x the pixels of its level, same channels
+  size_t umax = 0;
+  for (int idx = 0; idx < P; ++idx) {
+    const int lvl = P - idx;
+    const int cin = idx == 0 ? top : 2 * F * (1 << lvl);
+    const size_t e = (T0 >> (2 * (lvl - 1))) * cin;
+    if (e > umax) umax = e;
+  }
+  w.ups = bp.take(umax);
+  w.timg = bp.take(T0 * SRAD_IMG_CPAD);
+  const size_t nr = (size_t)P * c.n_blocks;
+  w.pool_bytes = nr * B * top * sizeof(float);
+  w.pool = bp.take(nr * B * top);
+  w.gate = bp.take((size_t)B * top);
+  w.bytes = bp.used;
+  return w;
+}
+
+int tail_out(srad_drn* h, const ConvW& t, const float* X, int ldx, int B, int Hh, int Ww, const DrnWs& w, float* y,
+             hipStream_t s) {
+  const int C = h->cfg.n_colors;
+  GemmParams p = conv_params(h, t, X, ldx, B, Hh, Ww, 1, w.timg, C, 0);
+  SRAD_TRY(srad_launch_gemm(h->cfg.precision, p, s));
+  const size_t tot = (size_t)B * Hh * Ww;
+  SradProfScope prof(s, SRAD_K_LAYOUT, 2.0 * tot * C * C, 8.0 * tot * C);
+  hipLaunchKernelGGL(affine_to_nchw_kernel, dim3(grid1d(tot)), dim3(256), 0, s, w.timg, C, y, B, C, Hh * Ww,
+                     h->pt.fptr(h->add_w), h->pt.fptr(h->add_b));
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}
+
+int forward_body(srad_drn* h, const float* x, int B, int H, int W, float* const* ys, const DrnWs& w, hipStream_t s) {
+  const srad_drn_config& c = h->cfg;
+  const int prec = c.precision, P = h->phase, F = c.n_feats, sc = c.scale, C = c.n_colors;
+  const int H0 = H * sc, W0 = W * sc;
+  const int top = F << P;
+  SRAD_CHECK_HIP(hipMemsetAsync(w.pool, 0, w.pool_bytes, s));
+  // bicubic upsample to the target size + sub_mean            (drn.py:243-246)
+  {
+    const size_t tot = (size_t)B * H0 * W0;
+    SradProfScope prof(s, SRAD_K_MISC, 40.0 * tot * C, 4.0 * tot * (4 + C));
+    hipLaunchKernelGGL(bicubic_submean_kernel, dim3(grid1d(tot)), dim3(256), 0, s, x, w.up0, B, C, H, W, sc,
+                       h->pt.fptr(h->sub_w), h->pt.fptr(h->sub_b));
+    SRAD_CHECK_HIP(hipGetLastError());
+  }
+  // head -> copies[0], stored in cat[0][:, F:2F]               (drn.py:247, 252)
+  {
+    GemmParams p = conv_params(h, h->head, w.up0, SRAD_IMG_CPAD, B, H0, W0, 1, w.cat[0], 2 * F, F);
+    p.Cin = SRAD_IMG_CPAD;
+    SRAD_TRY(srad_launch_gemm(prec, p, s));
+  }
+  // down phases                                               (drn.py:250-253, 83-119)
+  for (int L = 0; L < P; ++L) {
+    const int f = F << L, Hl = H0 >> L, Wl = W0 >> L;
+    GemmParams p = conv_params(h, h->down_s2[L], w.cat[L] + f, 2 * f, B, Hl, Wl, 2, w.dtmp, f, 0);
+    p.act = SRAD_ACT_LRELU; p.slope = c.negval;
+    SRAD_TRY(srad_launch_gemm(prec, p, s));
+    float* dst = L + 1 < P ? w.cat[L + 1] : w.deep;
+    const int ldd = L + 1 < P ? 4 * f : 2 * f, off = L + 1 < P ? 2 * f : 0;
+    GemmParams q = conv_params(h, h->down_s1[L], w.dtmp, f, B, Hl / 2, Wl / 2, 1, dst, ldd, off);
+    SRAD_TRY(srad_launch_gemm(prec, q, s));
+  }
+  // coarsest output                                           (drn.py:256-258)
+  SRAD_TRY(tail_out(h, h->tail[0], w.deep, top, B, H0 >> P, W0 >> P, w, ys[0], s));
+
+  const float* xin = w.deep;
+  int ldin = top;
+  for (int idx = 0; idx < P; ++idx) {
+    const int lvl = P - idx;
+    const int Hl = H0 >> lvl, Wl = W0 >> lvl;
+    const int ch = h->rcab[idx][0].ch;
+    const size_t T = (size_t)B * Hl * Wl;
+    float* cur = w.ra;
+    float* nxt = w.rb;
+    for (int b = 0; b < c.n_blocks; ++b) {
+      const RcabW& r = h->rcab[idx][b];
+      float* pool = w.pool + ((size_t)idx * c.n_blocks + b) * B * top;
+      {  // conv + ReLU                                         (drn.py:147-150)
+        GemmParams p = conv_params(h, r.c0, xin, ldin, B, Hl, Wl, 1, w.rt, ch, 0);
+        p.act = SRAD_ACT_RELU;
+        SRAD_TRY(srad_launch_gemm(prec, p, s));
+      }
+      {  // conv, with the global-average-pool sums taken in the epilogue (drn.py:127,136)
+        GemmParams p = conv_params(h, r.c1, w.rt, ch, B, Hl, Wl, 1, w.rr, ch, 0);
+        p.pool = pool;
+        SRAD_TRY(srad_launch_gemm(prec, p, s));
+      }
+      {
+        SradProfScope prof(s, SRAD_K_MISC, 4.0 * B * ch * (ch / 16), 8.0 * B * ch);
+        hipLaunchKernelGGL(ca_gate_kernel, dim3(B), dim3(128), 0, s, pool, 1.0f / (float)(Hl * Wl), ch, ch / 16,
+                           h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2), w.gate);
+      }
+      {  // res = body(x) * gate + x                             (drn.py:139, 156-157)
+        SradProfScope prof(s, SRAD_K_MISC, 2.0 * T * ch, 12.0 * T * ch);
+        hipLaunchKernelGGL(scale_add_kernel, dim3(grid1d(T * ch / 4)), dim3(256), 0, s, w.rr, w.gate, xin, ldin, cur, T, ch,
+                           Hl * Wl);
+      }
+      SRAD_CHECK_HIP(hipGetLastError());
+      xin = cur; ldin = ch;
+      float* t = cur; cur = nxt; nxt = t;
+    }
+    // Upsampler: conv ch -> 4 ch + PixelShuffle(2), then the 1x1 reducing conv into cat[lvl-1][:, :cout]
+    const int cout = F << (lvl - 1);
+    {
+      GemmParams p = conv_params(h, h->up_conv[idx], xin, ldin, B, Hl, Wl, 1, w.ups, ch, 0);
+      p.ps = 2;
+      SRAD_TRY(srad_launch_gemm(prec, p, s));
+    }
+    {
+      GemmParams p = conv_params(h, h->up_1x1[idx], w.ups, ch, B, 2 * Hl, 2 * Wl, 1, w.cat[lvl - 1], 2 * cout, 0);
+      SRAD_TRY(srad_launch_gemm(prec, p, s));
+    }
+    // torch.cat((x, copies[..]), 1) is cat[lvl-1] as it stands  (drn.py:263)
+    xin = w.cat[lvl - 1];
+    ldin = 2 * cout;
+    SRAD_TRY(tail_out(h, h->tail[idx + 1], xin, ldin, B, 2 * Hl, 2 * Wl, w, ys[idx + 1], s));
+  }
+  return SRAD_OK;
+}
+
+int drn_check_shape(const srad_drn* h, int B, int H, int W) {
+  SRAD_REQUIRE(B > 0 && H > 0 && W > 0, "drn: empty input %dx%dx%d", B, H, W);
+  SRAD_REQUIRE((double)B * H * W * h->cfg.scale * h->cfg.scale * (h->cfg.n_feats << h->phase) * 4.0 < 3.9e9,
+               "drn: problem too large for the 32-bit offsets of the conv kernel");
+  return SRAD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int srad_drn_create(const srad_drn_config* cfg, srad_drn_t** out) {
+  SRAD_REQUIRE(cfg && out, "drn_create: null argument");
+  SRAD_REQUIRE(cfg->n_colors == 1 || cfg->n_colors == 3, "drn_create: n_colors must be 1 or 3 (got %d)", cfg->n_colors);
+  SRAD_REQUIRE(cfg->scale == 2 || cfg->scale == 4 || cfg->scale == 8, "drn_create: scale must be 2, 4 or 8 (got %d)", cfg->scale);
+  SRAD_REQUIRE(cfg->n_feats > 0 && cfg->n_feats % 4 == 0,
+               "drn_create: n_feats must be a multiple of 4 for the float4 kernels (got %d; the reference's x8 "
+               "preset n_feats=10 is not supported yet)", cfg->n_feats);
+  SRAD_REQUIRE(cfg->n_blocks > 0, "drn_create: n_blocks must be positive");
+  SRAD_REQUIRE(cfg->precision == SRAD_PREC_F32 || cfg->precision == SRAD_PREC_BF16, "drn_create: bad precision %d", cfg->precision);
+  srad_drn* h = new (std::nothrow) srad_drn();
+  if (!h) return srad_set_error(SRAD_ERR_NOMEM, "drn_create: out of host memory");
+  h->cfg = *cfg;
+  h->pt.prec = cfg->precision;
+  int P = 0;
+  for (int s = cfg->scale; s > 1; s >>= 1) ++P;
+  h->phase = P;
+  const int C = cfg->n_colors, F = cfg->n_feats, top = F << P;
+  SRAD_REQUIRE(top <= 512 && top / 16 <= 64, "drn_create: n_feats*2^phase = %d too wide for the gate kernel", top);
+  h->sub_w = h->pt.add_raw("sub_mean.weight", C * C);
+  h->sub_b = h->pt.add_raw("sub_mean.bias", C);
+  h->add_w = h->pt.add_raw("add_mean.weight", C * C);
+  h->add_b = h->pt.add_raw("add_mean.bias", C);
+  h->head = h->pt.add_layer("head", F, C, 9, true);
+  for (int p = 0; p < P; ++p) {
+    const int f = F << p;
+    h->down_s2.push_back(h->pt.add_layer("down." + std::to_string(p) + ".dual_module.0.0", f, f, 9, false));
+    h->down_s1.push_back(h->pt.add_layer("down." + std::to_string(p) + ".dual_module.1", 2 * f, f, 9, false));
+  }
+  h->rcab.resize(P);
+  for (int idx = 0; idx < P; ++idx) {
+    const int ch = idx == 0 ? top : F << (P - idx + 1);
+    for (int b = 0; b < cfg->n_blocks; ++b) {
+      const std::string q = "up_blocks." + std::to_string(idx) + "." + std::to_string(b) + ".body.";
+      RcabW r;
+      r.ch = ch;
+      r.c0 = h->pt.add_layer(q + "0", ch, ch, 9, true);
+      r.c1 = h->pt.add_layer(q + "2", ch, ch, 9, true);
+      r.w1 = h->pt.add_raw(q + "3.conv_du.0.weight", (int64_t)(ch / 16) * ch);
+      r.b1 = h->pt.add_raw(q + "3.conv_du.0.bias", ch / 16);
+      r.w2 = h->pt.add_raw(q + "3.conv_du.2.weight", (int64_t)ch * (ch / 16));
+      r.b2 = h->pt.add_raw(q + "3.conv_du.2.bias", ch);
+      h->rcab[idx].push_back(r);
+    }
+    const int cin = idx == 0 ? top : 2 * F * (1 << (P - idx));
+    const int cout = F << (P - idx - 1);
+    const std::string u = "up_blocks." + std::to_string(idx) + ".";
+    h->up_conv.push_back(h->pt.add_layer(u + std::to_string(cfg->n_blocks) + ".0", 4 * cin, cin, 9, true));
+    h->up_1x1.push_back(h->pt.add_layer(u + std::to_string(cfg->n_blocks + 1), cout, cin, 1, true));
+  }
+  h->tail.push_back(h->pt.add_layer("tail.0", C, top, 9, true));
+  for (int j = 1, p = P; p >= 1; ++j, --p) h->tail.push_back(h->pt.add_layer("tail." + std::to_string(j), C, F << p, 9, true));
+  *out = h;
+  return SRAD_OK;
+}
+
+void srad_drn_destroy(srad_drn_t* h) {
+  if (!h) return;
+  h->gc.reset();
+  delete h;
+}
+
+int srad_drn_arena_bytes(const srad_drn_t* h, size_t* bytes) {
+  SRAD_REQUIRE(h && bytes, "drn_arena_bytes: null argument");
+  *bytes = h->pt.bytes;
+  return SRAD_OK;
+}
+
+int srad_drn_bind_arena(srad_drn_t* h, void* arena, size_t bytes) {
+  SRAD_REQUIRE(h && arena, "drn_bind_arena: null argument");
+  SRAD_REQUIRE(bytes >= h->pt.bytes, "drn_bind_arena: %zu bytes given, %zu needed", bytes, h->pt.bytes);
+  SRAD_REQUIRE(((uintptr_t)arena & 255) == 0, "drn_bind_arena: arena must be 256-byte aligned");
+  h->pt.arena = reinterpret_cast<char*>(arena);
+  h->pt.arena_bytes = bytes;
+  h->gc.reset();
+  return SRAD_OK;
+}
+
+int srad_drn_num_params(const srad_drn_t* h) { return h ? (int)h->pt.entries.size() : 0; }
+
+int srad_drn_param_info(const srad_drn_t* h, int idx, const char** name, int64_t* numel) {
+  SRAD_REQUIRE(h && idx >= 0 && idx < (int)h->pt.entries.size(), "drn_param_info: index %d out of range", idx);
+  if (name) *name = h->pt.entries[idx].name.c_str();
+  if (numel) *numel = h->pt.entries[idx].numel;
+  return SRAD_OK;
+}
+
+int srad_drn_set_param(srad_drn_t* h, const char* name, const float* dev_src, int64_t numel, void* stream) {
+  SRAD_REQUIRE(h && name && dev_src, "drn_set_param: null argument");
+  return h->pt.set(name, dev_src, numel, reinterpret_cast<hipStream_t>(stream));
+}
+
+int srad_drn_workspace_bytes(const srad_drn_t* h, int B, int H, int W, size_t* bytes) {
+  SRAD_REQUIRE(h && bytes, "drn_workspace_bytes: null argument");
+  SRAD_TRY(drn_check_shape(h, B, H, W));
+  *bytes = plan_ws(h, B, H, W, nullptr, 0).bytes;
+  return SRAD_OK;
+}
+
+int srad_drn_forward(srad_drn_t* h, const float* x, int B, int H, int W, float* const* ys, int n_out, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+  SRAD_REQUIRE(h && x && ys && workspace, "drn_forward: null argument");
+  SRAD_REQUIRE(n_out == h->phase + 1, "drn_forward: %d outputs given, the model returns %d", n_out, h->phase + 1);
+  for (int i = 0; i < n_out; ++i) SRAD_REQUIRE(ys[i] != nullptr, "drn_forward: output %d is null", i);
+  if (!h->pt.arena) return srad_set_error(SRAD_ERR_STATE, "drn_forward: no weight arena bound");
+  SRAD_TRY(drn_check_shape(h, B, H, W));
+  SRAD_REQUIRE(((uintptr_t)workspace & 255) == 0, "drn_forward: workspace must be 256-byte aligned");
+  const DrnWs w = plan_ws(h, B, H, W, workspace, workspace_bytes);
+  SRAD_REQUIRE(w.bytes <= workspace_bytes, "drn_forward: workspace %zu bytes, %zu needed", workspace_bytes, w.bytes);
+  std::vector<float*> outs(ys, ys + n_out);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return srad_run_with_graph(h->gc, h->cfg.use_graph != 0, x, outs.back(), workspace, B, H, W, s,
+                             [&](hipStream_t st) { return forward_body(h, x, B, H, W, outs.data(), w, st); });
+}
+
+int srad_drn_flops(const srad_drn_t* h, int B, int H, int W, double* flops) {
+  SRAD_REQUIRE(h && flops, "drn_flops: null argument");
+  const int P = h->phase, sc = h->cfg.scale;
+  const double T0 = (double)B * H * sc * W * sc;
+  double f = 0;
+  auto conv = [&](const ConvW& l, double pix) { f += 2.0 * pix * l.n * l.cin * l.ntaps; };
+  conv(h->head, T0);
+  for (int L = 0; L < P; ++L) { conv(h->down_s2[L], T0 / pow(4.0, L + 1)); conv(h->down_s1[L], T0 / pow(4.0, L + 1)); }
+  conv(h->tail[0], T0 / pow(4.0, P));
+  for (int idx = 0; idx < P; ++idx) {
+    const double T = T0 / pow(4.0, P - idx);
+    for (const RcabW& r : h->rcab[idx]) { conv(r.c0, T); conv(r.c1, T); }
+    conv(h->up_conv[idx], T);
+    conv(h->up_1x1[idx], 4 * T);
+    conv(h->tail[idx + 1], 4 * T);
+  }
+  *flops = f;
+  return SRAD_OK;
+}
+
+// ------------------------------------------------------------------ dual regression model
+int srad_dual_workspace_bytes(int B, int C, int H, int W, int n_feats, size_t* bytes) {
+  SRAD_REQUIRE(bytes && B > 0 && C > 0 && H > 0 && W > 0 && n_feats > 0, "dual_workspace_bytes: bad argument");
+  const size_t T = (size_t)B * H * W, T2 = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+  *bytes = srad_align_up(T * SRAD_IMG_CPAD * 4, 256) + srad_align_up(T2 * n_feats * 4, 256) + srad_align_up(T2 * SRAD_IMG_CPAD * 4, 256) +
+           srad_align_up(srad_packed_bytes(SRAD_PREC_F32, n_feats, C, 9), 256) + srad_align_up(srad_packed_bytes(SRAD_PREC_F32, C, n_feats, 9), 256);
+  return SRAD_OK;
+}
+
+int srad_dual_forward(const float* w0, const float* w1, int C, int n_feats, float negval, const float* x, int B, int H,
+                      int W, float* y, void* workspace, size_t workspace_bytes, int precision, void* stream) {
+  SRAD_REQUIRE(w0 && w1 && x && y && workspace, "dual_forward: null argument");
+  SRAD_REQUIRE(C == 1 || C == 3, "dual_forward: channels must be 1 or 3 (got %d)", C);
+  SRAD_REQUIRE(n_feats % 4 == 0, "dual_forward: n_feats must be a multiple of 4 (got %d)", n_feats);
+  size_t need = 0;
+  SRAD_TRY(srad_dual_workspace_bytes(B, C, H, W, n_feats, &need));
+  SRAD_REQUIRE(workspace_bytes >= need, "dual_forward: workspace %zu bytes, %zu needed", workspace_bytes, need);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Bump bp(workspace, workspace_bytes);
+  const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+  const size_t T = (size_t)B * H * W, T2 = (size_t)B * H2 * W2;
+  float* xin = bp.take(T * SRAD_IMG_CPAD);
+  float* mid = bp.take(T2 * n_feats);
+  float* outn = bp.take(T2 * SRAD_IMG_CPAD);
+  void* p0 = bp.take(srad_packed_bytes(SRAD_PREC_F32, n_feats, C, 9) / 4);
+  void* p1 = bp.take(srad_packed_bytes(SRAD_PREC_F32, C, n_feats, 9) / 4);
+  const float zero3[3] = {0.f, 0.f, 0.f};
+  SRAD_TRY(srad_launch_nchw_to_nhwc(x, xin, B, C, SRAD_IMG_CPAD, H, W, zero3, 1.0f, s));
+  SRAD_TRY(srad_launch_pack_weight(precision, w0, p0, n_feats, C, 9, s));
+  SRAD_TRY(srad_launch_pack_weight(precision, w1, p1, C, n_feats, 9, s));
+  GemmParams a{};
+  a.X = xin; a.ldx = SRAD_IMG_CPAD; a.Cin = SRAD_IMG_CPAD; a.Cp = srad_cp(SRAD_IMG_CPAD); a.ntaps = 9;
+  a.Hi = H; a.Wi = W; a.Ho = H2; a.Wo = W2; a.stride = 2; a.M = (int)T2;
+  a.ln_eps = 1e-5f; a.Wp = p0; a.N = n_feats; a.act = SRAD_ACT_LRELU; a.slope = negval; a.alpha = 1.f;
+  a.Y = mid; a.ldy = n_feats;
+  SRAD_TRY(srad_launch_gemm(precision, a, s));
+  GemmParams b{};
+  b.X = mid; b.ldx = n_feats; b.Cin = n_feats; b.Cp = srad_cp(n_feats); b.ntaps = 9;
+  b.Hi = H2; b.Wi = W2; b.Ho = H2; b.Wo = W2; b.stride = 1; b.M = (int)T2;
+  b.ln_eps = 1e-5f; b.Wp = p1; b.N = C; b.alpha = 1.f;
+  b.Y = outn; b.ldy = SRAD_IMG_CPAD;
+  SRAD_TRY(srad_launch_gemm(precision, b, s));
+  return srad_launch_nhwc_to_nchw(outn, SRAD_IMG_CPAD, y, B, C, H2, W2, zero3, 1.0f, s);
+}
+
+}  // extern "C"

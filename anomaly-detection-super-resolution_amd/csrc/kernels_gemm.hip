@@ -36,8 +36,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 //     its whole K <= 320), not from a second pass over memory.
 //   * mode switches (LayerNorm, conv gather, special epilogues) are template parameters.
 //   * the kernel is VALU-issue bound (one wave per SIMD, ~4 cycles per instruction), so addresses are
-//     uniform 64-bit bases (SALU) plus per-thread 32-bit byte offsets computed once; K padding is not
-//     masked at all (the packed weight is zero there and the clamped A values are finite).
+//     uniform 64-bit bases (SALU) plus per-thread 32-bit byte offsets computed once.
 //   * activations always have a channel count / row stride that is a multiple of 4 floats.
 // SPECIAL = pixel-shuffle scatter / head-padded columns / pooled sums in the epilogue.
 template <int PREC, int BM, int BN, int WAVES_M, int WAVES_N, int CPS, bool LN, bool CONV, bool SPECIAL>
@@ -86,7 +85,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   const int fr = lane & 15, fq = lane >> 4;
 
   // ---- per-thread A bookkeeping: rows tid/8 + 32*i, float4 column tid%8 of each 32-wide chunk.
-  //      a_off[i] = byte offset of (row / centre pixel, column tid%8 * 4) from X, computed once. ----
+  //      a_off[i] = byte offset of the row / centre pixel from X, computed once.  Columns are clamped
+  //      to Cin-4 (never read past a row) and the K padding is zero-filled at LDS-store time. ----
   const int col4 = tid & 7;
   unsigned a_off[RPT];
   [[maybe_unused]] int r_iy[RPT], r_ix[RPT];         // conv: top-left input coordinate of the 3x3 window
@@ -101,9 +101,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       const int pad = p.ntaps == 9 ? 1 : 0;
       r_iy[i] = oy * p.stride - pad;
       r_ix[i] = ox * p.stride - pad;
-      a_off[i] = (unsigned)(((bb * p.Hi + oy * p.stride) * p.Wi + ox * p.stride) * p.ldx + col4 * 4) * 4u;
+      a_off[i] = (unsigned)(((bb * p.Hi + oy * p.stride) * p.Wi + ox * p.stride) * p.ldx) * 4u;
     } else {
-      a_off[i] = (unsigned)(mm * p.ldx + col4 * 4) * 4u;
+      a_off[i] = (unsigned)(mm * p.ldx) * 4u;
     }
   }
 
@@ -112,9 +112,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   const int nstages = (nchunks + CPS - 1) / CPS;
 
   f32x4 a_reg[RPT][CPA];
-  [[maybe_unused]] unsigned a_ok = 0u;                         // conv: bit (i*CPS + j) = tap inside the image
+  unsigned a_ok = 0u;                                          // bit (i*CPA + j): block holds real data
   constexpr int W_SEGS = 32 * (int)sizeof(T) / 16;           // 16-byte segments per chunk per W row
   static_assert(CPS * W_SEGS == 32, "W stage rows are 32 x 16 bytes");
+  static_assert(RPT * CPA <= 32, "a_ok bitmask too small");
   constexpr int W_PT = BN / 8;                                // rows tid/32 + 8*j, segment tid%32
   u32x4 w_reg[W_PT];
   const int w_seg = tid & 31;
@@ -124,30 +125,38 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 
   auto load_a = [&](int st) {
     const int ch0 = st * CPS;
-    if constexpr (CONV) a_ok = 0u;
+    a_ok = 0u;
 #pragma unroll
     for (int j = 0; j < CPA; ++j) {
       if constexpr (CONV) {
         const int ky = ld_tap / 3, kx = ld_tap - ky * 3;                 // ld_tap <= 8: cheap scalar math
         const int dy = p.ntaps == 9 ? ky : 0, dx = p.ntaps == 9 ? kx : 0;
         const int pad = p.ntaps == 9 ? 1 : 0;
-        const int delta = (((dy - pad) * p.Wi + (dx - pad)) * p.ldx + ld_c0) * 4;
+        const int delta = ((dy - pad) * p.Wi + (dx - pad)) * p.ldx * 4;
+        const int c = ld_c0 + col4 * 4;
+        const bool c_ok = c < p.Cin;
+        const unsigned coff = (unsigned)min(c, p.Cin - 4) * 4u;
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
           const int iy = r_iy[i] + dy, ix = r_ix[i] + dx;
-          const bool ok = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-          const unsigned off = a_off[i] + (unsigned)(ok ? delta : ld_c0 * 4);   // centre pixel when outside
+          const bool in = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+          const unsigned off = a_off[i] + (unsigned)(in ? delta : 0) + coff;     // centre pixel when outside
           a_reg[i][j] = *reinterpret_cast<const f32x4*>(Xb + off);
-          a_ok |= (ok ? 1u : 0u) << (i * CPS + j);
+          a_ok |= ((in && c_ok) ? 1u : 0u) << (i * CPA + j);
         }
         if (ch0 + j + 1 < nchunks) {                                       // clamp: never step past the end
           ld_c0 += 32;
           if (ld_c0 == p.Cp) { ld_c0 = 0; ++ld_tap; }
         }
       } else {
-        const char* sb = Xb + (size_t)min(ch0 + j, nchunks - 1) * 128;    // uniform base, SALU
+        const int c = min(ch0 + j, nchunks - 1) * 32 + col4 * 4;
+        const unsigned coff = (unsigned)min(c, p.Cin - 4) * 4u;
+        const bool c_ok = c < p.Cin;
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) a_reg[i][j] = *reinterpret_cast<const f32x4*>(sb + a_off[i]);
+        for (int i = 0; i < RPT; ++i) {
+          a_reg[i][j] = *reinterpret_cast<const f32x4*>(Xb + a_off[i] + coff);
+          a_ok |= (c_ok ? 1u : 0u) << (i * CPA + j);
+        }
       }
     }
   };
@@ -173,8 +182,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
           const f32x4 b4 = *reinterpret_cast<const f32x4*>(s_b + j * 32 + col4 * 4);
           v = (v - ln_mu[i]) * ln_rs[i] * g4 + b4;               // gamma = beta = 0 in the K padding
         }
-        if constexpr (CONV) {
-          const bool ok = (a_ok >> (i * CPS + j)) & 1u;
+        {
+          // zero-fill: K padding (always) and taps outside the image (conv).  The clamped loads may
+          // have fetched anything, including NaN bit patterns from a neighbouring buffer.
+          const bool ok = (a_ok >> (i * CPA + j)) & 1u;
           v = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         T* dst = As + row * STA + j * 32 + col4 * 4;
@@ -238,8 +249,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       float s = 0.f, ss = 0.f;
 #pragma unroll
       for (int j = 0; j < CPA; ++j) {
-        const float w = (j * 32 + col4 * 4) < p.Cin ? 1.f : 0.f;     // Cin % 4 == 0: whole float4 in or out
-        const f32x4 vw = a_reg[i][j] * w;
+        const bool in = (j * 32 + col4 * 4) < p.Cin;                 // Cin % 4 == 0: whole float4 in or out
+        const f32x4 vw = in ? a_reg[i][j] : f32x4{0.f, 0.f, 0.f, 0.f};
         s += (vw[0] + vw[1]) + (vw[2] + vw[3]);
         ss += (vw[0] * vw[0] + vw[1] * vw[1]) + (vw[2] * vw[2] + vw[3] * vw[3]);
       }

@@ -122,8 +122,42 @@ int srad_val_metrics(const float* sr, const float* hr, int B, int C, int H, int 
  * arrays (n is the number of test images, a few hundred); returns non-zero if one class is absent. */
 int srad_roc_auc(const int32_t* labels, const double* scores, int n, double* auc);
 
-/* mean |a-b| (nn.L1Loss, src/loss.py:84) -> device double */
-int srad_l1_loss(const float* a, const float* b, int64_t n, double* out, void* stream);
+/* mean |a-b| (nn.L1Loss, src/loss.py:84) -> *out (device double); workspace >= srad_l1_workspace_bytes */
+int srad_l1_workspace_bytes(size_t* bytes);
+int srad_l1_loss(const float* a, const float* b, int64_t n, double* out, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------ single operators
+ * NHWC / token-major fp32 activations [rows][ld]; channel counts and row strides multiples of 4 floats. */
+/* Linear / 1x1 conv / 3x3 conv (pad 1, stride 1|2) with fused prologue + epilogue:
+ *   y = act(LN?(x) . w^T + bias) * alpha + r ;  w in PyTorch layout [N][Cin][taps] (packed into scratch)
+ *   act: 0 none, 1 GELU(erf), 2 LeakyReLU(slope), 3 ReLU; ps = 2 -> PixelShuffle(2) scatter of the output
+ *   nn.Linear (src/drct.py:178-181,262-264), nn.Conv2d (src/drct.py:782,837,844-847; src/drn.py:29-33,95-112) */
+size_t srad_op_gemm_scratch_bytes(int precision, int N, int Cin, int ntaps);
+int srad_op_gemm(int precision, const float* x, int ldx, int B, int Hi, int Wi, int Cin, const float* w, int N,
+                 int ntaps, int stride, const float* bias, const float* ln_g, const float* ln_b, int act, float slope,
+                 float alpha, const float* r, int ldr, float* y, int ldy, int yoff, int ps, void* scratch,
+                 size_t scratch_bytes, void* stream);
+/* WindowAttention core + cyclic shift + window partition/reverse (src/drct.py:271-302,472-506):
+ * qkv [B*H*W][3][heads][hdp] (each head slice padded to hdp floats, hdp % 4 == 0) -> out [B*H*W][d] */
+int srad_op_window_attn(int precision, const float* qkv, float* out, const float* table, int B, int H, int W, int ws,
+                        int shift, int d, int heads, int hdp, void* stream);
+/* nn.LayerNorm over the last dimension, eps 1e-5 (src/drct.py:798,833) */
+int srad_op_layernorm(const float* x, int ldx, float* y, int ldy, int rows, int C, const float* g, const float* b,
+                      void* stream);
+
+/* ------------------------------------------------------------------ diagnostics
+ * Per-kernel-class device timing with HIP events on the launch stream (bench.py's roofline numbers). */
+int srad_prof_enable(int on);
+int srad_prof_num_classes(void);
+const char* srad_prof_class_name(int cls);
+int srad_prof_collect(int64_t* launches, double* ms, double* flops, double* bytes);
+/* Back-to-back launches of one kernel, average microseconds per launch (tools/gemm_bench.py). */
+int srad_bench_gemm(int precision, const float* x, int ldx, int B, int Hi, int Wi, int Cin, const float* w, int N,
+                    int ntaps, int stride, const float* bias, const float* ln_g, const float* ln_b, int act,
+                    const float* r, int ldr, float* y, int ldy, int hsplit_hd, int hsplit_hdp, void* scratch,
+                    size_t scratch_bytes, int iters, float* us_out, void* stream);
+int srad_bench_window_attn(int precision, const float* qkv, float* out, const float* table, int B, int H, int W, int ws,
+                           int shift, int d, int heads, int hdp, int iters, float* us_out, void* stream);
 
 #ifdef __cplusplus
 }
