@@ -26,6 +26,18 @@ PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}      # dense MFMA peaks, MI355X_MICROA
 HBM_PEAK = 8.0e12
 
 
+def usable_cores() -> int:
+    """CPU cores this process may actually use (cgroup quota / affinity), not the host's total."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 class Opt:
     n_colors, img_size, window_size, upscale = 1, 32, 8, 4
     embed_dim, depths, num_heads, mlp_ratio, img_range = 180, (6,) * 12, (6,) * 12, 2, 1.0
@@ -139,9 +151,17 @@ def main():
         dom = max(prof, key=lambda k: prof[k]["ms"])
         d = prof[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3)
+        traffic, traffic_src = None, None
+        try:                                   # PMC bytes per launch of the same workload (tools/pmc_summary.py)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/r01_pmc_traffic.json: " + pmc["source"]
+        except Exception:
+            pass
         result["roofline"] = {
             "kernel": dom, "bound": "mfma", "achieved": round(achieved / 1e12, 2), "peak": PEAK[args.dtype] / 1e12,
-            "unit": "TFLOP/s", "frac": round(achieved / PEAK[args.dtype], 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK[args.dtype], 4), "traffic": traffic,
+            "traffic_source": traffic_src,
             "launches_per_step": d["launches"] // reps,
             "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 3),
             "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 4),
@@ -158,6 +178,7 @@ def main():
         if not args.no_cpu_baseline and n_gpus == 1:
             # the reference's --device cpu path, restated (oracle), same weights, same batch, fp32
             from oracle import sr_ref as R
+            torch.set_num_threads(usable_cores())
             sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
             xc = x.cpu()
             cfg = model.cfg
@@ -174,8 +195,8 @@ def main():
             result["cpu_baseline"] = {"value": round(hr_px / cpu_t / 1e6, 4), "unit": "HR Mpixels/s",
                                       "cores": torch.get_num_threads(), "kind": "port",
                                       "sample": f"{n} forwards of the same C2 batch (fp32, torch CPU kernels via "
-                                                f"oracle/sr_ref.py), {cpu_t * 1e3:.0f} ms each; host has "
-                                                f"{os.cpu_count()} logical cores"}
+                                                f"oracle/sr_ref.py), {cpu_t * 1e3:.0f} ms each; {torch.get_num_threads()} threads = "
+                                                f"the cores this job may use, host has {os.cpu_count()} logical cores"}
             result["speedup_vs_cpu"] = round(value / (hr_px / cpu_t / 1e6), 1)
             result["max_rel_err_vs_cpu_fp32"] = float(f"{err:.3e}")
         print(json.dumps(result))
