@@ -87,6 +87,8 @@ _SIG = {
                                   C.c_int, C.POINTER(C.c_float), _P]),
     "srad_bench_window_attn": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
+    "srad_bench_mlp_block": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_size_t, C.c_int, C.c_int,
+                                       C.POINTER(C.c_float), _P]),
     "srad_op_gemm_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "srad_op_window_attn": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, _P]),

@@ -10,6 +10,7 @@
 #include "engine.h"
 #include "../../include/srad.h"
 #include <math.h>
+#include <stdlib.h>
 #include <new>
 
 namespace {
@@ -32,6 +33,7 @@ struct srad_drct {
   int pe_g, pe_b, norm_g, norm_b;
   std::vector<SwinW> blocks;      // n_rdg * 5
   int dmax, hmax, qkvmax;         // widest block dim / hidden / head-padded qkv row
+  bool fuse_mlp = true;           // bf16: second half of each Swin block as one launch (kernels_fused.hip)
   GraphCache gc;
 };
 
@@ -127,6 +129,21 @@ int forward_body(srad_drct* h, const float* x, int B, int H, int W, float* y, co
                      hdp_of(d, sw.heads)};
         SRAD_TRY(srad_launch_window_attn(prec, a, s));
       }
+      const int no = k < 4 ? c.gc : E;
+      if (h->fuse_mlp && srad_mlp_block_supported(prec, T, d, sw.hidden, no)) {
+        // proj + shortcut -> norm2 -> fc1 -> GELU -> fc2 + residual -> adjust_k, one launch
+        // (drct.py:300, 509-510, 184-190, 389-396)
+        MlpBlockParams q{};
+        q.attn = w.attn; q.ld_attn = d; q.shortcut = cur; q.ld_short = D;
+        q.M = T; q.d = d; q.m = sw.hidden; q.no = no;
+        q.w_proj = h->pt.ptr(sw.proj.w); q.w_fc1 = h->pt.ptr(sw.fc1.w); q.w_fc2 = h->pt.ptr(sw.fc2.w); q.w_adj = h->pt.ptr(sw.adjust.w);
+        q.b_proj = h->pt.fptr(sw.proj.b); q.b_fc1 = h->pt.fptr(sw.fc1.b); q.b_fc2 = h->pt.fptr(sw.fc2.b); q.b_adj = h->pt.fptr(sw.adjust.b);
+        q.ln_g = h->pt.fptr(sw.n2g); q.ln_b = h->pt.fptr(sw.n2b); q.dbg = 0;
+        if (k < 4) { q.act = SRAD_ACT_LRELU; q.slope = 0.2f; q.alpha = 1.f; q.R = nullptr; q.ldr = 0; q.Y = cur; q.ldy = D; q.yoff = d; }
+        else { q.act = SRAD_ACT_NONE; q.slope = 0.f; q.alpha = 0.2f; q.R = cur; q.ldr = D; q.Y = nxt; q.ldy = D; q.yoff = 0; }
+        SRAD_TRY(srad_launch_mlp_block(q, s));
+        continue;
+      }
       // proj + shortcut                               (drct.py:300, 509)
       {
         GemmParams p = base_gemm(h, sw.proj, w.attn, d, T, w.x1, d);
@@ -215,6 +232,7 @@ int srad_drct_create(const srad_drct_config* cfg, srad_drct_t** out) {
   if (!h) return srad_set_error(SRAD_ERR_NOMEM, "drct_create: out of host memory");
   h->cfg = *cfg;
   h->pt.prec = cfg->precision;
+  h->fuse_mlp = getenv("SRAD_NO_FUSE") == nullptr;
   const int E = cfg->embed_dim, C = cfg->in_chans, ws = cfg->window_size, F = cfg->num_feat;
   h->conv_first = h->pt.add_layer("conv_first", E, C, 9, true);
   h->pe_g = h->pt.add_raw("patch_embed.norm.weight", E);

@@ -1,0 +1,358 @@
+// kernels_fused.hip - the second half of a DRCT Swin block as ONE launch (bf16 MFMA, fp32 accumulate):
+//
+//   x1  = shortcut + proj(attn) + b_proj                         (src/drct.py:300, 509)
+//   x2  = x1 + fc2(GELU(fc1(LayerNorm2(x1)) + b1)) + b2          (src/drct.py:510, 184-190)
+//   out = act(adjust(x2) + b_adj) * alpha (+ R)                  (src/drct.py:389-396: 1x1 conv,
+//                                                                  LeakyReLU 0.2 / "*0.2 + x" for adjust5)
+//
+// Everything after the attention is row-wise, so a workgroup owns 32 token rows for the whole chain:
+// the rows' activations never leave the CU (A operands in LDS as bf16, x1/x2 in accumulator registers
+// in fp32), and the four weight matrices are streamed through one LDS stage buffer, 128 output columns
+// x up to 256 k per stage, with later stages' global loads in flight behind the current MFMAs.
+// This replaces four launches (proj, fc1, fc2, adjust) and three HBM round trips per block.
+//
+// Measured on MI355X (tools/fused_bench.py) and designed around:
+//   * bias / gamma / beta loads inside the per-group epilogues each cost a memory round trip: they are
+//     staged into LDS once at the top.
+//   * 16x32 wave tiles made the kernel LDS-read bound (3 KB of fragments per 2 MFMAs); each wave now owns a
+//     32x32 tile of the stage (2 A + 2 B fragments per 4 MFMAs).
+//   * a runtime column-group index sends the accumulator tiles to scratch, so the stage geometry is a
+//     template parameter and the stage sequence is unrolled with static_for.
+// Rules carried over from kernels_gemm.hip: unconditional loads on clamped addresses, padding zeroed by
+// selects when values are written to LDS (never "x * 0": the clamped reads may be NaN bit patterns).
+#include "srad_common.h"
+#include <type_traits>
+
+namespace {
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I = B .. N-1
+template <int B, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < N) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, N>(f);
+  }
+}
+
+constexpr int FM = 32;             // rows per workgroup
+constexpr int F_LDA = 392;         // LDS row stride of the <=384-wide bf16 activation tile
+constexpr int F_LDH = 520;         // LDS row stride of the <=512-wide hidden tile
+constexpr int F_LDW = 264;         // LDS row stride of a weight stage (256 k + pad)
+constexpr int F_SC = 128;          // output columns per weight stage
+constexpr int F_NV = 2560;         // floats of bias / gamma / beta staged in LDS (10 per thread)
+
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): enough below bf16 resolution, ~4x fewer
+// instructions than erff
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = 1.0f / (1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erfa = 1.0f - poly * __expf(-z * z);
+  return 0.5f * x * (1.0f + (x < 0.f ? -erfa : erfa));
+}
+
+// GD/GM/GN = 128-column groups of the block dim / hidden / adjust output, KGD/KGM = 256-wide k groups
+// of the block dim / hidden.
+template <int GD, int KGD, int GM, int KGM, int GN>
+__global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* A1 = reinterpret_cast<__bf16*>(smem);                  // [FM][F_LDA] attn tile -> LN2(x1) -> x2
+  __bf16* Hs = A1 + FM * F_LDA;                                  // [FM][F_LDH] GELU(fc1)
+  __bf16* Ws = Hs + FM * F_LDH;                                  // [F_SC][F_LDW] weight stage
+  float* vec = reinterpret_cast<float*>(Ws + F_SC * F_LDW);      // b_proj | b_fc1 | b_fc2 | b_adj | gamma | beta
+  float* red = vec + F_NV;                                       // [FM][8 waves][2] LayerNorm partial sums
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int m0 = blockIdx.x * FM;
+  const int d = p.d, m = p.m, no = p.no;
+  const int Kd = (d + 31) & ~31, Km = (m + 31) & ~31;            // packed K of the weights (multiples of 32)
+  constexpr int n_proj = GD * KGD, n_fc1 = GM * KGD, n_fc2 = GD * KGM, n_adj = GN * KGD;
+  constexpr int n_stages = n_proj + n_fc1 + n_fc2 + n_adj;
+  // offsets of the staged vectors
+  float* const v_bp = vec; float* const v_b1 = vec + 384; float* const v_b2 = vec + 896; float* const v_ba = vec + 1280;
+  float* const v_g = vec + 1664; float* const v_b = vec + 2048;
+
+  auto stage_ptr = [&](int s, int& Kp, int& nch) -> const char* {
+    s = min(s, n_stages - 1);
+    const char* w; int kgs;
+    if (s < n_proj) { w = (const char*)p.w_proj; Kp = Kd; kgs = KGD; }
+    else if ((s -= n_proj) < n_fc1) { w = (const char*)p.w_fc1; Kp = Kd; kgs = KGD; }
+    else if ((s -= n_fc1) < n_fc2) { w = (const char*)p.w_fc2; Kp = Km; kgs = KGM; }
+    else { s -= n_fc2; w = (const char*)p.w_adj; Kp = Kd; kgs = KGD; }
+    const int g = s / kgs, kg = s - g * kgs;
+    nch = min(8, (Kp >> 5) - kg * 8);
+    return w + ((size_t)(g * F_SC) * Kp + kg * 256) * 2;
+  };
+
+  // 8 waves (two per SIMD): a lone wave issues one VALU instruction per 4 cycles, two interleave at 2, and
+  // the epilogue / staging arithmetic of this kernel is VALU-issue bound.
+  constexpr int NSETS = 3;
+  u32x4 w_reg[NSETS][8];
+  const int w_seg = tid & 31, w_row = tid >> 5;                  // rows w_row + 16*j (j < 8), 16-byte segment w_seg
+  auto load_w = [&](int s, u32x4 (&reg)[8]) {
+    int Kp, nch;
+    const char* base = stage_ptr(s, Kp, nch);
+    base += (size_t)w_row * Kp * 2 + (w_seg < nch * 4 ? w_seg : 0) * 16;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) reg[j] = *reinterpret_cast<const u32x4*>(base + (size_t)j * 16 * Kp * 2);
+  };
+  auto store_w = [&](const u32x4 (&reg)[8]) {
+    char* dst = reinterpret_cast<char*>(Ws) + (w_row * F_LDW) * 2 + w_seg * 16;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(dst + j * 16 * F_LDW * 2) = reg[j];
+  };
+  // c[rt] += (A[32 rows][k0 .. k0 + nch*32) . Ws[16 columns of this wave][..]^T)^T
+  auto mma_stage = [&](const __bf16* A, int lda, int k0, int nch, f32x4 (&c)[2]) {
+    const __bf16* ar = A + fr * lda + k0 + 8 * fq;
+    const __bf16* wr = Ws + (wave * 16 + fr) * F_LDW + 8 * fq;
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      if (cc < nch) {
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ar + cc * 32);
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ar + 16 * lda + cc * 32);
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wr + cc * 32);
+        // operands swapped (W as the MFMA "A", activations as "B"): the result tile is transposed, so a lane
+        // holds 4 CONSECUTIVE OUTPUT COLUMNS (4*fq + e) of one token row (fr) - exactly the k-contiguous
+        // quad the next GEMM's A operand, the bias/residual vectors and the global store want.
+        c[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a0, c[0], 0, 0, 0);
+        c[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a1, c[1], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- issue the independent loads: attn tile, first weight stages, vectors, shortcut in C layout ----
+  f32x4 a_reg[6];
+  {
+    const int row = tid >> 4, q16 = tid & 15;                     // 32 rows x 96 float4 (384 columns)
+    const char* src = reinterpret_cast<const char*>(p.attn) + (size_t)(m0 + row) * p.ld_attn * 4;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) a_reg[j] = *reinterpret_cast<const f32x4*>(src + (unsigned)min((q16 + 16 * j) * 4, d - 4) * 4u);
+  }
+#pragma unroll
+  for (int q = 0; q < NSETS; ++q) load_w(q, w_reg[q]);
+  float vq[5];
+  {
+    // staged vectors: [0,384) b_proj, [384,896) b_fc1, [896,1280) b_fc2, [1280,1664) b_adj, [1664,2048) gamma,
+    // [2048,2432) beta (clamped reads; entries past a vector's length are never used)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int i = tid + 512 * q;
+      const float* src; int n, o;
+      if (i < 384) { src = p.b_proj; n = d; o = i; }
+      else if (i < 896) { src = p.b_fc1; n = m; o = i - 384; }
+      else if (i < 1280) { src = p.b_fc2; n = d; o = i - 896; }
+      else if (i < 1664) { src = p.b_adj; n = no; o = i - 1280; }
+      else if (i < 2048) { src = p.ln_g; n = d; o = i - 1664; }
+      else { src = p.ln_b; n = d; o = i - 2048; }
+      vq[q] = src[min(o, n - 1)];
+    }
+  }
+  // accumulator layout of this lane: token row 16*rt + fr, columns 128*g + 16*wave + 4*fq + (0..3)
+  f32x4 x1[GD][2];
+#pragma unroll
+  for (int g = 0; g < GD; ++g) {
+    const int c4 = min(F_SC * g + 16 * wave + 4 * fq, d - 4);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+      x1[g][rt] = (p.dbg & 32) ? f32x4{0.f, 0.f, 0.f, 0.f}
+                               : *reinterpret_cast<const f32x4*>(p.shortcut + (size_t)(m0 + rt * 16 + fr) * p.ld_short + c4);
+  }
+#pragma unroll
+  for (int q = 0; q < 5; ++q) vec[tid + 512 * q] = vq[q];
+  {  // attn tile -> bf16 -> A1 (zero beyond d)
+    const int row = tid >> 4, q16 = tid & 15;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int c = (q16 + 16 * j) * 4;
+      const f32x4 v = c < d ? a_reg[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x4 h;
+      h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+      *reinterpret_cast<bf16x4*>(A1 + row * F_LDA + c) = h;
+    }
+  }
+
+  // ---- phase epilogues (run when the last k-group of a 128-column group is done) ----
+  auto col4_of = [&](int g) { return F_SC * g + 16 * wave + 4 * fq; };
+  auto store_bf4 = [&](__bf16* base, int ld, int rt, int c4, f32x4 v) {
+    bf16x4 h;
+    h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+    *reinterpret_cast<bf16x4*>(base + (rt * 16 + fr) * ld + c4) = h;
+  };
+  auto epi_proj = [&](auto G, const f32x4 (&c)[2]) {
+    constexpr int g = decltype(G)::value;
+    {
+      const f32x4 bp = *reinterpret_cast<const f32x4*>(v_bp + min(col4_of(g), 380));
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) x1[g][rt] += c[rt] + bp;
+    }
+    if constexpr (g != GD - 1) return;
+    // LayerNorm2 over the d real columns of x1 -> bf16 -> A1 (all proj reads of A1 are behind a barrier)
+    float sm[2] = {0.f, 0.f}, sq[2] = {0.f, 0.f};
+#pragma unroll
+    for (int gg = 0; gg < GD; ++gg) {
+      const bool in = col4_of(gg) < d;                             // d % 4 == 0: a quad is all in or all out
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const f32x4 v = in ? x1[gg][rt] : f32x4{0.f, 0.f, 0.f, 0.f};
+        sm[rt] += (v[0] + v[1]) + (v[2] + v[3]);
+        sq[rt] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+      }
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      sm[rt] += __shfl_xor(sm[rt], 16); sq[rt] += __shfl_xor(sq[rt], 16);
+      sm[rt] += __shfl_xor(sm[rt], 32); sq[rt] += __shfl_xor(sq[rt], 32);
+      if (fq == 0) {
+        red[((rt * 16 + fr) * 8 + wave) * 2 + 0] = sm[rt];
+        red[((rt * 16 + fr) * 8 + wave) * 2 + 1] = sq[rt];
+      }
+    }
+    __syncthreads();
+    float mu[2], rstd[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const float* r = red + (rt * 16 + fr) * 16;
+      float su = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { su += r[2 * w]; s2 += r[2 * w + 1]; }
+      mu[rt] = su / (float)d;
+      rstd[rt] = rsqrtf(fmaxf(s2 / (float)d - mu[rt] * mu[rt], 0.f) + 1e-5f);
+    }
+#pragma unroll
+    for (int gg = 0; gg < GD; ++gg) {
+      const int c4 = col4_of(gg);
+      const bool in = c4 < d;
+      const f32x4 gam = *reinterpret_cast<const f32x4*>(v_g + min(c4, 380));
+      const f32x4 bet = *reinterpret_cast<const f32x4*>(v_b + min(c4, 380));
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const f32x4 v = in ? (x1[gg][rt] - mu[rt]) * rstd[rt] * gam + bet : f32x4{0.f, 0.f, 0.f, 0.f};
+        store_bf4(A1, F_LDA, rt, c4, v);
+      }
+    }
+  };
+  auto epi_fc1 = [&](int g, const f32x4 (&c)[2]) {
+    const int c4 = col4_of(g);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(v_b1 + min(c4, 508));
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      f32x4 v = c[rt] + b1;
+      if (!(p.dbg & 4)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+      }
+      store_bf4(Hs, F_LDH, rt, c4, c4 < m ? v : f32x4{0.f, 0.f, 0.f, 0.f});      // m % 4 == 0
+    }
+  };
+  auto epi_fc2 = [&](auto G, const f32x4 (&c)[2]) {
+    constexpr int g = decltype(G)::value;
+    {
+      const f32x4 b2 = *reinterpret_cast<const f32x4*>(v_b2 + min(col4_of(g), 380));
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) x1[g][rt] += c[rt] + b2;
+    }
+    if constexpr (g != GD - 1) return;
+    // x2 -> bf16 -> A1 (its last readers, the fc1 stages, finished long ago)
+#pragma unroll
+    for (int gg = 0; gg < GD; ++gg) {
+      const int c4 = col4_of(gg);
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) store_bf4(A1, F_LDA, rt, c4, c4 < d ? x1[gg][rt] : f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+  };
+  auto epi_adj = [&](int g, const f32x4 (&c)[2]) {
+    const int c4 = col4_of(g);
+    const int cc = min(c4, no - 4);                                 // no % 4 == 0
+    const f32x4 ba = *reinterpret_cast<const f32x4*>(v_ba + min(c4, 380));
+    f32x4 rv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (p.R) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) rv[rt] = *reinterpret_cast<const f32x4*>(p.R + (size_t)(m0 + rt * 16 + fr) * p.ldr + cc);
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      f32x4 v = c[rt] + ba;
+      if (p.act == SRAD_ACT_LRELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+      }
+      v = v * p.alpha + rv[rt];
+      if (c4 < no) *reinterpret_cast<f32x4*>(p.Y + (size_t)(m0 + rt * 16 + fr) * p.ldy + p.yoff + c4) = v;
+    }
+  };
+
+  // ---- all weight stages, unrolled at compile time over the register sets ----
+  f32x4 c[2];
+  static_for<0, n_stages>([&](auto S) {
+    constexpr int s = decltype(S)::value;
+    constexpr int ph = s < n_proj ? 0 : (s < n_proj + n_fc1 ? 1 : (s < n_proj + n_fc1 + n_fc2 ? 2 : 3));
+    constexpr int ls = s - (ph == 0 ? 0 : (ph == 1 ? n_proj : (ph == 2 ? n_proj + n_fc1 : n_proj + n_fc1 + n_fc2)));
+    constexpr int kgs = ph == 2 ? KGM : KGD;
+    constexpr int g = ls / kgs, kg = ls - g * kgs;
+    u32x4 (&reg)[8] = w_reg[s % NSETS];
+    const int Kp = ph == 2 ? Km : Kd;
+    const int nch = min(8, (Kp >> 5) - kg * 8);
+    if (!(p.dbg & 8)) store_w(reg);
+    __syncthreads();                                   // stage (and any A tile / vector written before) visible
+    if (!(p.dbg & 1)) load_w(s + NSETS, reg);          // refill this set, NSETS stages ahead
+    if constexpr (kg == 0) { c[0] = f32x4{0.f, 0.f, 0.f, 0.f}; c[1] = c[0]; }
+    if (!(p.dbg & 2)) mma_stage(ph == 2 ? Hs : A1, ph == 2 ? F_LDH : F_LDA, kg * 256, nch, c);
+    __syncthreads();                                   // stage buffer free again
+    if (!(p.dbg & 16)) if constexpr (kg == kgs - 1) {
+      if constexpr (ph == 0) epi_proj(std::integral_constant<int, g>{}, c);
+      else if constexpr (ph == 1) epi_fc1(g, c);
+      else if constexpr (ph == 2) epi_fc2(std::integral_constant<int, g>{}, c);
+      else epi_adj(g, c);
+    }
+  });
+}
+
+struct FusedCfg { int gd, kgd, gm, kgm, gn; };
+inline FusedCfg fused_cfg(int d, int m, int no) {
+  const int Kd = srad_cp(d), Km = srad_cp(m);
+  return FusedCfg{(d + F_SC - 1) / F_SC, (Kd + 255) / 256, (m + F_SC - 1) / F_SC, (Km + 255) / 256, (no + F_SC - 1) / F_SC};
+}
+template <int GD, int KGD, int GM, int KGM, int GN>
+int launch_mlp(const MlpBlockParams& p, hipStream_t stream) {
+  constexpr size_t lds = (size_t)(FM * F_LDA + FM * F_LDH + F_SC * F_LDW) * 2 + (F_NV + FM * 16) * sizeof(float);
+  auto kern = mlp_block_kernel<GD, KGD, GM, KGM, GN>;
+  static bool configured = false;
+  if (!configured) {
+    SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  const double flops = 2.0 * p.M * ((double)p.d * p.d + 2.0 * p.d * p.m + (double)p.no * p.d);
+  const double bytes = 4.0 * p.M * (2.0 * p.d + p.no) + 2.0 * ((double)p.d * p.d + 2.0 * p.d * p.m + (double)p.no * p.d);
+  SradProfScope prof(stream, SRAD_K_MLP_BLOCK, flops, bytes);
+  hipLaunchKernelGGL(kern, dim3(p.M / FM), dim3(512), lds, stream, p);
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}
+// stage geometries of DRCT-L's Swin blocks (embed 180 + k*32; mlp ratio 2,2,2,1,1; adjust to 32 / 180 channels)
+#define SRAD_FUSED_CFGS(X) X(2, 1, 3, 2, 1) X(2, 1, 4, 2, 1) X(3, 2, 3, 2, 1) X(3, 2, 3, 2, 2)
+}  // namespace
+
+bool srad_mlp_block_supported(int prec, int M, int d, int m, int no) {
+  if (!(prec == SRAD_PREC_BF16 && M % FM == 0 && d % 4 == 0 && m % 4 == 0 && no % 4 == 0 && d >= 32 && d <= 384 && m >= 32 &&
+        m <= 512 && no >= 4 && no <= 384))
+    return false;
+  const FusedCfg c = fused_cfg(d, m, no);
+#define X(a, b, cc, dd, e) if (c.gd == a && c.kgd == b && c.gm == cc && c.kgm == dd && c.gn == e) return true;
+  SRAD_FUSED_CFGS(X)
+#undef X
+  return false;
+}
+
+int srad_launch_mlp_block(const MlpBlockParams& p, hipStream_t stream) {
+  SRAD_REQUIRE(srad_mlp_block_supported(SRAD_PREC_BF16, p.M, p.d, p.m, p.no), "mlp_block: unsupported shape M=%d d=%d m=%d no=%d", p.M, p.d, p.m, p.no);
+  SRAD_REQUIRE((p.ld_attn & 3) == 0 && ((uintptr_t)p.attn & 15) == 0, "mlp_block: attn rows must be float4-addressable");
+  SRAD_REQUIRE((p.ld_short & 3) == 0 && ((uintptr_t)p.shortcut & 15) == 0 && (p.ldy & 3) == 0 && (p.yoff & 3) == 0 &&
+                   ((uintptr_t)p.Y & 15) == 0 && (!p.R || ((p.ldr & 3) == 0 && ((uintptr_t)p.R & 15) == 0)),
+               "mlp_block: shortcut / output / residual rows must be float4-addressable");
+  const FusedCfg c = fused_cfg(p.d, p.m, p.no);
+#define X(a, b, cc, dd, e) if (c.gd == a && c.kgd == b && c.gm == cc && c.kgm == dd && c.gn == e) return launch_mlp<a, b, cc, dd, e>(p, stream);
+  SRAD_FUSED_CFGS(X)
+#undef X
+  return srad_set_error(SRAD_ERR_ARG, "mlp_block: no kernel instance for this geometry");
+}

@@ -99,6 +99,42 @@ int srad_bench_window_attn(int precision, const float* qkv, float* out, const fl
   return SRAD_OK;
 }
 
+// Diagnostic: the fused MLP block on synthetic operands, `iters` back-to-back launches, microseconds per launch.
+// scratch must hold the four packed bf16 weights; x/y are [M][320] fp32 buffers.
+int srad_bench_mlp_block(int M, int d, int m, int no, const float* attn, const float* shortcut, float* y,
+                         const float* w_fp32 /* >= 512*512 floats */, void* scratch, size_t scratch_bytes, int dbg,
+                         int iters, float* us_out, void* stream) {
+  SRAD_REQUIRE(attn && shortcut && y && w_fp32 && scratch && us_out && iters > 0, "bench_mlp_block: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t b1 = srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, d, d, 1), 256), b2 = srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, m, d, 1), 256),
+               b3 = srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, d, m, 1), 256), b4 = srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, no, d, 1), 256);
+  SRAD_REQUIRE(scratch_bytes >= b1 + b2 + b3 + b4, "bench_mlp_block: scratch too small");
+  char* sc = reinterpret_cast<char*>(scratch);
+  SRAD_TRY(srad_launch_pack_weight(SRAD_PREC_BF16, w_fp32, sc, d, d, 1, s));
+  SRAD_TRY(srad_launch_pack_weight(SRAD_PREC_BF16, w_fp32, sc + b1, m, d, 1, s));
+  SRAD_TRY(srad_launch_pack_weight(SRAD_PREC_BF16, w_fp32, sc + b1 + b2, d, m, 1, s));
+  SRAD_TRY(srad_launch_pack_weight(SRAD_PREC_BF16, w_fp32, sc + b1 + b2 + b3, no, d, 1, s));
+  MlpBlockParams q{};
+  q.attn = attn; q.ld_attn = 320; q.shortcut = shortcut; q.ld_short = 320; q.M = M; q.d = d; q.m = m; q.no = no;
+  q.w_proj = sc; q.w_fc1 = sc + b1; q.w_fc2 = sc + b1 + b2; q.w_adj = sc + b1 + b2 + b3;
+  q.b_proj = q.b_fc1 = q.b_fc2 = q.b_adj = q.ln_g = q.ln_b = w_fp32;
+  q.act = SRAD_ACT_LRELU; q.slope = 0.2f; q.alpha = 1.f; q.R = nullptr; q.ldr = 0; q.Y = y; q.ldy = 320; q.yoff = 0; q.dbg = dbg;
+  for (int i = 0; i < 3; ++i) SRAD_TRY(srad_launch_mlp_block(q, s));
+  hipEvent_t a, b;
+  SRAD_CHECK_HIP(hipEventCreate(&a));
+  SRAD_CHECK_HIP(hipEventCreate(&b));
+  SRAD_CHECK_HIP(hipEventRecord(a, s));
+  for (int i = 0; i < iters; ++i) SRAD_TRY(srad_launch_mlp_block(q, s));
+  SRAD_CHECK_HIP(hipEventRecord(b, s));
+  SRAD_CHECK_HIP(hipEventSynchronize(b));
+  float ms = 0.f;
+  SRAD_CHECK_HIP(hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  *us_out = ms * 1e3f / iters;
+  return SRAD_OK;
+}
+
 size_t srad_op_gemm_scratch_bytes(int precision, int N, int Cin, int ntaps) {
   return srad_packed_bytes(precision, N, Cin, ntaps);
 }

@@ -76,7 +76,7 @@ int srad_launch_gemm(int prec, const GemmParams& p, hipStream_t stream);
 
 // Packed weight geometry shared by the packer and the GEMM
 static inline int srad_cp(int cin) { return srad_round_up(cin, 32); }
-static inline int srad_np(int n) { return srad_round_up(n, 64); }
+static inline int srad_np(int n) { return srad_round_up(n, 128); }   // rows padded so 64- and 128-row stages never leave the tensor
 static inline size_t srad_packed_bytes(int prec, int n, int cin, int ntaps) {
   return (size_t)srad_np(n) * ntaps * srad_cp(cin) * (prec == SRAD_PREC_BF16 ? 2 : 4);
 }
@@ -97,6 +97,25 @@ struct AttnParams {
 int srad_launch_window_attn(int prec, const AttnParams& p, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------
+// Fused second half of a Swin block (kernels_fused.hip): proj + shortcut -> LayerNorm2 -> fc1 -> GELU
+// -> fc2 + residual -> adjust 1x1 conv (+ LeakyReLU | * alpha + R), 32 token rows per workgroup.
+// Weights are the ordinary packed bf16 matrices ([ceil64(N)][ceil32(K)]).
+// ------------------------------------------------------------------------------------------
+struct MlpBlockParams {
+  const float* attn; int ld_attn;        // [M][d] attention output (pre-proj)
+  const float* shortcut; int ld_short;   // [M][>=d] block input (residual)
+  int M, d, m, no;                       // rows, block dim, MLP hidden, adjust output channels
+  const void *w_proj, *w_fc1, *w_fc2, *w_adj;
+  const float *b_proj, *b_fc1, *b_fc2, *b_adj, *ln_g, *ln_b;
+  int act; float slope, alpha;           // adjust epilogue
+  const float* R; int ldr;
+  float* Y; int ldy, yoff;
+  int dbg;                               // timing experiments only (tools/): 1 skip W loads, 2 skip MFMA, 4 skip GELU, 8 skip W LDS stores
+};
+bool srad_mlp_block_supported(int prec, int M, int d, int m, int no);
+int srad_launch_mlp_block(const MlpBlockParams& p, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------
 // misc kernels
 // ------------------------------------------------------------------------------------------
 int srad_launch_layernorm(const float* x, int ldx, float* y, int ldy, int rows, int C,
@@ -114,7 +133,7 @@ int srad_launch_nhwc_to_nchw(const float* x, int ldx, float* y, int B, int C, in
 // ------------------------------------------------------------------------------------------
 enum {
   SRAD_K_GEMM_BN64 = 0, SRAD_K_GEMM_BN32, SRAD_K_GEMM_BN16, SRAD_K_ATTN, SRAD_K_LAYERNORM,
-  SRAD_K_LAYOUT, SRAD_K_PACK, SRAD_K_SCORE, SRAD_K_MISC, SRAD_K_COUNT
+  SRAD_K_LAYOUT, SRAD_K_PACK, SRAD_K_SCORE, SRAD_K_MISC, SRAD_K_MLP_BLOCK, SRAD_K_COUNT
 };
 struct SradProfScope {
   hipStream_t s; int active;

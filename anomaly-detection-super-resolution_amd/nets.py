@@ -78,7 +78,7 @@ class _EngineModule(nn.Module):
         self.use_graph = bool(use_graph)
         self._handle = None
         self._arena = None
-        self._packed_versions: Dict[str, tuple] = {}
+        self._param_cache = None
         self._ws: Dict[tuple, torch.Tensor] = {}
         self._static_io: Dict[tuple, tuple] = {}
         self._side_stream = None
@@ -129,22 +129,32 @@ class _EngineModule(nn.Module):
 
     def _sync_weights(self, device):
         """(Re)pack every parameter whose storage or version changed since the last forward
-        (optimizer steps and load_state_dict bump ``_version``)."""
+        (optimizer steps and load_state_dict bump ``_version``).  The steady-state cost is one pass
+        over a cached tensor list (no module-tree walks on the hot path)."""
         self._ensure_handle(device)
+        if getattr(self, "_param_cache", None) is None:
+            self._param_cache = [(name, self.get_parameter(name)) for name, _ in self._engine_params]
+            self._tags = [None] * len(self._param_cache)
+        tags = [(p.data_ptr(), p._version) for _, p in self._param_cache]
+        if tags == self._tags:
+            return
         stream = L.current_stream_ptr()
-        for name, numel in self._engine_params:
-            p = self.get_parameter(name)
+        for i, (name, p) in enumerate(self._param_cache):
+            if tags[i] == self._tags[i]:
+                continue
             if p.device != device or p.dtype != torch.float32:
                 raise RuntimeError(f"{name}: parameters must be fp32 on {device} (got {p.dtype} on {p.device})")
-            tag = (p.data_ptr(), p._version)
-            if self._packed_versions.get(name) == tag:
-                continue
             src = p.detach()
             if not src.is_contiguous():
                 src = src.contiguous()
             L.check(self._fn("set_param")(self._handle, name.encode(), L.dptr(src), C.c_int64(src.numel()), stream),
                     f"set_param({name})")
-            self._packed_versions[name] = tag
+        self._tags = tags
+
+    def _apply(self, fn, *a, **kw):
+        # .to()/.cuda()/.float() replace parameter storage: drop the cached tensor list
+        self._param_cache = None
+        return super()._apply(fn, *a, **kw)
 
     def _workspace(self, B, H, W, device) -> torch.Tensor:
         key = (B, H, W)
@@ -185,7 +195,7 @@ class _EngineModule(nn.Module):
             raise ValueError(f"expected {channels} channels, got {x.shape[1]}")
         if not x.is_cuda:
             raise RuntimeError("srad_amd runs on the GPU only (HIP engine); got a CPU tensor - there is no CPU fallback")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError("the HIP backward pass is not built yet: call under torch.no_grad() / .eval()")
         return x.detach().to(torch.float32).contiguous()
 

@@ -156,6 +156,9 @@ int srad_bench_gemm(int precision, const float* x, int ldx, int B, int Hi, int W
                     int ntaps, int stride, const float* bias, const float* ln_g, const float* ln_b, int act,
                     const float* r, int ldr, float* y, int ldy, int hsplit_hd, int hsplit_hdp, void* scratch,
                     size_t scratch_bytes, int iters, float* us_out, void* stream);
+int srad_bench_mlp_block(int M, int d, int m, int no, const float* attn, const float* shortcut, float* y,
+                         const float* w_fp32, void* scratch, size_t scratch_bytes, int dbg, int iters, float* us_out,
+                         void* stream);
 int srad_bench_window_attn(int precision, const float* qkv, float* out, const float* table, int B, int H, int W, int ws,
                            int shift, int d, int heads, int hdp, int iters, float* us_out, void* stream);
 

@@ -91,3 +91,21 @@ def test_drct_errors():
         m(torch.zeros(1, 1, 32, 32))
     with pytest.raises(ValueError, match="channels"):
         m(torch.zeros(1, 3, 32, 32, device="cuda"))
+
+
+def test_fused_mlp_block_matches_unfused_path(sr_golden, monkeypatch):
+    """bf16: the fused proj+LN2+MLP+adjust launch (kernels_fused.hip) against the four separate
+    launches and against the reference fixture."""
+    cfg, sd, x, y = drct_case(sr_golden, "drct_r2_rgb_x4")
+    xt = torch.from_numpy(x).cuda()
+    monkeypatch.setenv("SRAD_NO_FUSE", "1")
+    with torch.no_grad():
+        unfused = build(cfg, sd, "bf16")(xt).cpu().numpy()
+    monkeypatch.delenv("SRAD_NO_FUSE")
+    with torch.no_grad():
+        fused = build(cfg, sd, "bf16")(xt).cpu().numpy()
+    rng = float(y.max() - y.min())
+    print("fused vs unfused max/range", np.abs(fused - unfused).max() / rng, "fused vs ref", np.abs(fused - y).max() / rng)
+    assert np.abs(fused - unfused).max() / rng < 1e-2
+    assert np.abs(fused - y).max() / rng < 3e-2
+    assert 10 * np.log10(rng ** 2 / np.mean((fused - y).astype(np.float64) ** 2)) > 35.0
