@@ -115,19 +115,29 @@ int forward_body(srad_drct* h, const float* x, int B, int H, int W, float* y, co
     for (int k = 0; k < 5; ++k) {
       const SwinW& sw = h->blocks[i * 5 + k];
       const int d = sw.d;
+      if (h->fuse_mlp && srad_qkv_attn_supported(prec, c.window_size, H, W, d, sw.heads)) {
+        // norm1 + qkv + shifted-window attention of one (window, head) per workgroup, one launch
+        // (drct.py:477-504, 278-299)
+        QkvAttnParams a{};
+        a.x = cur; a.ldx = D; a.ln_g = h->pt.fptr(sw.n1g); a.ln_b = h->pt.fptr(sw.n1b);
+        a.w_qkv = h->pt.ptr(sw.qkv.w); a.b_qkv = h->pt.fptr(sw.qkv.b); a.table = h->pt.fptr(sw.table);
+        a.out = w.attn; a.ld_out = d; a.B = B; a.H = H; a.W = W; a.shift = sw.shift; a.d = d; a.heads = sw.heads;
+        SRAD_TRY(srad_launch_qkv_attn(a, s));
+      } else {
       // norm1 + qkv                                   (drct.py:477, 278)
-      {
-        const int hdp = hdp_of(d, sw.heads);
-        GemmParams p = base_gemm(h, sw.qkv, cur, D, T, w.qkv, 3 * sw.heads * hdp);
-        p.hsplit_hd = d / sw.heads; p.hsplit_hdp = hdp;      // head-padded q|k|v rows for the attention kernel
-        p.ln_g = h->pt.fptr(sw.n1g); p.ln_b = h->pt.fptr(sw.n1b);
-        SRAD_TRY(srad_launch_gemm(prec, p, s));
-      }
-      // shifted-window attention                      (drct.py:481-504, 281-299)
-      {
-        AttnParams a{w.qkv, w.attn, h->pt.fptr(sw.table), B, H, W, c.window_size, sw.shift, d, sw.heads,
-                     hdp_of(d, sw.heads)};
-        SRAD_TRY(srad_launch_window_attn(prec, a, s));
+        {
+          const int hdp = hdp_of(d, sw.heads);
+          GemmParams p = base_gemm(h, sw.qkv, cur, D, T, w.qkv, 3 * sw.heads * hdp);
+          p.hsplit_hd = d / sw.heads; p.hsplit_hdp = hdp;      // head-padded q|k|v rows for the attention kernel
+          p.ln_g = h->pt.fptr(sw.n1g); p.ln_b = h->pt.fptr(sw.n1b);
+          SRAD_TRY(srad_launch_gemm(prec, p, s));
+        }
+        // shifted-window attention                      (drct.py:481-504, 281-299)
+        {
+          AttnParams a{w.qkv, w.attn, h->pt.fptr(sw.table), B, H, W, c.window_size, sw.shift, d, sw.heads,
+                       hdp_of(d, sw.heads)};
+          SRAD_TRY(srad_launch_window_attn(prec, a, s));
+        }
       }
       const int no = k < 4 ? c.gc : E;
       if (h->fuse_mlp && srad_mlp_block_supported(prec, T, d, sw.hidden, no)) {

@@ -1,0 +1,330 @@
+// kernels_fused_attn.hip - the FIRST half of a DRCT Swin block as one bf16 launch per (window, head):
+//
+//   xn      = LayerNorm1(x[window tokens])                                   (src/drct.py:477)
+//   q|k|v   = xn . Wqkv[head]^T + b                                          (src/drct.py:278)
+//   out     = softmax(q*scale k^T + rel-pos bias + shift mask) v             (src/drct.py:281-299)
+//
+// with the cyclic shift / window partition / reverse (drct.py:482-504) as token index arithmetic.
+// The window's 64 tokens (window size 8) are gathered once, normalised in registers, and stay in LDS as
+// the A operand; the head's three weight slices are streamed through a 64-row LDS stage buffer; q, k, v
+// never exist in HBM.  This replaces the LN1+QKV GEMM launch, its [T][3d] round trip and the attention
+// launch.  Same rules as kernels_gemm.hip / kernels_fused.hip (unconditional clamped loads, selects for
+// padding, template-unrolled stages, transposed MFMA results so a lane owns 4 consecutive columns).
+#include "srad_common.h"
+#include <type_traits>
+
+namespace {
+
+template <int B, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < N) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, N>(f);
+  }
+}
+
+constexpr int QA_LDX = 328;    // LDS row stride of the normalised window tile (d <= 320)
+constexpr int QA_LDW = 264;    // weight stage row stride
+constexpr int QA_LDP = 72;     // probability tile row stride
+
+// HDT = ceil(head_dim / 16) (2, 3, 4, 5 or 8), KG = ceil(ceil32(d) / 256)
+template <int HDT, int KG>
+__global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
+  constexpr int HDP = 16 * HDT;            // padded head dim
+  constexpr int HDP32 = (HDP + 31) & ~31;  // k extent of the q.k^T MFMA steps
+  constexpr int HS = HDP32 + 8;            // q/k/v LDS row stride
+  constexpr int NV = 3 * HDP;              // virtual output columns [q | k | v]
+  constexpr int NS = (NV + 63) / 64;       // 64-column stages
+  constexpr int n_stages = NS * KG;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* XN = reinterpret_cast<__bf16*>(smem);                 // [64][QA_LDX]
+  __bf16* QKV = XN + 64 * QA_LDX;                               // [3][64][HS]
+  __bf16* Ps = QKV + 3 * 64 * HS;                               // [64][QA_LDP]
+  __bf16* Ws = Ps + 64 * QA_LDP;                                // [64][QA_LDW]
+  float* v_g = reinterpret_cast<float*>(Ws + 64 * QA_LDW);      // [320] gamma
+  float* v_b = v_g + 320;                                       // [320] beta
+  float* v_bias = v_b + 320;                                    // [3][HDP] q|k|v bias of this head (0 in padding)
+  float* tbl = v_bias + 3 * HDP;                                // [225] relative position bias of this head
+  float* lsum = tbl + 232;                                      // [64] softmax denominators
+  int* tok = reinterpret_cast<int*>(lsum + 64);                 // [64] token index
+  int* inf = tok + 64;                                          // [64] (region << 16) | (py << 8) | px
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int rt = wave & 3, chh = wave >> 2;                     // GEMM: row tile, 32-column half of a stage
+  const int d = p.d, heads = p.heads, hd = d / heads;
+  const int Kp = (d + 31) & ~31;
+  const int h = blockIdx.x, win = blockIdx.y;
+  const int ws = 8, nWx = p.W / ws, nW = (p.H / ws) * nWx;
+  const int b = win / nW, widx = win - b * nW;
+  const int wy = widx / nWx, wx = widx - wy * nWx;
+  const float scale = rsqrtf((float)hd);
+
+  if (tid < 64) {
+    const int py = tid >> 3, px = tid & 7;
+    const int r = wy * ws + py, c = wx * ws + px;               // coordinates in the shifted image
+    int orr = r + p.shift; if (orr >= p.H) orr -= p.H;
+    int occ = c + p.shift; if (occ >= p.W) occ -= p.W;
+    tok[tid] = (b * p.H + orr) * p.W + occ;
+    const int rh = r < p.H - ws ? 0 : (r < p.H - p.shift ? 1 : 2);
+    const int rw = c < p.W - ws ? 0 : (c < p.W - p.shift ? 1 : 2);
+    inf[tid] = ((rh * 3 + rw) << 16) | (py << 8) | px;
+  }
+  __syncthreads();
+
+  // ---- weight stages: 64 virtual rows [q_h | k_h | v_h], each slice padded to HDP rows ----
+  constexpr int NSETS = 3;
+  u32x4 w_reg[NSETS][4];
+  const int w_seg = tid & 31, w_row = tid >> 5;                 // virtual rows w_row + 16*j (j < 4)
+  const char* const Wb = reinterpret_cast<const char*>(p.w_qkv);
+  auto load_w = [&](int s, u32x4 (&reg)[4]) {
+    s = min(s, n_stages - 1);
+    const int st = s / KG, kg = s - st * KG;
+    const int nch = min(8, (Kp >> 5) - kg * 8);
+    const int seg = w_seg < nch * 4 ? w_seg : 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int vr = st * 64 + w_row + 16 * j;
+      const int which = min(vr / HDP, 2), c = min(vr - (vr / HDP) * HDP, hd - 1);
+      const int row = which * d + h * hd + c;
+      reg[j] = *reinterpret_cast<const u32x4*>(Wb + ((size_t)row * Kp + kg * 256) * 2 + seg * 16);
+    }
+  };
+  auto store_w = [&](const u32x4 (&reg)[4]) {
+    char* dst = reinterpret_cast<char*>(Ws) + (w_row * QA_LDW) * 2 + w_seg * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(dst + j * 16 * QA_LDW * 2) = reg[j];
+  };
+
+  // ---- issue the loads: window rows of x (gathered), first weight stages, vectors ----
+  f32x4 a_reg[10];
+  const int xrow = tid >> 3, col4 = tid & 7;
+  {
+    const char* src = reinterpret_cast<const char*>(p.x) + (size_t)tok[xrow] * p.ldx * 4;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) a_reg[j] = *reinterpret_cast<const f32x4*>(src + (unsigned)min(j * 32 + col4 * 4, d - 4) * 4u);
+  }
+#pragma unroll
+  for (int q = 0; q < NSETS; ++q) load_w(q, w_reg[q]);
+  {
+    // gamma | beta (320 each), bias (3*HDP), table (225): <= 640 + 384 + 225 = 1249 values, 3 per thread
+    float vq[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int i = tid + 512 * q;
+      float v;
+      if (i < 320) v = p.ln_g[min(i, d - 1)];
+      else if (i < 640) v = p.ln_b[min(i - 320, d - 1)];
+      else if (i < 640 + 3 * HDP) {
+        const int o = i - 640, which = o / HDP, c = o - which * HDP;
+        v = p.b_qkv[which * d + h * hd + min(c, hd - 1)];
+        v = c < hd ? v : 0.f;
+      } else {
+        v = p.table[(size_t)min(i - 640 - 3 * HDP, 224) * heads + h];
+      }
+      vq[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int i = tid + 512 * q;
+      if (i < 640 + 3 * HDP + 225) v_g[i] = vq[q];                // gamma | beta | bias | table are contiguous
+    }
+  }
+  if constexpr (HDP32 != HDP) {
+    // head dims padded to 48 / 80: the last 32-wide k step of q.k^T also covers 16 columns no epilogue writes
+    const int row = tid >> 2, part = tid & 3;                     // 128 (q and k) rows x 4 quads of 4 columns
+    *reinterpret_cast<bf16x4*>(QKV + row * HS + HDP + 4 * part) = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+  }
+
+  // ---- LayerNorm1 from the registers (the 8 lanes of a row hold all its columns) -> bf16 -> XN ----
+  {
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const bool in = j * 32 + col4 * 4 < d;
+      const f32x4 v = in ? a_reg[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+      ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+    const float mu = s / (float)d;
+    const float rstd = rsqrtf(fmaxf(ss / (float)d - mu * mu, 0.f) + 1e-5f);
+    __syncthreads();                                              // gamma / beta staged
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const int c = j * 32 + col4 * 4;
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(v_g + c);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(v_b + c);
+      const f32x4 v = c < d ? (a_reg[j] - mu) * rstd * g4 + b4 : f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x4 hh;
+      hh[0] = (__bf16)v[0]; hh[1] = (__bf16)v[1]; hh[2] = (__bf16)v[2]; hh[3] = (__bf16)v[3];
+      *reinterpret_cast<bf16x4*>(XN + xrow * QA_LDX + c) = hh;
+    }
+  }
+
+  // ---- q|k|v = xn . W^T : stages of 64 virtual columns, transposed result (lane: token fr, 4 columns) ----
+  f32x4 acc[2];
+  static_for<0, n_stages>([&](auto S) {
+    constexpr int s = decltype(S)::value;
+    constexpr int st = s / KG, kg = s - st * KG;
+    u32x4 (&reg)[4] = w_reg[s % NSETS];
+    const int nch = min(8, (Kp >> 5) - kg * 8);
+    store_w(reg);
+    __syncthreads();
+    load_w(s + NSETS, reg);
+    if constexpr (kg == 0) { acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0]; }
+    {
+      const __bf16* ar = XN + (rt * 16 + fr) * QA_LDX + kg * 256 + 8 * fq;
+      const __bf16* wr = Ws + (chh * 32 + fr) * QA_LDW + 8 * fq;
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) {
+        if (cc < nch) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + cc * 32);
+          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wr + cc * 32);
+          const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wr + 16 * QA_LDW + cc * 32);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, a, acc[1], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if constexpr (kg == KG - 1) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int vc = st * 64 + chh * 32 + ct * 16 + 4 * fq;     // virtual column of element 0
+        if (vc < NV) {
+          const int which = vc / HDP, c = vc - which * HDP;       // HDP % 16 == 0: a quad stays in one slice
+          const f32x4 bias = *reinterpret_cast<const f32x4*>(v_bias + which * HDP + c);
+          f32x4 v = acc[ct] + bias;
+          if (which == 0) v = v * scale;
+          bf16x4 hh;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hh[e] = (__bf16)(c + e < hd ? v[e] : 0.f);
+          *reinterpret_cast<bf16x4*>(QKV + (which * 64 + rt * 16 + fr) * HS + c) = hh;
+        }
+      }
+    }
+  });
+  __syncthreads();                                                // q, k, v complete
+
+  const __bf16* Qs = QKV;
+  const __bf16* Ks = QKV + 64 * HS;
+  const __bf16* Vs = QKV + 2 * 64 * HS;
+
+  // ---- S = q k^T, bias, mask, softmax: waves 0..3, 16 query rows x 64 keys each ----
+  if (wave < 4) {
+    f32x4 sc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < HDP32; kk += 32) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Qs + (wave * 16 + fr) * HS + kk + 8 * fq);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x8 bb = *reinterpret_cast<const bf16x8*>(Ks + (j * 16 + fr) * HS + kk + 8 * fq);
+        sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, sc[j], 0, 0, 0);
+      }
+    }
+    int qinf[4], kinf[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) qinf[e] = inf[wave * 16 + fq * 4 + e];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kinf[j] = inf[j * 16 + fr];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int qy = (qinf[e] >> 8) & 0xff, qx = qinf[e] & 0xff, qr = qinf[e] >> 16;
+      float mx = -1e30f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ky = (kinf[j] >> 8) & 0xff, kx = kinf[j] & 0xff, kr = kinf[j] >> 16;
+        float v = sc[j][e] + tbl[(qy - ky + 7) * 15 + (qx - kx + 7)];
+        if (p.shift > 0 && qr != kr) v += -100.0f;
+        sc[j][e] = v;
+        mx = fmaxf(mx, v);
+      }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+      float rs = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float pv = __expf(sc[j][e] - mx); sc[j][e] = pv; rs += pv; }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) rs += __shfl_xor(rs, off);
+      if (fr == 0) lsum[wave * 16 + fq * 4 + e] = rs;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Ps[(wave * 16 + fq * 4 + e) * QA_LDP + j * 16 + fr] = (__bf16)sc[j][e];
+    }
+  }
+  __syncthreads();
+
+  // ---- O = P V (transposed result: lane owns token fr of row tile rt, 4 consecutive output columns) ----
+  {
+    const int tq = fr >> 2, tp = fr & 3;
+#pragma unroll
+    for (int j = 0; j < HDT; ++j) {
+      if ((j & 1) != chh) continue;                               // output column tiles split over the two wave groups
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 64; kk += 32) {
+        const bf16x8 pa = *reinterpret_cast<const bf16x8*>(Ps + (rt * 16 + fr) * QA_LDP + kk + 8 * fq);
+        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+        const __bf16* r0 = Vs + (kk + 8 * fq + tq) * HS + j * 16 + 4 * tp;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0 + 4 * HS));
+        bf16x8 vb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vb[e] = lo[e]; vb[4 + e] = hi[e]; }
+        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb, pa, o, 0, 0, 0);
+      }
+      const int row = rt * 16 + fr;
+      const float inv = 1.0f / lsum[row];
+      float* dst = p.out + (size_t)tok[row] * p.ld_out + h * hd;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = j * 16 + 4 * fq + e;
+        if (c < hd) dst[c] = o[e] * inv;
+      }
+    }
+  }
+}
+
+template <int HDT, int KG>
+int launch_qa(const QkvAttnParams& p, hipStream_t stream) {
+  constexpr int HDP = 16 * HDT, HS = ((HDP + 31) & ~31) + 8;
+  constexpr size_t lds = (size_t)(64 * QA_LDX + 3 * 64 * HS + 64 * QA_LDP + 64 * QA_LDW) * 2 +
+                         (size_t)(640 + 3 * HDP + 232 + 64) * sizeof(float) + 128 * sizeof(int);
+  auto kern = qkv_attn_kernel<HDT, KG>;
+  static bool configured = false;
+  if (!configured) {
+    SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  const double T = (double)p.B * p.H * p.W;
+  const double flops = 2.0 * T * 3.0 * p.d * p.d + 4.0 * T * 64.0 * p.d;
+  const double bytes = 4.0 * T * p.d * 2 + 2.0 * 3.0 * p.d * p.d;
+  SradProfScope prof(stream, SRAD_K_QKV_ATTN, flops, bytes);
+  const int nW = (p.H / 8) * (p.W / 8);
+  hipLaunchKernelGGL(kern, dim3(p.heads, p.B * nW), dim3(512), lds, stream, p);
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}
+
+#define SRAD_QA_CFGS(X) X(2, 1) X(4, 1) X(8, 1) X(3, 2) X(5, 2) X(2, 2) X(3, 1) X(4, 2) X(5, 1) X(8, 2)
+}  // namespace
+
+bool srad_qkv_attn_supported(int prec, int ws, int H, int W, int d, int heads) {
+  if (prec != SRAD_PREC_BF16 || ws != 8 || H % 8 || W % 8 || d % 4 || d > 320 || d < 32 || heads < 1 || d % heads) return false;
+  const int hdt = (d / heads + 15) / 16;
+  return hdt == 2 || hdt == 3 || hdt == 4 || hdt == 5 || hdt == 8;
+}
+
+int srad_launch_qkv_attn(const QkvAttnParams& p, hipStream_t stream) {
+  SRAD_REQUIRE(srad_qkv_attn_supported(SRAD_PREC_BF16, 8, p.H, p.W, p.d, p.heads), "qkv_attn: unsupported shape d=%d heads=%d %dx%d", p.d, p.heads, p.H, p.W);
+  SRAD_REQUIRE((p.ldx & 3) == 0 && ((uintptr_t)p.x & 15) == 0, "qkv_attn: x rows must be float4-addressable");
+  SRAD_REQUIRE(p.shift >= 0 && p.shift < 8, "qkv_attn: shift %d must be in [0, 8)", p.shift);
+  const int hdt = (p.d / p.heads + 15) / 16, kg = (srad_cp(p.d) + 255) / 256;
+#define X(a, b) if (hdt == a && kg == b) return launch_qa<a, b>(p, stream);
+  SRAD_QA_CFGS(X)
+#undef X
+  return srad_set_error(SRAD_ERR_ARG, "qkv_attn: no kernel instance for head tiles %d, k groups %d", hdt, kg);
+}

@@ -116,6 +116,21 @@ bool srad_mlp_block_supported(int prec, int M, int d, int m, int no);
 int srad_launch_mlp_block(const MlpBlockParams& p, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------
+// Fused first half of a Swin block (kernels_fused_attn.hip): LayerNorm1 -> q|k|v of one head ->
+// shifted-window attention, one workgroup per (window, head); window size 8 only.
+// ------------------------------------------------------------------------------------------
+struct QkvAttnParams {
+  const float* x; int ldx;                 // block input rows [T][ldx] (columns [0, d) are read)
+  const float *ln_g, *ln_b;
+  const void* w_qkv; const float* b_qkv;   // packed bf16 [ceil128(3d)][ceil32(d)], bias [3d]
+  const float* table;                      // [225][heads]
+  float* out; int ld_out;                  // attention output [T][d]
+  int B, H, W, shift, d, heads;
+};
+bool srad_qkv_attn_supported(int prec, int ws, int H, int W, int d, int heads);
+int srad_launch_qkv_attn(const QkvAttnParams& p, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------
 // misc kernels
 // ------------------------------------------------------------------------------------------
 int srad_launch_layernorm(const float* x, int ldx, float* y, int ldy, int rows, int C,
@@ -133,7 +148,7 @@ int srad_launch_nhwc_to_nchw(const float* x, int ldx, float* y, int B, int C, in
 // ------------------------------------------------------------------------------------------
 enum {
   SRAD_K_GEMM_BN64 = 0, SRAD_K_GEMM_BN32, SRAD_K_GEMM_BN16, SRAD_K_ATTN, SRAD_K_LAYERNORM,
-  SRAD_K_LAYOUT, SRAD_K_PACK, SRAD_K_SCORE, SRAD_K_MISC, SRAD_K_MLP_BLOCK, SRAD_K_COUNT
+  SRAD_K_LAYOUT, SRAD_K_PACK, SRAD_K_SCORE, SRAD_K_MISC, SRAD_K_MLP_BLOCK, SRAD_K_QKV_ATTN, SRAD_K_COUNT
 };
 struct SradProfScope {
   hipStream_t s; int active;
