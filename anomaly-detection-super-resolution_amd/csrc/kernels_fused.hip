@@ -34,7 +34,8 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-constexpr int FM = 32;             // rows per workgroup
+constexpr int FM = 16;             // rows per workgroup
+constexpr int NRT = FM / 16;       // 16-row MFMA tiles per workgroup
 constexpr int F_LDA = 392;         // LDS row stride of the <=384-wide bf16 activation tile
 constexpr int F_LDH = 520;         // LDS row stride of the <=512-wide hidden tile
 constexpr int F_LDW = 264;         // LDS row stride of a weight stage (256 k + pad)
@@ -103,31 +104,35 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(dst + j * 16 * F_LDW * 2) = reg[j];
   };
   // c[rt] += (A[32 rows][k0 .. k0 + nch*32) . Ws[16 columns of this wave][..]^T)^T
-  auto mma_stage = [&](const __bf16* A, int lda, int k0, int nch, f32x4 (&c)[2]) {
+  auto mma_stage = [&](const __bf16* A, int lda, int k0, int nch, f32x4 (&c)[NRT]) {
     const __bf16* ar = A + fr * lda + k0 + 8 * fq;
     const __bf16* wr = Ws + (wave * 16 + fr) * F_LDW + 8 * fq;
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
       if (cc < nch) {
-        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ar + cc * 32);
-        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ar + 16 * lda + cc * 32);
         const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wr + cc * 32);
         // operands swapped (W as the MFMA "A", activations as "B"): the result tile is transposed, so a lane
         // holds 4 CONSECUTIVE OUTPUT COLUMNS (4*fq + e) of one token row (fr) - exactly the k-contiguous
         // quad the next GEMM's A operand, the bias/residual vectors and the global store want.
-        c[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a0, c[0], 0, 0, 0);
-        c[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a1, c[1], 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + rt * 16 * lda + cc * 32);
+          c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, c[rt], 0, 0, 0);
+        }
       }
     }
   };
 
   // ---- issue the independent loads: attn tile, first weight stages, vectors, shortcut in C layout ----
-  f32x4 a_reg[6];
-  {
-    const int row = tid >> 4, q16 = tid & 15;                     // 32 rows x 96 float4 (384 columns)
-    const char* src = reinterpret_cast<const char*>(p.attn) + (size_t)(m0 + row) * p.ld_attn * 4;
+  constexpr int NAQ = 32 * GD;                                    // float4 per row of the attn tile actually needed
+  constexpr int NAJ = FM * NAQ / 512;                             // float4 per thread
+  static_assert(FM * NAQ % 512 == 0, "attn tile must divide over the workgroup");
+  f32x4 a_reg[NAJ];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) a_reg[j] = *reinterpret_cast<const f32x4*>(src + (unsigned)min((q16 + 16 * j) * 4, d - 4) * 4u);
+  for (int j = 0; j < NAJ; ++j) {
+    const int idx = tid + 512 * j, row = idx / NAQ, c = (idx - row * NAQ) * 4;
+    a_reg[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.attn) + (size_t)(m0 + row) * p.ld_attn * 4 +
+                                               (unsigned)min(c, d - 4) * 4u);
   }
 #pragma unroll
   for (int q = 0; q < NSETS; ++q) load_w(q, w_reg[q]);
@@ -149,22 +154,21 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     }
   }
   // accumulator layout of this lane: token row 16*rt + fr, columns 128*g + 16*wave + 4*fq + (0..3)
-  f32x4 x1[GD][2];
+  f32x4 x1[GD][NRT];
 #pragma unroll
   for (int g = 0; g < GD; ++g) {
     const int c4 = min(F_SC * g + 16 * wave + 4 * fq, d - 4);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < NRT; ++rt)
       x1[g][rt] = (p.dbg & 32) ? f32x4{0.f, 0.f, 0.f, 0.f}
                                : *reinterpret_cast<const f32x4*>(p.shortcut + (size_t)(m0 + rt * 16 + fr) * p.ld_short + c4);
   }
 #pragma unroll
   for (int q = 0; q < 5; ++q) vec[tid + 512 * q] = vq[q];
   {  // attn tile -> bf16 -> A1 (zero beyond d)
-    const int row = tid >> 4, q16 = tid & 15;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int c = (q16 + 16 * j) * 4;
+    for (int j = 0; j < NAJ; ++j) {
+      const int idx = tid + 512 * j, row = idx / NAQ, c = (idx - row * NAQ) * 4;
       const f32x4 v = c < d ? a_reg[j] : f32x4{0.f, 0.f, 0.f, 0.f};
       bf16x4 h;
       h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
@@ -179,28 +183,30 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
     *reinterpret_cast<bf16x4*>(base + (rt * 16 + fr) * ld + c4) = h;
   };
-  auto epi_proj = [&](auto G, const f32x4 (&c)[2]) {
+  auto epi_proj = [&](auto G, const f32x4 (&c)[NRT]) {
     constexpr int g = decltype(G)::value;
     {
       const f32x4 bp = *reinterpret_cast<const f32x4*>(v_bp + min(col4_of(g), 380));
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) x1[g][rt] += c[rt] + bp;
+      for (int rt = 0; rt < NRT; ++rt) x1[g][rt] += c[rt] + bp;
     }
     if constexpr (g != GD - 1) return;
     // LayerNorm2 over the d real columns of x1 -> bf16 -> A1 (all proj reads of A1 are behind a barrier)
-    float sm[2] = {0.f, 0.f}, sq[2] = {0.f, 0.f};
+    float sm[NRT], sq[NRT];
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) { sm[rt] = 0.f; sq[rt] = 0.f; }
 #pragma unroll
     for (int gg = 0; gg < GD; ++gg) {
       const bool in = col4_of(gg) < d;                             // d % 4 == 0: a quad is all in or all out
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
+      for (int rt = 0; rt < NRT; ++rt) {
         const f32x4 v = in ? x1[gg][rt] : f32x4{0.f, 0.f, 0.f, 0.f};
         sm[rt] += (v[0] + v[1]) + (v[2] + v[3]);
         sq[rt] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
       }
     }
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < NRT; ++rt) {
       sm[rt] += __shfl_xor(sm[rt], 16); sq[rt] += __shfl_xor(sq[rt], 16);
       sm[rt] += __shfl_xor(sm[rt], 32); sq[rt] += __shfl_xor(sq[rt], 32);
       if (fq == 0) {
@@ -209,9 +215,9 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
       }
     }
     __syncthreads();
-    float mu[2], rstd[2];
+    float mu[NRT], rstd[NRT];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < NRT; ++rt) {
       const float* r = red + (rt * 16 + fr) * 16;
       float su = 0.f, s2 = 0.f;
 #pragma unroll
@@ -226,17 +232,17 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
       const f32x4 gam = *reinterpret_cast<const f32x4*>(v_g + min(c4, 380));
       const f32x4 bet = *reinterpret_cast<const f32x4*>(v_b + min(c4, 380));
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
+      for (int rt = 0; rt < NRT; ++rt) {
         const f32x4 v = in ? (x1[gg][rt] - mu[rt]) * rstd[rt] * gam + bet : f32x4{0.f, 0.f, 0.f, 0.f};
         store_bf4(A1, F_LDA, rt, c4, v);
       }
     }
   };
-  auto epi_fc1 = [&](int g, const f32x4 (&c)[2]) {
+  auto epi_fc1 = [&](int g, const f32x4 (&c)[NRT]) {
     const int c4 = col4_of(g);
     const f32x4 b1 = *reinterpret_cast<const f32x4*>(v_b1 + min(c4, 508));
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < NRT; ++rt) {
       f32x4 v = c[rt] + b1;
       if (!(p.dbg & 4)) {
 #pragma unroll
@@ -245,12 +251,12 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
       store_bf4(Hs, F_LDH, rt, c4, c4 < m ? v : f32x4{0.f, 0.f, 0.f, 0.f});      // m % 4 == 0
     }
   };
-  auto epi_fc2 = [&](auto G, const f32x4 (&c)[2]) {
+  auto epi_fc2 = [&](auto G, const f32x4 (&c)[NRT]) {
     constexpr int g = decltype(G)::value;
     {
       const f32x4 b2 = *reinterpret_cast<const f32x4*>(v_b2 + min(col4_of(g), 380));
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) x1[g][rt] += c[rt] + b2;
+      for (int rt = 0; rt < NRT; ++rt) x1[g][rt] += c[rt] + b2;
     }
     if constexpr (g != GD - 1) return;
     // x2 -> bf16 -> A1 (its last readers, the fc1 stages, finished long ago)
@@ -258,20 +264,22 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     for (int gg = 0; gg < GD; ++gg) {
       const int c4 = col4_of(gg);
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) store_bf4(A1, F_LDA, rt, c4, c4 < d ? x1[gg][rt] : f32x4{0.f, 0.f, 0.f, 0.f});
+      for (int rt = 0; rt < NRT; ++rt) store_bf4(A1, F_LDA, rt, c4, c4 < d ? x1[gg][rt] : f32x4{0.f, 0.f, 0.f, 0.f});
     }
   };
-  auto epi_adj = [&](int g, const f32x4 (&c)[2]) {
+  auto epi_adj = [&](int g, const f32x4 (&c)[NRT]) {
     const int c4 = col4_of(g);
     const int cc = min(c4, no - 4);                                 // no % 4 == 0
     const f32x4 ba = *reinterpret_cast<const f32x4*>(v_ba + min(c4, 380));
-    f32x4 rv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 rv[NRT];
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) rv[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.R) {
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) rv[rt] = *reinterpret_cast<const f32x4*>(p.R + (size_t)(m0 + rt * 16 + fr) * p.ldr + cc);
+      for (int rt = 0; rt < NRT; ++rt) rv[rt] = *reinterpret_cast<const f32x4*>(p.R + (size_t)(m0 + rt * 16 + fr) * p.ldr + cc);
     }
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < NRT; ++rt) {
       f32x4 v = c[rt] + ba;
       if (p.act == SRAD_ACT_LRELU) {
 #pragma unroll
@@ -283,7 +291,7 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
   };
 
   // ---- all weight stages, unrolled at compile time over the register sets ----
-  f32x4 c[2];
+  f32x4 c[NRT];
   static_for<0, n_stages>([&](auto S) {
     constexpr int s = decltype(S)::value;
     constexpr int ph = s < n_proj ? 0 : (s < n_proj + n_fc1 ? 1 : (s < n_proj + n_fc1 + n_fc2 ? 2 : 3));
@@ -296,7 +304,10 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     if (!(p.dbg & 8)) store_w(reg);
     __syncthreads();                                   // stage (and any A tile / vector written before) visible
     if (!(p.dbg & 1)) load_w(s + NSETS, reg);          // refill this set, NSETS stages ahead
-    if constexpr (kg == 0) { c[0] = f32x4{0.f, 0.f, 0.f, 0.f}; c[1] = c[0]; }
+    if constexpr (kg == 0) {
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) c[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     if (!(p.dbg & 2)) mma_stage(ph == 2 ? Hs : A1, ph == 2 ? F_LDH : F_LDA, kg * 256, nch, c);
     __syncthreads();                                   // stage buffer free again
     if (!(p.dbg & 16)) if constexpr (kg == kgs - 1) {

@@ -23,13 +23,14 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-constexpr int QA_LDX = 328;    // LDS row stride of the normalised window tile (d <= 320)
 constexpr int QA_LDW = 264;    // weight stage row stride
 constexpr int QA_LDP = 72;     // probability tile row stride
 
-// HDT = ceil(head_dim / 16) (2, 3, 4, 5 or 8), KG = ceil(ceil32(d) / 256)
-template <int HDT, int KG>
+// HDT = ceil(head_dim / 16) (2, 3, 4, 5 or 8), KC = ceil(d / 32) 32-wide k chunks (<= 10)
+template <int HDT, int KC>
 __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
+  constexpr int KG = (KC + 7) / 8;         // 256-wide k groups per weight stage
+  constexpr int QA_LDX = KC * 32 + 8;      // LDS row stride of the normalised window tile
   constexpr int HDP = 16 * HDT;            // padded head dim
   constexpr int HDP32 = (HDP + 31) & ~31;  // k extent of the q.k^T MFMA steps
   constexpr int HS = HDP32 + 8;            // q/k/v LDS row stride
@@ -39,8 +40,8 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* XN = reinterpret_cast<__bf16*>(smem);                 // [64][QA_LDX]
   __bf16* QKV = XN + 64 * QA_LDX;                               // [3][64][HS]
-  __bf16* Ps = QKV + 3 * 64 * HS;                               // [64][QA_LDP]
-  __bf16* Ws = Ps + 64 * QA_LDP;                                // [64][QA_LDW]
+  __bf16* Ws = QKV + 3 * 64 * HS;                               // [64][QA_LDW] weight stage
+  __bf16* Ps = Ws;                                              // [64][QA_LDP] probabilities (after the GEMM)
   float* v_g = reinterpret_cast<float*>(Ws + 64 * QA_LDW);      // [320] gamma
   float* v_b = v_g + 320;                                       // [320] beta
   float* v_bias = v_b + 320;                                    // [3][HDP] q|k|v bias of this head (0 in padding)
@@ -53,8 +54,10 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
   const int fr = lane & 15, fq = lane >> 4;
   const int rt = wave & 3, chh = wave >> 2;                     // GEMM: row tile, 32-column half of a stage
   const int d = p.d, heads = p.heads, hd = d / heads;
-  const int Kp = (d + 31) & ~31;
-  const int h = blockIdx.x, win = blockIdx.y;
+  constexpr int Kp = KC * 32;
+  // grid = (windows, heads): linear ids of one window's heads differ by a multiple of 8 when the window
+  // count is, so they share an XCD and the window's x rows are fetched into one L2 only
+  const int h = blockIdx.y, win = blockIdx.x;
   const int ws = 8, nWx = p.W / ws, nW = (p.H / ws) * nWx;
   const int b = win / nW, widx = win - b * nW;
   const int wy = widx / nWx, wx = widx - wy * nWx;
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
   auto load_w = [&](int s, u32x4 (&reg)[4]) {
     s = min(s, n_stages - 1);
     const int st = s / KG, kg = s - st * KG;
-    const int nch = min(8, (Kp >> 5) - kg * 8);
+    const int nch = min(8, KC - kg * 8);
     const int seg = w_seg < nch * 4 ? w_seg : 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -97,12 +100,12 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
   };
 
   // ---- issue the loads: window rows of x (gathered), first weight stages, vectors ----
-  f32x4 a_reg[10];
+  f32x4 a_reg[KC];
   const int xrow = tid >> 3, col4 = tid & 7;
   {
     const char* src = reinterpret_cast<const char*>(p.x) + (size_t)tok[xrow] * p.ldx * 4;
 #pragma unroll
-    for (int j = 0; j < 10; ++j) a_reg[j] = *reinterpret_cast<const f32x4*>(src + (unsigned)min(j * 32 + col4 * 4, d - 4) * 4u);
+    for (int j = 0; j < KC; ++j) a_reg[j] = *reinterpret_cast<const f32x4*>(src + (unsigned)min(j * 32 + col4 * 4, d - 4) * 4u);
   }
 #pragma unroll
   for (int q = 0; q < NSETS; ++q) load_w(q, w_reg[q]);
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
   {
     float s = 0.f, ss = 0.f;
 #pragma unroll
-    for (int j = 0; j < 10; ++j) {
+    for (int j = 0; j < KC; ++j) {
       const bool in = j * 32 + col4 * 4 < d;
       const f32x4 v = in ? a_reg[j] : f32x4{0.f, 0.f, 0.f, 0.f};
       s += (v[0] + v[1]) + (v[2] + v[3]);
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
     const float rstd = rsqrtf(fmaxf(ss / (float)d - mu * mu, 0.f) + 1e-5f);
     __syncthreads();                                              // gamma / beta staged
 #pragma unroll
-    for (int j = 0; j < 10; ++j) {
+    for (int j = 0; j < KC; ++j) {
       const int c = j * 32 + col4 * 4;
       const f32x4 g4 = *reinterpret_cast<const f32x4*>(v_g + c);
       const f32x4 b4 = *reinterpret_cast<const f32x4*>(v_b + c);
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
     constexpr int s = decltype(S)::value;
     constexpr int st = s / KG, kg = s - st * KG;
     u32x4 (&reg)[4] = w_reg[s % NSETS];
-    const int nch = min(8, (Kp >> 5) - kg * 8);
+    constexpr int nch = KC - kg * 8 < 8 ? KC - kg * 8 : 8;
     store_w(reg);
     __syncthreads();
     load_w(s + NSETS, reg);
@@ -288,12 +291,12 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
   }
 }
 
-template <int HDT, int KG>
+template <int HDT, int KC>
 int launch_qa(const QkvAttnParams& p, hipStream_t stream) {
   constexpr int HDP = 16 * HDT, HS = ((HDP + 31) & ~31) + 8;
-  constexpr size_t lds = (size_t)(64 * QA_LDX + 3 * 64 * HS + 64 * QA_LDP + 64 * QA_LDW) * 2 +
+  constexpr size_t lds = (size_t)(64 * (KC * 32 + 8) + 3 * 64 * HS + 64 * QA_LDW) * 2 +
                          (size_t)(640 + 3 * HDP + 232 + 64) * sizeof(float) + 128 * sizeof(int);
-  auto kern = qkv_attn_kernel<HDT, KG>;
+  auto kern = qkv_attn_kernel<HDT, KC>;
   static bool configured = false;
   if (!configured) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -304,27 +307,31 @@ int launch_qa(const QkvAttnParams& p, hipStream_t stream) {
   const double bytes = 4.0 * T * p.d * 2 + 2.0 * 3.0 * p.d * p.d;
   SradProfScope prof(stream, SRAD_K_QKV_ATTN, flops, bytes);
   const int nW = (p.H / 8) * (p.W / 8);
-  hipLaunchKernelGGL(kern, dim3(p.heads, p.B * nW), dim3(512), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3(p.B * nW, p.heads), dim3(512), lds, stream, p);
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
 }
 
-#define SRAD_QA_CFGS(X) X(2, 1) X(4, 1) X(8, 1) X(3, 2) X(5, 2) X(2, 2) X(3, 1) X(4, 2) X(5, 1) X(8, 2)
+// (head tiles, k chunks) of DRCT-L's five Swin blocks: d = 180/212/244/276/308, heads 6/4/2/6/4
+#define SRAD_QA_CFGS(X) X(2, 6) X(4, 7) X(8, 8) X(3, 9) X(5, 10)
 }  // namespace
 
 bool srad_qkv_attn_supported(int prec, int ws, int H, int W, int d, int heads) {
   if (prec != SRAD_PREC_BF16 || ws != 8 || H % 8 || W % 8 || d % 4 || d > 320 || d < 32 || heads < 1 || d % heads) return false;
-  const int hdt = (d / heads + 15) / 16;
-  return hdt == 2 || hdt == 3 || hdt == 4 || hdt == 5 || hdt == 8;
+  const int hdt = (d / heads + 15) / 16, kc = (d + 31) / 32;
+#define X(a, b) if (hdt == a && kc == b) return true;
+  SRAD_QA_CFGS(X)
+#undef X
+  return false;
 }
 
 int srad_launch_qkv_attn(const QkvAttnParams& p, hipStream_t stream) {
   SRAD_REQUIRE(srad_qkv_attn_supported(SRAD_PREC_BF16, 8, p.H, p.W, p.d, p.heads), "qkv_attn: unsupported shape d=%d heads=%d %dx%d", p.d, p.heads, p.H, p.W);
   SRAD_REQUIRE((p.ldx & 3) == 0 && ((uintptr_t)p.x & 15) == 0, "qkv_attn: x rows must be float4-addressable");
   SRAD_REQUIRE(p.shift >= 0 && p.shift < 8, "qkv_attn: shift %d must be in [0, 8)", p.shift);
-  const int hdt = (p.d / p.heads + 15) / 16, kg = (srad_cp(p.d) + 255) / 256;
-#define X(a, b) if (hdt == a && kg == b) return launch_qa<a, b>(p, stream);
+  const int hdt = (p.d / p.heads + 15) / 16, kc = (p.d + 31) / 32;
+#define X(a, b) if (hdt == a && kc == b) return launch_qa<a, b>(p, stream);
   SRAD_QA_CFGS(X)
 #undef X
-  return srad_set_error(SRAD_ERR_ARG, "qkv_attn: no kernel instance for head tiles %d, k groups %d", hdt, kg);
+  return srad_set_error(SRAD_ERR_ARG, "qkv_attn: no kernel instance for head tiles %d, k chunks %d", hdt, kc);
 }

@@ -20,6 +20,10 @@ def classify(name: str) -> str:
     if "gemm_kernel" in name:
         args = name.split("gemm_kernel<")[1].split(">")[0].replace(" ", "").split(",")
         return {"64": "gemm_bn64", "32": "gemm_bn32", "16": "gemm_bn16"}[args[2]]
+    if "mlp_block_kernel" in name:
+        return "mlp_block"
+    if "qkv_attn_kernel" in name:
+        return "qkv_attn"
     if "window_attn_kernel" in name:
         return "window_attn"
     if "layernorm_kernel" in name:
