@@ -180,11 +180,12 @@ DrnWs plan_ws(const srad_drn* h, int B, int H, int W, void* base, size_t cap) {
   Bump bp(base, cap);
   DrnWs w;
   w.up0 = bp.take(T0 * SRAD_IMG_CPAD);
-  for (int L = 0; L < P; ++L) w.cat.push_back(bp.take((T0 >> (2 * L)) * 2 * F * (1 << L)));
+  const int F0 = srad_round_up(F, 4);                 // level-0 channel count as stored (x8 preset: 10 -> 12)
+  for (int L = 0; L < P; ++L) w.cat.push_back(bp.take((T0 >> (2 * L)) * 2 * (L == 0 ? F0 : F << L)));
   const size_t TP = T0 >> (2 * P);
   const int top = F << P;
   w.deep = bp.take(TP * top);
-  w.dtmp = bp.take((T0 >> 2) * F);                    // largest: level 0 stride-2 output [T0/4][F]
+  w.dtmp = bp.take((T0 >> 2) * F0);                    // largest: level 0 stride-2 output [T0/4][F]
   // RCAB stacks: idx 0 at level P (top channels), idx >= 1 at level P-idx with 2 F 2^(P-idx) channels
   size_t rmax = TP * top;
   for (int idx = 1; idx < P; ++idx) {
@@ -228,6 +229,7 @@ int forward_body(srad_drn* h, const float* x, int B, int H, int W, float* const*
   const int prec = c.precision, P = h->phase, F = c.n_feats, sc = c.scale, C = c.n_colors;
   const int H0 = H * sc, W0 = W * sc;
   const int top = F << P;
+  const int F0 = srad_round_up(F, 4);   // stored width of the level-0 feature groups; pad columns are exact zeros
   SRAD_CHECK_HIP(hipMemsetAsync(w.pool, 0, w.pool_bytes, s));
   // bicubic upsample to the target size + sub_mean            (drn.py:243-246)
   {
@@ -239,18 +241,19 @@ int forward_body(srad_drn* h, const float* x, int B, int H, int W, float* const*
   }
   // head -> copies[0], stored in cat[0][:, F:2F]               (drn.py:247, 252)
   {
-    GemmParams p = conv_params(h, h->head, w.up0, SRAD_IMG_CPAD, B, H0, W0, 1, w.cat[0], 2 * F, F);
+    GemmParams p = conv_params(h, h->head, w.up0, SRAD_IMG_CPAD, B, H0, W0, 1, w.cat[0], 2 * F0, F0);
     p.Cin = SRAD_IMG_CPAD;
     SRAD_TRY(srad_launch_gemm(prec, p, s));
   }
   // down phases                                               (drn.py:250-253, 83-119)
   for (int L = 0; L < P; ++L) {
-    const int f = F << L, Hl = H0 >> L, Wl = W0 >> L;
+    const int f = L == 0 ? F0 : F << L, Hl = H0 >> L, Wl = W0 >> L;
     GemmParams p = conv_params(h, h->down_s2[L], w.cat[L] + f, 2 * f, B, Hl, Wl, 2, w.dtmp, f, 0);
     p.act = SRAD_ACT_LRELU; p.slope = c.negval;
     SRAD_TRY(srad_launch_gemm(prec, p, s));
     float* dst = L + 1 < P ? w.cat[L + 1] : w.deep;
-    const int ldd = L + 1 < P ? 4 * f : 2 * f, off = L + 1 < P ? 2 * f : 0;
+    const int f1 = F << (L + 1);
+    const int ldd = L + 1 < P ? 2 * f1 : f1, off = L + 1 < P ? f1 : 0;
     GemmParams q = conv_params(h, h->down_s1[L], w.dtmp, f, B, Hl / 2, Wl / 2, 1, dst, ldd, off);
     SRAD_TRY(srad_launch_gemm(prec, q, s));
   }
@@ -294,7 +297,7 @@ int forward_body(srad_drn* h, const float* x, int B, int H, int W, float* const*
       float* t = cur; cur = nxt; nxt = t;
     }
     // Upsampler: conv ch -> 4 ch + PixelShuffle(2), then the 1x1 reducing conv into cat[lvl-1][:, :cout]
-    const int cout = F << (lvl - 1);
+    const int cout = lvl == 1 ? F0 : F << (lvl - 1);
     {
       GemmParams p = conv_params(h, h->up_conv[idx], xin, ldin, B, Hl, Wl, 1, w.ups, ch, 0);
       p.ps = 2;
@@ -327,9 +330,9 @@ int srad_drn_create(const srad_drn_config* cfg, srad_drn_t** out) {
   SRAD_REQUIRE(cfg && out, "drn_create: null argument");
   SRAD_REQUIRE(cfg->n_colors == 1 || cfg->n_colors == 3, "drn_create: n_colors must be 1 or 3 (got %d)", cfg->n_colors);
   SRAD_REQUIRE(cfg->scale == 2 || cfg->scale == 4 || cfg->scale == 8, "drn_create: scale must be 2, 4 or 8 (got %d)", cfg->scale);
-  SRAD_REQUIRE(cfg->n_feats > 0 && cfg->n_feats % 4 == 0,
-               "drn_create: n_feats must be a multiple of 4 for the float4 kernels (got %d; the reference's x8 "
-               "preset n_feats=10 is not supported yet)", cfg->n_feats);
+  SRAD_REQUIRE(cfg->n_feats > 0 && cfg->n_feats % 2 == 0,
+               "drn_create: n_feats must be even (got %d): levels >= 1 then hold multiples of 4 channels and only "
+               "level 0 is zero-padded to one", cfg->n_feats);
   SRAD_REQUIRE(cfg->n_blocks > 0, "drn_create: n_blocks must be positive");
   SRAD_REQUIRE(cfg->precision == SRAD_PREC_F32 || cfg->precision == SRAD_PREC_BF16, "drn_create: bad precision %d", cfg->precision);
   srad_drn* h = new (std::nothrow) srad_drn();
@@ -340,16 +343,23 @@ int srad_drn_create(const srad_drn_config* cfg, srad_drn_t** out) {
   for (int s = cfg->scale; s > 1; s >>= 1) ++P;
   h->phase = P;
   const int C = cfg->n_colors, F = cfg->n_feats, top = F << P;
+  const int F0 = srad_round_up(F, 4), g0 = F0 != F ? F : 0, g0p = F0 != F ? F0 : 0;   // level-0 group padding
   SRAD_REQUIRE(top <= 512 && top / 16 <= 64, "drn_create: n_feats*2^phase = %d too wide for the gate kernel", top);
   h->sub_w = h->pt.add_raw("sub_mean.weight", C * C);
   h->sub_b = h->pt.add_raw("sub_mean.bias", C);
   h->add_w = h->pt.add_raw("add_mean.weight", C * C);
   h->add_b = h->pt.add_raw("add_mean.bias", C);
-  h->head = h->pt.add_layer("head", F, C, 9, true);
+  h->head = h->pt.add_layer_padded("head", F, C, 9, true, F0, 0, 0);
   for (int p = 0; p < P; ++p) {
     const int f = F << p;
-    h->down_s2.push_back(h->pt.add_layer("down." + std::to_string(p) + ".dual_module.0.0", f, f, 9, false));
-    h->down_s1.push_back(h->pt.add_layer("down." + std::to_string(p) + ".dual_module.1", 2 * f, f, 9, false));
+    const std::string d = "down." + std::to_string(p) + ".dual_module.";
+    if (p == 0) {
+      h->down_s2.push_back(h->pt.add_layer_padded(d + "0.0", f, f, 9, false, F0, g0, g0p));
+      h->down_s1.push_back(h->pt.add_layer_padded(d + "1", 2 * f, f, 9, false, 2 * f, g0, g0p));
+    } else {
+      h->down_s2.push_back(h->pt.add_layer(d + "0.0", f, f, 9, false));
+      h->down_s1.push_back(h->pt.add_layer(d + "1", 2 * f, f, 9, false));
+    }
   }
   h->rcab.resize(P);
   for (int idx = 0; idx < P; ++idx) {
@@ -370,10 +380,12 @@ int srad_drn_create(const srad_drn_config* cfg, srad_drn_t** out) {
     const int cout = F << (P - idx - 1);
     const std::string u = "up_blocks." + std::to_string(idx) + ".";
     h->up_conv.push_back(h->pt.add_layer(u + std::to_string(cfg->n_blocks) + ".0", 4 * cin, cin, 9, true));
-    h->up_1x1.push_back(h->pt.add_layer(u + std::to_string(cfg->n_blocks + 1), cout, cin, 1, true));
+    h->up_1x1.push_back(h->pt.add_layer_padded(u + std::to_string(cfg->n_blocks + 1), cout, cin, 1, true,
+                                               idx == P - 1 ? F0 : cout, 0, 0));
   }
   h->tail.push_back(h->pt.add_layer("tail.0", C, top, 9, true));
-  for (int j = 1, p = P; p >= 1; ++j, --p) h->tail.push_back(h->pt.add_layer("tail." + std::to_string(j), C, F << p, 9, true));
+  for (int j = 1, p = P; p >= 1; ++j, --p)   // tail.P reads the level-0 concat, two groups of F stored as F0 each
+    h->tail.push_back(h->pt.add_layer_padded("tail." + std::to_string(j), C, F << p, 9, true, C, p == 1 ? g0 : 0, p == 1 ? g0p : 0));
   *out = h;
   return SRAD_OK;
 }
@@ -442,7 +454,10 @@ int srad_drn_flops(const srad_drn_t* h, int B, int H, int W, double* flops) {
   const int P = h->phase, sc = h->cfg.scale;
   const double T0 = (double)B * H * sc * W * sc;
   double f = 0;
-  auto conv = [&](const ConvW& l, double pix) { f += 2.0 * pix * l.n * l.cin * l.ntaps; };
+  auto conv = [&](const ConvW& l, double pix) {   // real (unpadded) sizes
+    const ParamEntry& e = h->pt.entries[l.w];
+    f += 2.0 * pix * e.n * e.cin * e.ntaps;
+  };
   conv(h->head, T0);
   for (int L = 0; L < P; ++L) { conv(h->down_s2[L], T0 / pow(4.0, L + 1)); conv(h->down_s1[L], T0 / pow(4.0, L + 1)); }
   conv(h->tail[0], T0 / pow(4.0, P));
@@ -461,8 +476,9 @@ int srad_drn_flops(const srad_drn_t* h, int B, int H, int W, double* flops) {
 int srad_dual_workspace_bytes(int B, int C, int H, int W, int n_feats, size_t* bytes) {
   SRAD_REQUIRE(bytes && B > 0 && C > 0 && H > 0 && W > 0 && n_feats > 0, "dual_workspace_bytes: bad argument");
   const size_t T = (size_t)B * H * W, T2 = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2);
-  *bytes = srad_align_up(T * SRAD_IMG_CPAD * 4, 256) + srad_align_up(T2 * n_feats * 4, 256) + srad_align_up(T2 * SRAD_IMG_CPAD * 4, 256) +
-           srad_align_up(srad_packed_bytes(SRAD_PREC_F32, n_feats, C, 9), 256) + srad_align_up(srad_packed_bytes(SRAD_PREC_F32, C, n_feats, 9), 256);
+  const int Fp = srad_round_up(n_feats, 4);
+  *bytes = srad_align_up(T * SRAD_IMG_CPAD * 4, 256) + srad_align_up(T2 * Fp * 4, 256) + srad_align_up(T2 * SRAD_IMG_CPAD * 4, 256) +
+           srad_align_up(srad_packed_bytes(SRAD_PREC_F32, Fp, C, 9), 256) + srad_align_up(srad_packed_bytes(SRAD_PREC_F32, C, Fp, 9), 256);
   return SRAD_OK;
 }
 
@@ -470,7 +486,7 @@ int srad_dual_forward(const float* w0, const float* w1, int C, int n_feats, floa
                       int W, float* y, void* workspace, size_t workspace_bytes, int precision, void* stream) {
   SRAD_REQUIRE(w0 && w1 && x && y && workspace, "dual_forward: null argument");
   SRAD_REQUIRE(C == 1 || C == 3, "dual_forward: channels must be 1 or 3 (got %d)", C);
-  SRAD_REQUIRE(n_feats % 4 == 0, "dual_forward: n_feats must be a multiple of 4 (got %d)", n_feats);
+  const int Fp = srad_round_up(n_feats, 4);   // hidden width as stored; pad columns are zeros (x8 preset: 10 -> 12)
   size_t need = 0;
   SRAD_TRY(srad_dual_workspace_bytes(B, C, H, W, n_feats, &need));
   SRAD_REQUIRE(workspace_bytes >= need, "dual_forward: workspace %zu bytes, %zu needed", workspace_bytes, need);
@@ -479,22 +495,22 @@ int srad_dual_forward(const float* w0, const float* w1, int C, int n_feats, floa
   const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
   const size_t T = (size_t)B * H * W, T2 = (size_t)B * H2 * W2;
   float* xin = bp.take(T * SRAD_IMG_CPAD);
-  float* mid = bp.take(T2 * n_feats);
+  float* mid = bp.take(T2 * Fp);
   float* outn = bp.take(T2 * SRAD_IMG_CPAD);
-  void* p0 = bp.take(srad_packed_bytes(SRAD_PREC_F32, n_feats, C, 9) / 4);
-  void* p1 = bp.take(srad_packed_bytes(SRAD_PREC_F32, C, n_feats, 9) / 4);
+  void* p0 = bp.take(srad_packed_bytes(SRAD_PREC_F32, Fp, C, 9) / 4);
+  void* p1 = bp.take(srad_packed_bytes(SRAD_PREC_F32, C, Fp, 9) / 4);
   const float zero3[3] = {0.f, 0.f, 0.f};
   SRAD_TRY(srad_launch_nchw_to_nhwc(x, xin, B, C, SRAD_IMG_CPAD, H, W, zero3, 1.0f, s));
-  SRAD_TRY(srad_launch_pack_weight(precision, w0, p0, n_feats, C, 9, s));
-  SRAD_TRY(srad_launch_pack_weight(precision, w1, p1, C, n_feats, 9, s));
+  SRAD_TRY(srad_launch_pack_weight_padded(precision, w0, p0, n_feats, C, 9, Fp, 0, 0, s));
+  SRAD_TRY(srad_launch_pack_weight_padded(precision, w1, p1, C, n_feats, 9, C, Fp != n_feats ? n_feats : 0, Fp != n_feats ? Fp : 0, s));
   GemmParams a{};
   a.X = xin; a.ldx = SRAD_IMG_CPAD; a.Cin = SRAD_IMG_CPAD; a.Cp = srad_cp(SRAD_IMG_CPAD); a.ntaps = 9;
   a.Hi = H; a.Wi = W; a.Ho = H2; a.Wo = W2; a.stride = 2; a.M = (int)T2;
-  a.ln_eps = 1e-5f; a.Wp = p0; a.N = n_feats; a.act = SRAD_ACT_LRELU; a.slope = negval; a.alpha = 1.f;
-  a.Y = mid; a.ldy = n_feats;
+  a.ln_eps = 1e-5f; a.Wp = p0; a.N = Fp; a.act = SRAD_ACT_LRELU; a.slope = negval; a.alpha = 1.f;
+  a.Y = mid; a.ldy = Fp;
   SRAD_TRY(srad_launch_gemm(precision, a, s));
   GemmParams b{};
-  b.X = mid; b.ldx = n_feats; b.Cin = n_feats; b.Cp = srad_cp(n_feats); b.ntaps = 9;
+  b.X = mid; b.ldx = Fp; b.Cin = Fp; b.Cp = srad_cp(Fp); b.ntaps = 9;
   b.Hi = H2; b.Wi = W2; b.Ho = H2; b.Wo = W2; b.stride = 1; b.M = (int)T2;
   b.ln_eps = 1e-5f; b.Wp = p1; b.N = C; b.alpha = 1.f;
   b.Y = outn; b.ldy = SRAD_IMG_CPAD;

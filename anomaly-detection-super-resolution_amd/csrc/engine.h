@@ -17,7 +17,8 @@ struct ParamEntry {
   int64_t numel;     // elements of the fp32 source tensor
   size_t off;        // byte offset in the arena
   int packed;        // 1: GEMM weight packed by srad_launch_pack_weight, 0: raw fp32 copy
-  int n, cin, ntaps; // packed geometry
+  int n, cin, ntaps; // packed geometry (real sizes of the source tensor)
+  int n_pad = 0, grp_real = 0, grp_pad = 0;   // optional padding (srad_launch_pack_weight_padded)
 };
 
 struct ConvW {       // one Linear / conv layer
@@ -51,6 +52,27 @@ struct ParamTable {
     if (bias) c.b = add_raw(prefix + ".bias", n);
     return c;
   }
+  // Layer whose output rows are zero-padded to n_pad and whose input channels are regrouped from groups of
+  // grp_real to grp_pad channels (0: keep).  The returned ConvW carries the PADDED sizes the GEMM runs with;
+  // the bias slot is n_pad long: set() zeroes it and writes the first n entries.
+  ConvW add_layer_padded(const std::string& prefix, int n, int cin, int ntaps, bool bias, int n_pad, int grp_real, int grp_pad) {
+    const int cin_pad = grp_pad > 0 ? (cin / grp_real) * grp_pad : cin;
+    ConvW c;
+    c.n = n_pad; c.cin = cin_pad; c.ntaps = ntaps;
+    ParamEntry e{prefix + ".weight", (int64_t)n * cin * ntaps, bytes, 1, n, cin, ntaps};
+    e.n_pad = n_pad; e.grp_real = grp_real; e.grp_pad = grp_pad;
+    bytes += srad_align_up(srad_packed_bytes(prec, n_pad, cin_pad, ntaps), 256);
+    entries.push_back(e);
+    c.w = (int)entries.size() - 1;
+    if (bias) {
+      ParamEntry b{prefix + ".bias", n, bytes, 0, 0, 0, 0};
+      b.n_pad = n_pad;
+      bytes += srad_align_up((size_t)n_pad * 4, 256);
+      entries.push_back(b);
+      c.b = (int)entries.size() - 1;
+    }
+    return c;
+  }
   int find(const char* name) const {
     for (size_t i = 0; i < entries.size(); ++i)
       if (entries[i].name == name) return (int)i;
@@ -67,7 +89,9 @@ struct ParamTable {
     if (numel != e.numel)
       return srad_set_error(SRAD_ERR_ARG, "set_param(%s): got %lld elements, expected %lld", name, (long long)numel,
                             (long long)e.numel);
-    if (e.packed) return srad_launch_pack_weight(prec, src, arena + e.off, e.n, e.cin, e.ntaps, s);
+    if (e.packed)
+      return srad_launch_pack_weight_padded(prec, src, arena + e.off, e.n, e.cin, e.ntaps, e.n_pad > 0 ? e.n_pad : e.n, e.grp_real, e.grp_pad, s);
+    if (e.n_pad > numel) SRAD_CHECK_HIP(hipMemsetAsync(arena + e.off, 0, (size_t)e.n_pad * 4, s));
     SRAD_CHECK_HIP(hipMemcpyAsync(arena + e.off, src, (size_t)numel * 4, hipMemcpyDeviceToDevice, s));
     return SRAD_OK;
   }

@@ -397,18 +397,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   }
 }
 
-// ---- weight packer: PyTorch [N][Cin][taps] fp32 -> [Np][taps][Cp] compute type, zero padded ----
+// ---- weight packer: PyTorch [N][Cin][taps] fp32 -> [Np][taps][Cp] compute type, zero padded.
+// Optional channel-group padding: the destination channels are groups of grp_pad of which the first
+// grp_real are real (dst channel c <- src channel (c / grp_pad) * grp_real + c % grp_pad), and rows
+// n >= N are zero - how DRN's 10-channel level is widened to 12 for the float4 kernels. ----
 template <int PREC>
 __global__ void pack_weight_kernel(const float* __restrict__ src, void* __restrict__ dst, int N, int Cin,
-                                   int ntaps, int Np, int Cp) {
+                                   int ntaps, int Np, int Cp, int grp_real, int grp_pad) {
   using T = typename PrecT<PREC>::type;
   const size_t total = (size_t)Np * ntaps * Cp;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % Cp);
     const int tap = (int)((i / Cp) % ntaps);
     const int n = (int)(i / ((size_t)Cp * ntaps));
+    int sc = c;
+    if (grp_pad > 0) {
+      const int blk = c / grp_pad, o = c - blk * grp_pad;
+      sc = o < grp_real ? blk * grp_real + o : -1;
+    }
     float v = 0.f;
-    if (n < N && c < Cin) v = src[((size_t)n * Cin + c) * ntaps + tap];
+    if (n < N && sc >= 0 && sc < Cin) v = src[((size_t)n * Cin + sc) * ntaps + tap];
     reinterpret_cast<T*>(dst)[i] = (T)v;
   }
 }
@@ -494,15 +502,23 @@ int srad_launch_gemm(int prec, const GemmParams& p, hipStream_t stream) {
   return SRAD_OK;
 }
 
-int srad_launch_pack_weight(int prec, const float* src, void* dst, int n, int cin, int ntaps, hipStream_t stream) {
-  const int Np = srad_np(n), Cp = srad_cp(cin);
+int srad_launch_pack_weight_padded(int prec, const float* src, void* dst, int n, int cin, int ntaps, int n_pad,
+                                   int grp_real, int grp_pad, hipStream_t stream) {
+  const int cin_pad = grp_pad > 0 ? (cin / grp_real) * grp_pad : cin;
+  SRAD_REQUIRE(n_pad >= n && (grp_pad == 0 || (grp_real > 0 && grp_pad >= grp_real && cin % grp_real == 0)),
+               "pack_weight: bad padding n=%d->%d cin=%d groups %d->%d", n, n_pad, cin, grp_real, grp_pad);
+  const int Np = srad_np(n_pad), Cp = srad_cp(cin_pad);
   const size_t total = (size_t)Np * ntaps * Cp;
   const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
   SradProfScope prof(stream, SRAD_K_PACK, 0.0, 4.0 * n * cin * ntaps + (prec == SRAD_PREC_BF16 ? 2.0 : 4.0) * total);
   if (prec == SRAD_PREC_BF16)
-    hipLaunchKernelGGL((pack_weight_kernel<SRAD_PREC_BF16>), dim3(blocks), dim3(256), 0, stream, src, dst, n, cin, ntaps, Np, Cp);
+    hipLaunchKernelGGL((pack_weight_kernel<SRAD_PREC_BF16>), dim3(blocks), dim3(256), 0, stream, src, dst, n, cin, ntaps, Np, Cp, grp_real, grp_pad);
   else
-    hipLaunchKernelGGL((pack_weight_kernel<SRAD_PREC_F32>), dim3(blocks), dim3(256), 0, stream, src, dst, n, cin, ntaps, Np, Cp);
+    hipLaunchKernelGGL((pack_weight_kernel<SRAD_PREC_F32>), dim3(blocks), dim3(256), 0, stream, src, dst, n, cin, ntaps, Np, Cp, grp_real, grp_pad);
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
+}
+
+int srad_launch_pack_weight(int prec, const float* src, void* dst, int n, int cin, int ntaps, hipStream_t stream) {
+  return srad_launch_pack_weight_padded(prec, src, dst, n, cin, ntaps, n, 0, 0, stream);
 }

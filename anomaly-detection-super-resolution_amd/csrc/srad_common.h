@@ -83,6 +83,10 @@ static inline size_t srad_packed_bytes(int prec, int n, int cin, int ntaps) {
 // src: PyTorch layout [N][Cin][kh][kw] (kh*kw = ntaps) or [N][Cin] for Linear
 int srad_launch_pack_weight(int prec, const float* src, void* dst, int n, int cin, int ntaps,
                             hipStream_t stream);
+// same with zero rows up to n_pad and input channels regrouped from groups of grp_real to grp_pad (0: none);
+// the packed geometry is that of (n_pad, (cin / grp_real) * grp_pad)
+int srad_launch_pack_weight_padded(int prec, const float* src, void* dst, int n, int cin, int ntaps, int n_pad,
+                                   int grp_real, int grp_pad, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------
 // Window attention (DRCT): qkv [T][3d] -> out [T][d], tokens in raster order per image.

@@ -23,7 +23,7 @@ def build(cfg, sd, precision, use_graph=False):
     return m
 
 
-@pytest.mark.parametrize("name", [c for c in DRN_CASES if "x8" not in c])
+@pytest.mark.parametrize("name", DRN_CASES)   # incl. the x8 preset: 10 features, stored as 12 at level 0
 @pytest.mark.parametrize("graph", [False, True])
 def test_drn_fp32_matches_reference_golden(sr_golden, name, graph):
     cfg, sd, dual, x, ys, dual_y = drn_case(sr_golden, name)
@@ -57,13 +57,19 @@ def test_drn_bf16_close_to_reference(sr_golden, name):
     assert psnr > 35.0
 
 
-def test_drn_x8_preset_is_rejected_clearly(sr_golden):
+def test_drn_x8_preset_bf16_and_odd_feats_rejected(sr_golden):
+    """x8 preset (n_feats=10 -> level 0 zero-padded to 12) in bf16; an odd n_feats is refused with a message."""
+    cfg, sd, dual, x, ys, _ = drn_case(sr_golden, "drn_x8_gray")
+    with torch.no_grad():
+        out = build(cfg, sd, "bf16")(torch.from_numpy(x).cuda())[-1].cpu().numpy()
+    psnr = 10 * np.log10(255.0 ** 2 / np.mean((out - ys[-1]).astype(np.float64) ** 2))
+    assert psnr > 35.0
     from srad_amd import spec as S
-    cfg = S.DRNConfig.for_scale(8, 1)
     from srad_amd.nets import DRN
-    m = DRN(Opt(cfg, "fp32")).cuda().eval()
-    with pytest.raises(RuntimeError, match="multiple of 4"):
-        m(torch.zeros(1, 1, 4, 4, device="cuda"))
+    import dataclasses
+    bad = dataclasses.replace(S.DRNConfig.for_scale(4, 1), n_feats=7)
+    with pytest.raises(RuntimeError, match="n_feats must be even"):
+        DRN(Opt(bad, "fp32")).cuda().eval()(torch.zeros(1, 1, 4, 4, device="cuda"))
 
 
 def test_drn_oracle_c1_shape():
