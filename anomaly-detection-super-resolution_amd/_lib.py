@@ -48,6 +48,20 @@ _SIG = {
     "srad_drct_workspace_bytes": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "srad_drct_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
     "srad_drct_flops": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    # DRCT training
+    "srad_drct_train_param_floats": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "srad_drct_train_param_offset": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
+    "srad_drct_train_arena_bytes": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
+    "srad_drct_train_bind": (C.c_int, [_P, _P, C.c_size_t]),
+    "srad_drct_sync_params": (C.c_int, [_P, _P, _P]),
+    "srad_drct_train_workspace_bytes": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "srad_drct_forward_train": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_size_t, _P]),
+    "srad_drct_num_buckets": (C.c_int, [_P]),
+    "srad_drct_bucket_range": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "srad_drct_backward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_size_t, _P, _P, _P]),
+    "srad_l1_grad": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, _P]),
+    "srad_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                 C.c_int, C.c_float, _P]),
     # DRN
     "srad_drn_create": (C.c_int, [C.POINTER(DrnConfig), C.POINTER(_P)]),
     "srad_drn_destroy": (None, [_P]),
@@ -93,7 +107,17 @@ _SIG = {
     "srad_op_window_attn": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, _P]),
     "srad_op_layernorm": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    # backward operators
+    "srad_op_wgrad": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_int, _P, C.c_float, _P, _P, _P]),
+    "srad_op_dgrad": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P,
+                                C.c_int, C.c_int, C.c_float, C.c_float, _P, _P, C.c_int, _P, C.c_size_t, _P]),
+    "srad_op_layernorm_bwd": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P]),
+    "srad_op_window_attn_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, _P]),
 }
+
+BUCKET_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
 
 
 def exported_symbols():

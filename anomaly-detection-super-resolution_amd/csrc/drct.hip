@@ -7,35 +7,12 @@
 // [T][embed+4*gc]: swin_k reads channels [0, d_k) and adjust_k writes channels [d_k, d_k+gc),
 // which is exactly torch.cat((x, x1, ..), -1) without any copy.  Two dense buffers ping-pong
 // between RDGs (adjust5 writes 0.2*x5 + x into the next one).
-#include "engine.h"
 #include "../../include/srad.h"
 #include <math.h>
 #include <stdlib.h>
 #include <new>
 
-namespace {
-
-struct SwinW {
-  int d, heads, hidden, shift;
-  int n1g, n1b, n2g, n2b, table;
-  ConvW qkv, proj, fc1, fc2, adjust;
-};
-
-}  // namespace
-
-static inline int hdp_of(int d, int heads) { return srad_round_up(d / heads, 4); }
-
-struct srad_drct {
-  srad_drct_config cfg;
-  ParamTable pt;
-  ConvW conv_first, conv_after_body, conv_before_up, conv_last;
-  std::vector<ConvW> up;
-  int pe_g, pe_b, norm_g, norm_b;
-  std::vector<SwinW> blocks;      // n_rdg * 5
-  int dmax, hmax, qkvmax;         // widest block dim / hidden / head-padded qkv row
-  bool fuse_mlp = true;           // bf16: second half of each Swin block as one launch (kernels_fused.hip)
-  GraphCache gc;
-};
+#include "drct_engine.h"
 
 namespace {
 

@@ -1,0 +1,587 @@
+// drct_train.hip - DRCT training step on gfx950: forward that keeps what the backward needs, the
+// backward itself, and the parameter plumbing around them.  Stands in for loss.backward() /
+// optimizer.step() of reference src/trainer.py:186-205 on the model of src/drct.py (DropPath 107-133,
+// SwinTransformerBlock.forward 472-512, RDG.forward 388-396, DRCT.forward 886-898).
+//
+// Memory plan (288 GB of HBM: nothing is recomputed except LayerNorm statistics and the softmax):
+//   * parameters live in ONE flat fp32 buffer owned by the caller (PyTorch parameters are views of it),
+//     gradients in a second flat buffer with the same offsets; srad_drct_sync_params() refreshes the
+//     packed forward weights AND their transposed twins (data-gradient operand) in one launch.
+//   * every RDG keeps its dense [T][embed + 4 gc] buffer; every Swin block keeps LN1(x), q|k|v, the
+//     attention output, x + attn, LN2(.), fc1 pre-activation, GELU output and the block output.
+//     ~2.8 k floats per token per block -> 5.5 GB for DRCT-L at 8 x 32 x 32 tokens.
+//   * weight gradients accumulate (atomicAdd) into the flat gradient buffer: zero it per step.
+#include <math.h>
+#include <stdlib.h>
+#include <type_traits>
+
+#include "drct_engine.h"
+
+struct SyncDesc {
+  long long src_off;    // floats into the flat parameter buffer
+  long long dst_off;    // bytes into the forward arena
+  long long tdst_off;   // bytes into the training arena (-1: no transposed pack)
+  int packed, n, cin, ntaps, Np, Cp, tRp, tKp;
+  long long numel;
+  unsigned blk0, nblk;
+};
+
+namespace {
+
+constexpr int SYNC_EPB = 2048;   // elements per block of the sync kernel
+
+template <int PREC>
+__global__ __launch_bounds__(256) void sync_params_kernel(const SyncDesc* __restrict__ descs, int ndesc,
+                                                          const float* __restrict__ flat, char* __restrict__ arena,
+                                                          char* __restrict__ tarena) {
+  using T = typename std::conditional<PREC == SRAD_PREC_BF16, __bf16, float>::type;
+  // binary search: last descriptor with blk0 <= blockIdx.x
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].blk0 <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const SyncDesc d = descs[lo];
+  const long long base = (long long)(blockIdx.x - d.blk0) * SYNC_EPB;
+  const float* src = flat + d.src_off;
+  if (!d.packed) {
+    float* dst = reinterpret_cast<float*>(arena + d.dst_off);
+    for (long long i = base + threadIdx.x; i < base + SYNC_EPB && i < d.numel; i += 256) dst[i] = src[i];
+    return;
+  }
+  const long long ftotal = (long long)d.Np * d.ntaps * d.Cp;
+  T* dst = reinterpret_cast<T*>(arena + d.dst_off);
+  for (long long i = base + threadIdx.x; i < base + SYNC_EPB && i < ftotal; i += 256) {
+    const int c = (int)(i % d.Cp);
+    const int tap = (int)((i / d.Cp) % d.ntaps);
+    const int n = (int)(i / ((long long)d.Cp * d.ntaps));
+    float v = 0.f;
+    if (n < d.n && c < d.cin) v = src[((long long)n * d.cin + c) * d.ntaps + tap];
+    dst[i] = (T)v;
+  }
+  if (d.tdst_off >= 0) {
+    const long long ttotal = (long long)d.tRp * d.ntaps * d.tKp;
+    T* tdst = reinterpret_cast<T*>(tarena + d.tdst_off);
+    for (long long i = base + threadIdx.x; i < base + SYNC_EPB && i < ttotal; i += 256) {
+      const int n = (int)(i % d.tKp);
+      const int tap = (int)((i / d.tKp) % d.ntaps);
+      const int c = (int)(i / ((long long)d.tKp * d.ntaps));
+      float v = 0.f;
+      if (n < d.n && c < d.cin) v = src[((long long)n * d.cin + c) * d.ntaps + (d.ntaps - 1 - tap)];
+      tdst[i] = (T)v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ workspace
+struct BlockSave { float *xn1, *qkv, *attn, *x1, *xn2, *hpre, *hact, *x2; };
+
+struct TrainWs {
+  float *xin, *feat0;
+  std::vector<float*> dense;          // n_rdg + 1 buffers [T][D]
+  std::vector<BlockSave> blk;
+  float *body, *c1, *c2, *outn;
+  std::vector<float*> upb;
+  // backward temporaries
+  float *dimg, *dus, *dc2, *dc1, *dbody, *g0, *g1, *dx2, *dxn, *dx1, *dO, *dA, *dh, *dqkv, *dfeat, *dxin;
+  std::vector<float*> dup;            // gradient of upb[j]
+  size_t bytes;
+};
+
+TrainWs plan_train_ws(const srad_drct* h, int B, int H, int W, void* base, size_t cap) {
+  const srad_drct_config& c = h->cfg;
+  const size_t T = (size_t)B * H * W;
+  const int E = c.embed_dim, D = E + 4 * c.gc, F = c.num_feat;
+  Bump bp(base, cap);
+  TrainWs w;
+  w.xin = bp.take(T * SRAD_IMG_CPAD);
+  w.feat0 = bp.take(T * E);
+  for (int i = 0; i <= c.n_rdg; ++i) w.dense.push_back(bp.take(T * D));
+  for (const SwinW& sw : h->blocks) {
+    BlockSave s;
+    const int d = sw.d, q = 3 * sw.heads * hdp_of(d, sw.heads);
+    s.xn1 = bp.take(T * d); s.qkv = bp.take(T * q); s.attn = bp.take(T * d); s.x1 = bp.take(T * d);
+    s.xn2 = bp.take(T * d); s.hpre = bp.take(T * sw.hidden); s.hact = bp.take(T * sw.hidden); s.x2 = bp.take(T * d);
+    w.blk.push_back(s);
+  }
+  w.body = bp.take(T * E); w.c1 = bp.take(T * E); w.c2 = bp.take(T * F);
+  size_t t = T;
+  for (size_t j = 0; j < h->up.size(); ++j) { t *= 4; w.upb.push_back(bp.take(t * F)); }
+  const size_t Tout = t;
+  w.outn = bp.take(Tout * SRAD_IMG_CPAD);
+  w.dimg = bp.take(Tout * SRAD_IMG_CPAD);
+  t = T;
+  for (size_t j = 0; j < h->up.size(); ++j) { t *= 4; w.dup.push_back(bp.take(t * F)); }
+  w.dus = bp.take((h->up.empty() ? T : Tout / 4) * 4 * F);
+  w.dc2 = bp.take(T * F); w.dc1 = bp.take(T * E); w.dbody = bp.take(T * E);
+  w.g0 = bp.take(T * D); w.g1 = bp.take(T * D);
+  w.dx2 = bp.take(T * h->dmax); w.dxn = bp.take(T * h->dmax); w.dx1 = bp.take(T * h->dmax); w.dO = bp.take(T * h->dmax);
+  w.dA = bp.take(T * E); w.dh = bp.take(T * h->hmax); w.dqkv = bp.take(T * 3 * h->dmax);
+  w.dfeat = bp.take(T * E); w.dxin = bp.take(T * SRAD_IMG_CPAD);
+  w.bytes = bp.used;
+  return w;
+}
+
+GemmParams fwd_gemm(const srad_drct* h, const ConvW& c, const float* X, int ldx, int M, float* Y, int ldy) {
+  GemmParams p{};
+  p.X = X; p.ldx = ldx; p.M = M; p.Cin = c.cin; p.Cp = srad_cp(c.cin); p.ntaps = c.ntaps;
+  p.stride = 1; p.ln_eps = 1e-5f;
+  p.Wp = h->pt.ptr(c.w); p.N = c.n; p.bias = h->pt.fptr(c.b);
+  p.alpha = 1.f; p.Y = Y; p.ldy = ldy;
+  return p;
+}
+// dX = dY W : the forward GEMM on the transposed pack (rows = input channels, K = output channels)
+GemmParams dgrad_gemm(const srad_drct* h, const ConvW& c, const float* dY, int ldy, int M, float* dX, int ldx) {
+  GemmParams p{};
+  const int npad = srad_round_up(c.n, 4), cpad = srad_round_up(c.cin, 4);
+  p.X = dY; p.ldx = ldy; p.M = M; p.Cin = npad; p.Cp = srad_cp(npad); p.ntaps = c.ntaps;
+  p.stride = 1; p.ln_eps = 1e-5f;
+  p.Wp = h->tarena + h->t_off[c.w]; p.N = cpad; p.bias = nullptr;
+  p.alpha = 1.f; p.Y = dX; p.ldy = ldx;
+  return p;
+}
+WgradParams wgrad_of(const srad_drct* h, const ConvW& c, float* flat_grad, const float* dY, int ldy, int ycol0,
+                     const float* X, int ldx, int M) {
+  WgradParams p{};
+  p.dY = dY; p.ldy = ldy; p.ycol0 = ycol0; p.X = X; p.ldx = ldx; p.M = M;
+  p.N = srad_round_up(c.n, 4); p.Cin = srad_round_up(c.cin, 4); p.ntaps = c.ntaps;
+  p.n_real = c.n; p.cin_real = c.cin; p.stride = 1; p.alpha = 1.f;
+  p.dW = flat_grad + h->flat_off[c.w];
+  p.db = c.b >= 0 ? flat_grad + h->flat_off[c.b] : nullptr;
+  return p;
+}
+void geom(GemmParams& p, int H, int W) { p.Hi = p.Ho = H; p.Wi = p.Wo = W; }
+void geom(WgradParams& p, int H, int W) { p.Hi = p.Ho = H; p.Wi = p.Wo = W; }
+
+int train_check(const srad_drct* h, int B, int H, int W) {
+  SRAD_REQUIRE(h->train_ready, "drct training: call srad_drct_train_bind() and srad_drct_sync_params() first");
+  SRAD_REQUIRE(B > 0 && H > 0 && W > 0, "drct training: empty input");
+  SRAD_REQUIRE(h->cfg.window_size == 8, "drct training: window size 8 only (got %d)", h->cfg.window_size);
+  SRAD_REQUIRE(H % 8 == 0 && W % 8 == 0, "drct training: input %dx%d is not a multiple of the window size 8", H, W);
+  SRAD_REQUIRE((double)B * H * W * h->cfg.upscale * h->cfg.upscale * h->cfg.num_feat * 4.0 < 3.9e9 &&
+               (double)B * H * W * 3 * h->dmax * 4.0 < 3.9e9, "drct training: batch too large for 32-bit offsets");
+  return SRAD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int srad_drct_train_param_floats(srad_drct_t* h, int64_t* total) {
+  SRAD_REQUIRE(h && total, "train_param_floats: null argument");
+  if (h->flat_off.empty()) {
+    int64_t off = 0;
+    for (const ParamEntry& e : h->pt.entries) {
+      h->flat_off.push_back(off);
+      off += (e.numel + 63) / 64 * 64;
+    }
+    h->flat_total = off;
+  }
+  *total = h->flat_total;
+  return SRAD_OK;
+}
+
+int srad_drct_train_param_offset(srad_drct_t* h, int idx, int64_t* off_floats) {
+  int64_t tot = 0;
+  SRAD_TRY(srad_drct_train_param_floats(h, &tot));
+  SRAD_REQUIRE(off_floats && idx >= 0 && idx < (int)h->pt.entries.size(), "train_param_offset: index %d out of range", idx);
+  *off_floats = h->flat_off[idx];
+  return SRAD_OK;
+}
+
+int srad_drct_train_arena_bytes(srad_drct_t* h, size_t* bytes) {
+  SRAD_REQUIRE(h && bytes, "train_arena_bytes: null argument");
+  int64_t tot = 0;
+  SRAD_TRY(srad_drct_train_param_floats(h, &tot));
+  if (h->t_off.empty()) {
+    size_t off = 0;
+    for (const ParamEntry& e : h->pt.entries) {
+      h->t_off.push_back(off);
+      if (e.packed) off += srad_align_up(srad_packed_bytes(h->pt.prec, srad_round_up(e.cin, 4), srad_round_up(e.n, 4), e.ntaps), 256);
+    }
+    h->t_desc_off = off;
+    off += srad_align_up(h->pt.entries.size() * sizeof(SyncDesc), 256);
+    h->t_bytes = off;
+  }
+  *bytes = h->t_bytes;
+  return SRAD_OK;
+}
+
+// Binds the caller-owned training arena (transposed weight packs + the descriptor table of the sync kernel).
+// Synchronous (one small host-to-device copy); call once after srad_drct_bind_arena.
+int srad_drct_train_bind(srad_drct_t* h, void* train_arena, size_t bytes) {
+  SRAD_REQUIRE(h && train_arena, "train_bind: null argument");
+  size_t need = 0;
+  SRAD_TRY(srad_drct_train_arena_bytes(h, &need));
+  SRAD_REQUIRE(bytes >= need, "train_bind: %zu bytes given, %zu needed", bytes, need);
+  SRAD_REQUIRE(((uintptr_t)train_arena & 255) == 0, "train_bind: arena must be 256-byte aligned");
+  if (!h->pt.arena) return srad_set_error(SRAD_ERR_STATE, "train_bind: bind the forward arena first");
+  std::vector<SyncDesc> descs;
+  unsigned blk = 0;
+  for (size_t i = 0; i < h->pt.entries.size(); ++i) {
+    const ParamEntry& e = h->pt.entries[i];
+    SyncDesc d{};
+    d.src_off = h->flat_off[i]; d.dst_off = (long long)e.off; d.tdst_off = -1;
+    d.packed = e.packed; d.numel = e.numel;
+    long long work = e.numel;
+    if (e.packed) {
+      SRAD_REQUIRE(e.grp_pad == 0 && (e.n_pad == 0 || e.n_pad == e.n), "train_bind: padded layers are not trainable");
+      d.n = e.n; d.cin = e.cin; d.ntaps = e.ntaps; d.Np = srad_np(e.n); d.Cp = srad_cp(e.cin);
+      d.tRp = srad_np(srad_round_up(e.cin, 4)); d.tKp = srad_cp(srad_round_up(e.n, 4));
+      d.tdst_off = (long long)h->t_off[i];
+      const long long f = (long long)d.Np * d.ntaps * d.Cp, t = (long long)d.tRp * d.ntaps * d.tKp;
+      work = f > t ? f : t;
+    }
+    d.blk0 = blk;
+    d.nblk = (unsigned)((work + SYNC_EPB - 1) / SYNC_EPB);
+    if (d.nblk == 0) d.nblk = 1;
+    blk += d.nblk;
+    descs.push_back(d);
+  }
+  h->n_sync_blocks = (int)blk;
+  h->tarena = reinterpret_cast<char*>(train_arena);
+  SRAD_CHECK_HIP(hipMemcpy(h->tarena + h->t_desc_off, descs.data(), descs.size() * sizeof(SyncDesc), hipMemcpyHostToDevice));
+  h->train_ready = false;
+  return SRAD_OK;
+}
+
+// Refreshes every packed weight (forward and transposed) and raw parameter from the flat fp32 master buffer:
+// one launch, to be called after each optimizer step (and once after loading a checkpoint).
+int srad_drct_sync_params(srad_drct_t* h, const float* flat_params, void* stream) {
+  SRAD_REQUIRE(h && flat_params, "sync_params: null argument");
+  if (!h->tarena) return srad_set_error(SRAD_ERR_STATE, "sync_params: no training arena bound");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const SyncDesc* descs = reinterpret_cast<const SyncDesc*>(h->tarena + h->t_desc_off);
+  SradProfScope prof(s, SRAD_K_PACK, 0.0, 4.0 * h->flat_total + 2.0 * (h->pt.bytes + h->t_bytes));
+  if (h->pt.prec == SRAD_PREC_BF16)
+    hipLaunchKernelGGL((sync_params_kernel<SRAD_PREC_BF16>), dim3(h->n_sync_blocks), dim3(256), 0, s, descs,
+                       (int)h->pt.entries.size(), flat_params, h->pt.arena, h->tarena);
+  else
+    hipLaunchKernelGGL((sync_params_kernel<SRAD_PREC_F32>), dim3(h->n_sync_blocks), dim3(256), 0, s, descs,
+                       (int)h->pt.entries.size(), flat_params, h->pt.arena, h->tarena);
+  SRAD_CHECK_HIP(hipGetLastError());
+  h->train_ready = true;
+  h->gc.reset();
+  return SRAD_OK;
+}
+
+int srad_drct_train_workspace_bytes(const srad_drct_t* h, int B, int H, int W, size_t* bytes) {
+  SRAD_REQUIRE(h && bytes && B > 0 && H > 0 && W > 0, "train_workspace_bytes: bad argument");
+  *bytes = plan_train_ws(h, B, H, W, nullptr, 0).bytes;
+  return SRAD_OK;
+}
+
+// Gradient buckets in the order the backward completes them: 0 = everything after the RDGs (norm ...
+// conv_last), 1 .. n_rdg = layers.(n_rdg-1) ... layers.0, n_rdg + 1 = conv_first + patch_embed.norm.
+int srad_drct_num_buckets(const srad_drct_t* h) { return h ? h->cfg.n_rdg + 2 : 0; }
+
+int srad_drct_bucket_range(srad_drct_t* h, int bucket, int64_t* off_floats, int64_t* n_floats) {
+  SRAD_REQUIRE(h && off_floats && n_floats, "bucket_range: null argument");
+  int64_t tot = 0;
+  SRAD_TRY(srad_drct_train_param_floats(h, &tot));
+  const int R = h->cfg.n_rdg;
+  SRAD_REQUIRE(bucket >= 0 && bucket < R + 2, "bucket_range: bucket %d out of range", bucket);
+  auto start_of_rdg = [&](int i) { return i < R ? h->flat_off[h->blocks[i * 5].n1g] : h->flat_off[h->norm_g]; };
+  int64_t a, b;
+  if (bucket == 0) { a = h->flat_off[h->norm_g]; b = tot; }
+  else if (bucket <= R) { const int i = R - bucket; a = start_of_rdg(i); b = start_of_rdg(i + 1); }
+  else { a = 0; b = start_of_rdg(0); }
+  *off_floats = a; *n_floats = b - a;
+  return SRAD_OK;
+}
+
+// Training-mode DRCT.forward: as srad_drct_forward, with DropPath (src/drct.py:107-133) applied through
+// `keep_scale` ([2 * n_blocks][B] floats: 0 or 1/keep_prob per sample, row 2j for the attention branch of
+// block j and 2j+1 for its MLP branch; null = no DropPath) and every tensor the backward needs left in
+// `workspace`, which the caller must hand unchanged to srad_drct_backward.
+int srad_drct_forward_train(srad_drct_t* h, const float* x, int B, int H, int W, float* y, const float* keep_scale,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  SRAD_REQUIRE(h && x && y && workspace, "drct_forward_train: null argument");
+  SRAD_TRY(train_check(h, B, H, W));
+  SRAD_REQUIRE(((uintptr_t)workspace & 255) == 0, "drct_forward_train: workspace must be 256-byte aligned");
+  const TrainWs w = plan_train_ws(h, B, H, W, workspace, workspace_bytes);
+  SRAD_REQUIRE(w.bytes <= workspace_bytes, "drct_forward_train: workspace %zu bytes, %zu needed", workspace_bytes, w.bytes);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const srad_drct_config& c = h->cfg;
+  const int prec = c.precision;
+  const int T = B * H * W, HW = H * W;
+  const int E = c.embed_dim, D = E + 4 * c.gc, F = c.num_feat;
+  const float mean3[3] = {c.in_chans == 3 ? 0.4488f : 0.f, c.in_chans == 3 ? 0.4371f : 0.f, c.in_chans == 3 ? 0.4040f : 0.f};
+
+  SRAD_TRY(srad_launch_nchw_to_nhwc(x, w.xin, B, c.in_chans, SRAD_IMG_CPAD, H, W, mean3, c.img_range, s));
+  {
+    GemmParams p = fwd_gemm(h, h->conv_first, w.xin, SRAD_IMG_CPAD, T, w.feat0, E);
+    p.Cin = SRAD_IMG_CPAD; geom(p, H, W);
+    SRAD_TRY(srad_launch_gemm(prec, p, s));
+  }
+  SRAD_TRY(srad_launch_layernorm(w.feat0, E, w.dense[0], D, T, E, h->pt.fptr(h->pe_g), h->pt.fptr(h->pe_b), 1e-5f, s));
+  for (int i = 0; i < c.n_rdg; ++i) {
+    float* cur = w.dense[i];
+    float* nxt = w.dense[i + 1];
+    for (int k = 0; k < 5; ++k) {
+      const int bi = i * 5 + k;
+      const SwinW& sw = h->blocks[bi];
+      const BlockSave& sv = w.blk[bi];
+      const int d = sw.d, hdp = hdp_of(d, sw.heads);
+      const float* ks1 = keep_scale ? keep_scale + (size_t)(2 * bi) * B : nullptr;
+      const float* ks2 = keep_scale ? keep_scale + (size_t)(2 * bi + 1) * B : nullptr;
+      SRAD_TRY(srad_launch_layernorm(cur, D, sv.xn1, d, T, d, h->pt.fptr(sw.n1g), h->pt.fptr(sw.n1b), 1e-5f, s));
+      SRAD_CHECK_HIP(hipMemsetAsync(sv.qkv, 0, (size_t)T * 3 * sw.heads * hdp * sizeof(float), s));   // finite pad columns
+      {
+        GemmParams p = fwd_gemm(h, sw.qkv, sv.xn1, d, T, sv.qkv, 3 * sw.heads * hdp);
+        p.hsplit_hd = d / sw.heads; p.hsplit_hdp = hdp;
+        SRAD_TRY(srad_launch_gemm(prec, p, s));
+      }
+      {
+        AttnParams a{sv.qkv, sv.attn, h->pt.fptr(sw.table), B, H, W, c.window_size, sw.shift, d, sw.heads, hdp};
+        SRAD_TRY(srad_launch_window_attn(prec, a, s));
+      }
+      {  // x1 = shortcut + drop_path(proj(attn))          (drct.py:300, 509)
+        GemmParams p = fwd_gemm(h, sw.proj, sv.attn, d, T, sv.x1, d);
+        p.R = cur; p.ldr = D; p.row_scale = ks1; p.rps = HW;
+        SRAD_TRY(srad_launch_gemm(prec, p, s));
+      }
+      SRAD_TRY(srad_launch_layernorm(sv.x1, d, sv.xn2, d, T, d, h->pt.fptr(sw.n2g), h->pt.fptr(sw.n2b), 1e-5f, s));
+      {  // fc1 + GELU, pre-activation kept            (drct.py:185-186)
+        GemmParams p = fwd_gemm(h, sw.fc1, sv.xn2, d, T, sv.hact, sw.hidden);
+        p.act = SRAD_ACT_GELU; p.Ypre = sv.hpre;
+        SRAD_TRY(srad_launch_gemm(prec, p, s));
+      }
+      {  // x2 = x1 + drop_path(fc2(.))                (drct.py:188, 510)
+        GemmParams p = fwd_gemm(h, sw.fc2, sv.hact, sw.hidden, T, sv.x2, d);
+        p.R = sv.x1; p.ldr = d; p.row_scale = ks2; p.rps = HW;
+        SRAD_TRY(srad_launch_gemm(prec, p, s));
+      }
+      if (k < 4) {                                      // (drct.py:389-392)
+        GemmParams p = fwd_gemm(h, sw.adjust, sv.x2, d, T, cur, D);
+        p.yoff = d; p.act = SRAD_ACT_LRELU; p.slope = 0.2f;
+        SRAD_TRY(srad_launch_gemm(prec, p, s));
+      } else {                                          // (drct.py:393, 396)
+        GemmParams p = fwd_gemm(h, sw.adjust, sv.x2, d, T, nxt, D);
+        p.alpha = 0.2f; p.R = cur; p.ldr = D;
+        SRAD_TRY(srad_launch_gemm(prec, p, s));
+      }
+    }
+  }
+  SRAD_TRY(srad_launch_layernorm(w.dense[c.n_rdg], D, w.body, E, T, E, h->pt.fptr(h->norm_g), h->pt.fptr(h->norm_b), 1e-5f, s));
+  {
+    GemmParams p = fwd_gemm(h, h->conv_after_body, w.body, E, T, w.c1, E);
+    geom(p, H, W); p.R = w.feat0; p.ldr = E;
+    SRAD_TRY(srad_launch_gemm(prec, p, s));
+  }
+  {
+    GemmParams p = fwd_gemm(h, h->conv_before_up, w.c1, E, T, w.c2, F);
+    geom(p, H, W); p.act = SRAD_ACT_LRELU; p.slope = 0.01f;
+    SRAD_TRY(srad_launch_gemm(prec, p, s));
+  }
+  const float* src = w.c2;
+  int hh = H, ww = W;
+  for (size_t j = 0; j < h->up.size(); ++j) {
+    GemmParams p = fwd_gemm(h, h->up[j], src, F, B * hh * ww, w.upb[j], F);
+    geom(p, hh, ww); p.ps = 2;
+    SRAD_TRY(srad_launch_gemm(prec, p, s));
+    src = w.upb[j]; hh *= 2; ww *= 2;
+  }
+  {
+    GemmParams p = fwd_gemm(h, h->conv_last, src, F, B * hh * ww, w.outn, SRAD_IMG_CPAD);
+    geom(p, hh, ww);
+    SRAD_TRY(srad_launch_gemm(prec, p, s));
+  }
+  return srad_launch_nhwc_to_nchw(w.outn, SRAD_IMG_CPAD, y, B, c.in_chans, hh, ww, mean3, 1.0f / c.img_range, s);
+}
+
+// Backward of srad_drct_forward_train.  dy [B,C,H*s,W*s] is dLoss/dy; parameter gradients are ACCUMULATED
+// into flat_grad (same offsets as the flat parameter buffer); dx (optional) receives dLoss/dx.
+// `on_bucket(user, bucket)` (optional) is called on the host right after the last kernel that writes bucket
+// `bucket` (srad_drct_bucket_range) has been enqueued - the hook a data-parallel trainer uses to start that
+// bucket's all-reduce on another stream while the rest of the backward is still running.
+int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, const float* keep_scale, float* dx,
+                       float* flat_grad, void* workspace, size_t workspace_bytes, void* stream,
+                       srad_bucket_fn on_bucket, void* user) {
+  SRAD_REQUIRE(h && dy && flat_grad && workspace, "drct_backward: null argument");
+  SRAD_TRY(train_check(h, B, H, W));
+  const TrainWs w = plan_train_ws(h, B, H, W, workspace, workspace_bytes);
+  SRAD_REQUIRE(w.bytes <= workspace_bytes, "drct_backward: workspace %zu bytes, %zu needed", workspace_bytes, w.bytes);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const srad_drct_config& c = h->cfg;
+  const int prec = c.precision;
+  const int T = B * H * W, HW = H * W;
+  const int E = c.embed_dim, D = E + 4 * c.gc, F = c.num_feat;
+  const float zero3[3] = {0.f, 0.f, 0.f};
+  const int stages = (int)h->up.size();
+  int hh = H << stages, ww = W << stages;
+  float* G = flat_grad;
+
+  // dLoss/d(outn) = dy / img_range, NCHW -> NHWC (pad channels zero)           (drct.py:897)
+  SRAD_TRY(srad_launch_nchw_to_nhwc(dy, w.dimg, B, c.in_chans, SRAD_IMG_CPAD, hh, ww, zero3, 1.0f / c.img_range, s));
+  {  // conv_last                                                                (drct.py:895)
+    const float* src = stages ? w.upb[stages - 1] : w.c2;
+    float* dsrc = stages ? w.dup[stages - 1] : w.dc2;
+    WgradParams g = wgrad_of(h, h->conv_last, G, w.dimg, SRAD_IMG_CPAD, 0, src, F, B * hh * ww);
+    geom(g, hh, ww);
+    SRAD_TRY(srad_launch_wgrad(prec, g, s));
+    GemmParams p = dgrad_gemm(h, h->conv_last, w.dimg, SRAD_IMG_CPAD, B * hh * ww, dsrc, F);
+    geom(p, hh, ww);
+    SRAD_TRY(srad_launch_gemm(prec, p, s));
+  }
+  for (int j = stages - 1; j >= 0; --j) {   // Upsample stage j: conv F -> 4F + PixelShuffle(2)   (drct.py:694-713)
+    hh /= 2; ww /= 2;
+    const float* src = j ? w.upb[j - 1] : w.c2;
+    float* dsrc = j ? w.dup[j - 1] : w.dc2;
+    SRAD_TRY(srad_launch_unshuffle(w.dup[j], w.dus, B, hh, ww, F, s));
+    WgradParams g = wgrad_of(h, h->up[j], G, w.dus, 4 * F, 0, src, F, B * hh * ww);
+    geom(g, hh, ww);
+    SRAD_TRY(srad_launch_wgrad(prec, g, s));
+    GemmParams p = dgrad_gemm(h, h->up[j], w.dus, 4 * F, B * hh * ww, dsrc, F);
+    geom(p, hh, ww);
+    SRAD_TRY(srad_launch_gemm(prec, p, s));
+  }
+  {  // conv_before_upsample + LeakyReLU(0.01)                                   (drct.py:844-845)
+    SRAD_TRY(srad_launch_dact(w.dc2, F, w.c2, F, w.dc2, F, T, F, 0.01f, s));
+    WgradParams g = wgrad_of(h, h->conv_before_up, G, w.dc2, F, 0, w.c1, E, T);
+    geom(g, H, W);
+    SRAD_TRY(srad_launch_wgrad(prec, g, s));
+    GemmParams p = dgrad_gemm(h, h->conv_before_up, w.dc2, F, T, w.dc1, E);
+    geom(p, H, W);
+    SRAD_TRY(srad_launch_gemm(prec, p, s));
+  }
+  {  // conv_after_body(...) + x                                                 (drct.py:893)
+    WgradParams g = wgrad_of(h, h->conv_after_body, G, w.dc1, E, 0, w.body, E, T);
+    geom(g, H, W);
+    SRAD_TRY(srad_launch_wgrad(prec, g, s));
+    GemmParams p = dgrad_gemm(h, h->conv_after_body, w.dc1, E, T, w.dbody, E);
+    geom(p, H, W);
+    SRAD_TRY(srad_launch_gemm(prec, p, s));
+  }
+  float* gn = w.g0;     // gradient of the RDG stack's output lives in gn[:, :E]
+  float* gc = w.g1;
+  {  // norm                                                                      (drct.py:881)
+    LnBwdParams l{};
+    l.dxn = w.dbody; l.ld_dxn = E; l.x = w.dense[c.n_rdg]; l.ldx = D; l.gamma = h->pt.fptr(h->norm_g);
+    l.out = gn; l.ld_out = D; l.dgamma = G + h->flat_off[h->norm_g]; l.dbeta = G + h->flat_off[h->norm_b];
+    l.rows = T; l.C = E; l.eps = 1e-5f;
+    SRAD_TRY(srad_launch_ln_bwd(l, s));
+  }
+  if (on_bucket) on_bucket(user, 0);
+
+  for (int i = c.n_rdg - 1; i >= 0; --i) {
+    const float* cur = w.dense[i];
+    // gc = [ gn[:, :E] | 0 ]: the residual path of out = 0.2 x5 + x               (drct.py:396)
+    SRAD_TRY(srad_launch_copy_cols(gn, D, gc, D, T, E, s));
+    for (int k = 4; k >= 0; --k) {
+      const int bi = i * 5 + k;
+      const SwinW& sw = h->blocks[bi];
+      const BlockSave& sv = w.blk[bi];
+      const int d = sw.d, hdp = hdp_of(d, sw.heads);
+      const float* ks1 = keep_scale ? keep_scale + (size_t)(2 * bi) * B : nullptr;
+      const float* ks2 = keep_scale ? keep_scale + (size_t)(2 * bi + 1) * B : nullptr;
+      // ---- adjust_k: 1x1 conv (+ LeakyReLU 0.2 | * 0.2)                        (drct.py:389-393)
+      const float* dA; int ldA, no; float aalpha = 1.f;
+      if (k < 4) {
+        SRAD_TRY(srad_launch_dact(gc + d, D, cur + d, D, w.dA, c.gc, T, c.gc, 0.2f, s));
+        dA = w.dA; ldA = c.gc; no = c.gc;
+      } else {
+        dA = gn; ldA = D; no = E; aalpha = 0.2f;
+      }
+      {
+        WgradParams g = wgrad_of(h, sw.adjust, G, dA, ldA, 0, sv.x2, d, T);
+        g.alpha = aalpha;
+        SRAD_TRY(srad_launch_wgrad(prec, g, s));
+        GemmParams p = dgrad_gemm(h, sw.adjust, dA, ldA, T, w.dx2, d);
+        p.alpha = aalpha;
+        SRAD_TRY(srad_launch_gemm(prec, p, s));
+        (void)no;
+      }
+      // ---- MLP branch: x2 = x1 + rs2 * fc2(gelu(fc1(LN2(x1))))                 (drct.py:510, 184-190)
+      {
+        WgradParams g = wgrad_of(h, sw.fc2, G, w.dx2, d, 0, sv.hact, sw.hidden, T);
+        g.row_scale = ks2; g.rps = HW;
+        SRAD_TRY(srad_launch_wgrad(prec, g, s));
+        GemmParams p = dgrad_gemm(h, sw.fc2, w.dx2, d, T, w.dh, sw.hidden);
+        p.row_scale = ks2; p.rps = HW; p.R = sv.hpre; p.ldr = sw.hidden; p.rmode = SRAD_RMODE_DGELU;
+        SRAD_TRY(srad_launch_gemm(prec, p, s));
+      }
+      {
+        WgradParams g = wgrad_of(h, sw.fc1, G, w.dh, sw.hidden, 0, sv.xn2, d, T);
+        SRAD_TRY(srad_launch_wgrad(prec, g, s));
+        GemmParams p = dgrad_gemm(h, sw.fc1, w.dh, sw.hidden, T, w.dxn, d);
+        SRAD_TRY(srad_launch_gemm(prec, p, s));
+      }
+      {  // dx1 = dx2 + dLN2(dxn)
+        LnBwdParams l{};
+        l.dxn = w.dxn; l.ld_dxn = d; l.x = sv.x1; l.ldx = d; l.gamma = h->pt.fptr(sw.n2g);
+        l.dres = w.dx2; l.ld_dres = d; l.out = w.dx1; l.ld_out = d;
+        l.dgamma = G + h->flat_off[sw.n2g]; l.dbeta = G + h->flat_off[sw.n2b];
+        l.rows = T; l.C = d; l.eps = 1e-5f;
+        SRAD_TRY(srad_launch_ln_bwd(l, s));
+      }
+      // ---- attention branch: x1 = x + rs1 * proj(attn(LN1(x)))                  (drct.py:477-509)
+      {
+        WgradParams g = wgrad_of(h, sw.proj, G, w.dx1, d, 0, sv.attn, d, T);
+        g.row_scale = ks1; g.rps = HW;
+        SRAD_TRY(srad_launch_wgrad(prec, g, s));
+        GemmParams p = dgrad_gemm(h, sw.proj, w.dx1, d, T, w.dO, d);
+        p.row_scale = ks1; p.rps = HW;
+        SRAD_TRY(srad_launch_gemm(prec, p, s));
+      }
+      {
+        AttnBwdParams a{sv.qkv, w.dO, w.dqkv, h->pt.fptr(sw.table), G + h->flat_off[sw.table], B, H, W, c.window_size,
+                        sw.shift, d, sw.heads, hdp};
+        SRAD_TRY(srad_launch_window_attn_bwd(a, s));
+      }
+      {
+        WgradParams g = wgrad_of(h, sw.qkv, G, w.dqkv, 3 * d, 0, sv.xn1, d, T);
+        SRAD_TRY(srad_launch_wgrad(prec, g, s));
+        GemmParams p = dgrad_gemm(h, sw.qkv, w.dqkv, 3 * d, T, w.dxn, d);
+        SRAD_TRY(srad_launch_gemm(prec, p, s));
+      }
+      {  // gc[:, :d] += dx1 + dLN1(dxn)
+        LnBwdParams l{};
+        l.dxn = w.dxn; l.ld_dxn = d; l.x = cur; l.ldx = D; l.gamma = h->pt.fptr(sw.n1g);
+        l.dres = w.dx1; l.ld_dres = d; l.out = gc; l.ld_out = D; l.accumulate = 1;
+        l.dgamma = G + h->flat_off[sw.n1g]; l.dbeta = G + h->flat_off[sw.n1b];
+        l.rows = T; l.C = d; l.eps = 1e-5f;
+        SRAD_TRY(srad_launch_ln_bwd(l, s));
+      }
+    }
+    float* t = gn; gn = gc; gc = t;
+    if (on_bucket) on_bucket(user, c.n_rdg - i);
+  }
+  {  // patch_embed.norm, joined by the long skip of conv_after_body(...) + x      (drct.py:873, 893)
+    LnBwdParams l{};
+    l.dxn = gn; l.ld_dxn = D; l.x = w.feat0; l.ldx = E; l.gamma = h->pt.fptr(h->pe_g);
+    l.dres = w.dc1; l.ld_dres = E; l.out = w.dfeat; l.ld_out = E;
+    l.dgamma = G + h->flat_off[h->pe_g]; l.dbeta = G + h->flat_off[h->pe_b];
+    l.rows = T; l.C = E; l.eps = 1e-5f;
+    SRAD_TRY(srad_launch_ln_bwd(l, s));
+  }
+  {  // conv_first                                                                 (drct.py:892)
+    WgradParams g = wgrad_of(h, h->conv_first, G, w.dfeat, E, 0, w.xin, SRAD_IMG_CPAD, T);
+    geom(g, H, W);
+    SRAD_TRY(srad_launch_wgrad(prec, g, s));
+    if (dx) {
+      GemmParams p = dgrad_gemm(h, h->conv_first, w.dfeat, E, T, w.dxin, SRAD_IMG_CPAD);
+      geom(p, H, W);
+      SRAD_TRY(srad_launch_gemm(prec, p, s));
+      SRAD_TRY(srad_launch_nhwc_to_nchw(w.dxin, SRAD_IMG_CPAD, dx, B, c.in_chans, H, W, zero3, c.img_range, s));
+    }
+  }
+  if (on_bucket) on_bucket(user, c.n_rdg + 1);
+  return SRAD_OK;
+}
+
+/* sign(a - b) * scale: the gradient seed of nn.L1Loss(reduction='mean') when scale = 1 / numel (src/loss.py:84) */
+int srad_l1_grad(const float* a, const float* b, float* out, int64_t n, float scale, void* stream) {
+  SRAD_REQUIRE(a && b && out && n > 0, "l1_grad: bad argument");
+  return srad_launch_l1_grad(a, b, out, (size_t)n, scale, reinterpret_cast<hipStream_t>(stream));
+}
+
+/* torch.optim.Adam step on flat buffers (src/trainer.py:49-59: lr 1e-4, betas (0.9, 0.999), eps 1e-8, L2 weight decay) */
+int srad_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  SRAD_REQUIRE(params && grads && exp_avg && exp_avg_sq && n > 0, "adam_step: bad argument");
+  return srad_launch_adam(params, grads, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps, weight_decay, step,
+                          grad_scale, reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

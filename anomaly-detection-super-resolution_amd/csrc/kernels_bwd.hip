@@ -1,0 +1,568 @@
+// kernels_bwd.hip - backward kernels of the training step on gfx950 (reference src/trainer.py:152-222:
+// loss.backward() through src/drct.py / src/drn.py; the arithmetic is PyTorch autograd's for Linear,
+// conv2d, LayerNorm, softmax attention, GELU / LeakyReLU and PixelShuffle).
+//
+//   wgrad_kernel            dW += dY^T A(X)      MFMA straight from global memory, no LDS staging
+//   window_attn_bwd_kernel  dq, dk, dv, dtable   recomputes P per (window, head) from the saved q|k|v
+//   ln_bwd_kernel           dx, dgamma, dbeta    one wave per row, statistics recomputed
+//   small elementwise kernels (activation backward, pixel un-shuffle, column copies, L1 seed, Adam)
+//
+// Data gradients (dX = dY W) are not here: they are the forward GEMM of kernels_gemm.hip run on the
+// transposed packed weight (srad_launch_pack_weight_transposed).
+#include "srad_common.h"
+
+namespace {
+
+static inline int grid_for(size_t total) {
+  size_t b = (total + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient.  The contraction runs over the rows m (tokens / pixels), which are the SLOW axis of
+// both operands in memory ([m][n] and [m][c], channel contiguous).  An MFMA lane supplies A[i][k] and
+// B[k][j] for ONE i / j and a few k, and nothing fixes which n a tile row i stands for - so lane
+// (fq, fr) loads the float4 dY[m][n0 + 4 fr .. +3] and uses component e as row fr of n-subtile e
+// (n = n0 + 4 fr + e), likewise X for the c-subtiles.  Sixteen lanes then read 256 contiguous bytes of
+// one row: fully coalesced fragment loads, 2 loads feed 16 MFMAs, and no LDS transpose is needed.
+//   fp32: v_mfma_f32_16x16x4_f32, k = 4 rows per step (row m0 + fq)
+//   bf16: v_mfma_f32_16x16x32_bf16, k = 32 rows per step (rows m0 + 8 fq + t, t = 0..7)
+// One workgroup = 4 waves on one 64 x 64 (n, c) tile of one tap, each wave on its own rows of the
+// workgroup's row range (split-K); waves are summed through LDS, workgroups through atomicAdd.
+// ------------------------------------------------------------------------------------------
+template <int PREC, bool CONV>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const int ksplit) {
+  __shared__ float tile[64 * 65];
+  __shared__ float dbs[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tap = blockIdx.z / ksplit, ks = blockIdx.z - tap * ksplit;
+  for (int i = tid; i < 64 * 65; i += 256) tile[i] = 0.f;
+  if (tid < 64) dbs[tid] = 0.f;
+  __syncthreads();
+
+  constexpr int KR = PREC == SRAD_PREC_BF16 ? 32 : 4;        // rows per wave step
+  constexpr int RL = PREC == SRAD_PREC_BF16 ? 8 : 1;         // rows per lane per step
+  const int rows_per = ((p.M + ksplit - 1) / ksplit + 4 * KR - 1) / (4 * KR) * (4 * KR);
+  const int mb = ks * rows_per;
+  const int me = min(p.M, mb + rows_per);
+
+  const int ncol = n0 + 4 * fr, ccol = c0 + 4 * fr;
+  const bool n_ok = ncol < p.N, c_ok = ccol < p.Cin;
+  const unsigned noff = (unsigned)(min(ncol, p.N - 4) + p.ycol0);
+  const unsigned coff = (unsigned)min(ccol, p.Cin - 4);
+  [[maybe_unused]] const int pad = p.ntaps == 9 ? 1 : 0;
+  [[maybe_unused]] const int ky = p.ntaps == 9 ? tap / 3 : 0, kx = p.ntaps == 9 ? tap - (tap / 3) * 3 : 0;
+  [[maybe_unused]] const int hwo = p.Ho * p.Wo;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int m0 = mb + wave * KR; m0 < me; m0 += 4 * KR) {
+    f32x4 av[RL], bv[RL];
+    bool a_ok[RL], b_ok[RL];
+    float rs[RL];
+    // every load is unconditional on a clamped address; masking happens on the registers afterwards
+#pragma unroll
+    for (int t = 0; t < RL; ++t) {
+      const int m = m0 + RL * fq + t;
+      const int mc = min(m, p.M - 1);
+      a_ok[t] = m < me && n_ok;
+      av[t] = *reinterpret_cast<const f32x4*>(p.dY + (size_t)mc * p.ldy + noff);
+      size_t xr = (size_t)mc;
+      bool in = true;
+      if constexpr (CONV) {
+        const int bb = mc / hwo, rem = mc - bb * hwo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int iy = oy * p.stride - pad + ky, ix = ox * p.stride - pad + kx;
+        in = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        xr = (size_t)((bb * p.Hi + min(max(iy, 0), p.Hi - 1)) * p.Wi + min(max(ix, 0), p.Wi - 1));
+      }
+      b_ok[t] = m < me && c_ok && in;
+      bv[t] = *reinterpret_cast<const f32x4*>(p.X + xr * p.ldx + coff);
+      rs[t] = p.row_scale ? p.row_scale[mc / p.rps] : 1.f;
+    }
+#pragma unroll
+    for (int t = 0; t < RL; ++t) {
+      av[t] = a_ok[t] ? av[t] * rs[t] : zero4;
+      bv[t] = b_ok[t] ? bv[t] : zero4;
+      bsum += av[t];
+    }
+    if constexpr (PREC == SRAD_PREC_BF16) {
+      bf16x8 ah[4], bh[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { ah[e][t] = (__bf16)av[t][e]; bh[e][t] = (__bf16)bv[t][e]; }
+#pragma unroll
+      for (int en = 0; en < 4; ++en)
+#pragma unroll
+        for (int ec = 0; ec < 4; ++ec)
+          acc[en][ec] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[en], bh[ec], acc[en][ec], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int en = 0; en < 4; ++en)
+#pragma unroll
+        for (int ec = 0; ec < 4; ++ec)
+          acc[en][ec] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][en], bv[0][ec], acc[en][ec], 0, 0, 0);
+    }
+  }
+
+  // ---- sum the four waves in LDS: lane (fq, fr) element e of acc[en][ec] is (n = 16 fq + 4 e + en, c = 4 fr + ec) ----
+#pragma unroll
+  for (int en = 0; en < 4; ++en)
+#pragma unroll
+    for (int ec = 0; ec < 4; ++ec)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(&tile[(16 * fq + 4 * e + en) * 65 + 4 * fr + ec], acc[en][ec][e]);
+  const bool do_bias = p.db != nullptr && blockIdx.y == 0 && tap == 0;
+  if (do_bias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(&dbs[4 * fr + e], bsum[e]);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 64 * 64; idx += 256) {
+    const int nl = idx >> 6, cl = idx & 63;
+    const int n = n0 + nl, c = c0 + cl;
+    if (n < p.n_real && c < p.cin_real)
+      atomicAdd(p.dW + ((size_t)n * p.cin_real + c) * p.ntaps + tap, tile[nl * 65 + cl] * p.alpha);
+  }
+  if (do_bias && tid < 64 && n0 + tid < p.n_real) atomicAdd(p.db + n0 + tid, dbs[tid] * p.alpha);
+}
+
+template <int PREC>
+int launch_wgrad(const WgradParams& p, hipStream_t s) {
+  const bool conv = p.ntaps == 9 || p.stride != 1;
+  const int tn = (p.N + 63) / 64, tc = (p.Cin + 63) / 64;
+  const long tiles = (long)tn * tc * p.ntaps;
+  constexpr int KR = PREC == SRAD_PREC_BF16 ? 32 : 4;
+  // enough workgroups to cover the chip a few times, but at least two steps of rows per wave
+  long ksplit = (1536 + tiles - 1) / tiles;
+  const long kmax = (p.M + 8 * KR - 1) / (8 * KR);
+  if (ksplit > kmax) ksplit = kmax;
+  if (ksplit < 1) ksplit = 1;
+  if ((long)p.ntaps * ksplit > 65535) ksplit = 65535 / p.ntaps;
+  dim3 grid(tn, tc, (unsigned)(p.ntaps * ksplit));
+  const double K = (double)p.ntaps * p.cin_real;
+  SradProfScope prof(s, SRAD_K_WGRAD, 2.0 * p.M * p.n_real * K, 4.0 * p.M * (p.N + (double)p.Cin * (conv ? 1.0 : 1.0)) + 4.0 * p.n_real * K);
+  if (conv) hipLaunchKernelGGL((wgrad_kernel<PREC, true>), grid, dim3(256), 0, s, p, (int)ksplit);
+  else hipLaunchKernelGGL((wgrad_kernel<PREC, false>), grid, dim3(256), 0, s, p, (int)ksplit);
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm backward, one wave per row, RPW rows per workgroup.  Mean / rstd are recomputed exactly as
+// the forward kernel does; dgamma / dbeta partials live in registers across the workgroup's rows.
+// ------------------------------------------------------------------------------------------
+constexpr int LNB_RPW = 32;
+constexpr int LNB_J = 5;     // 64 * 5 = 320 channels at most
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdParams p) {
+  __shared__ float red_g[64 * LNB_J], red_b[64 * LNB_J];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 64 * LNB_J; i += 256) { red_g[i] = 0.f; red_b[i] = 0.f; }
+  __syncthreads();
+  float gam[LNB_J], dg[LNB_J], db[LNB_J];
+#pragma unroll
+  for (int j = 0; j < LNB_J; ++j) {
+    const int c = lane + 64 * j;
+    gam[j] = p.gamma[min(c, p.C - 1)];
+    dg[j] = 0.f; db[j] = 0.f;
+  }
+  const float invC = 1.0f / (float)p.C;
+  const int r_end = min(p.rows, (int)(blockIdx.x + 1) * LNB_RPW);
+  for (int row = blockIdx.x * LNB_RPW + wave; row < r_end; row += 4) {
+    const float* xr = p.x + (size_t)row * p.ldx;
+    const float* dr = p.dxn + (size_t)row * p.ld_dxn;
+    float xv[LNB_J], dy[LNB_J], rv[LNB_J], ov[LNB_J];
+#pragma unroll
+    for (int j = 0; j < LNB_J; ++j) {
+      const int c = lane + 64 * j, cc = min(c, p.C - 1);
+      const bool ok = c < p.C;
+      const float a = xr[cc], b = dr[cc];
+      const float r = p.dres ? p.dres[(size_t)row * p.ld_dres + cc] : 0.f;
+      const float o = p.accumulate ? p.out[(size_t)row * p.ld_out + cc] : 0.f;
+      xv[j] = ok ? a : 0.f; dy[j] = ok ? b : 0.f; rv[j] = ok ? r : 0.f; ov[j] = ok ? o : 0.f;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LNB_J; ++j) s += xv[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * invC;
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < LNB_J; ++j) { const float d = (lane + 64 * j) < p.C ? xv[j] - mean : 0.f; v += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const float rstd = rsqrtf(v * invC + p.eps);
+    float xh[LNB_J], gy[LNB_J];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LNB_J; ++j) {
+      const bool ok = (lane + 64 * j) < p.C;
+      xh[j] = ok ? (xv[j] - mean) * rstd : 0.f;
+      gy[j] = dy[j] * gam[j];
+      s1 += gy[j]; s2 += gy[j] * xh[j];
+      dg[j] += dy[j] * xh[j]; db[j] += dy[j];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    s1 *= invC; s2 *= invC;
+    float* orow = p.out + (size_t)row * p.ld_out;
+#pragma unroll
+    for (int j = 0; j < LNB_J; ++j) {
+      const int c = lane + 64 * j;
+      if (c < p.C) orow[c] = rstd * (gy[j] - s1 - xh[j] * s2) + rv[j] + ov[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < LNB_J; ++j) { atomicAdd(&red_g[lane + 64 * j], dg[j]); atomicAdd(&red_b[lane + 64 * j], db[j]); }
+  __syncthreads();
+  for (int c = tid; c < p.C; c += 256) {
+    if (p.dgamma) atomicAdd(p.dgamma + c, red_g[c]);
+    if (p.dbeta) atomicAdd(p.dbeta + c, red_b[c]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Window attention backward for 8x8 windows (N = 64 tokens), one workgroup per (window, head).
+// Pass A walks the head dimension in chunks of 32 columns accumulating S = (q*scale) k^T and
+// dP = dO v^T in MFMA accumulators; the softmax is redone in registers exactly as the forward kernel
+// does (bias table + 0/-100 shift mask), dS = P (dP - rowsum(P dP)); P and dS go to LDS.
+// Pass B walks the chunks again: dq = scale dS k, dk = dS^T (q*scale), dv = P^T dO.
+// All MFMAs are v_mfma_f32_16x16x4_f32 (fp32 in, fp32 out) in both precision modes.
+// ------------------------------------------------------------------------------------------
+constexpr int AB_HC = 32, AB_HS = AB_HC + 4, AB_PS = 64 + 4;
+constexpr size_t AB_LDS = (size_t)(4 * 64 * AB_HS + 2 * 64 * AB_PS + 2 * 256) * sizeof(float) + 2 * 64 * sizeof(int);
+
+__global__ __launch_bounds__(256) void window_attn_bwd_kernel(const AttnBwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Qs = reinterpret_cast<float*>(smem);
+  float* Ks = Qs + 64 * AB_HS;
+  float* Vs = Ks + 64 * AB_HS;
+  float* Gs = Vs + 64 * AB_HS;
+  float* Pm = Gs + 64 * AB_HS;
+  float* Dm = Pm + 64 * AB_PS;
+  float* tbl = Dm + 64 * AB_PS;      // [225] (256 reserved)
+  float* dtb = tbl + 256;
+  int* tok = reinterpret_cast<int*>(dtb + 256);
+  int* inf = tok + 64;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int ws = 8, d = p.d, heads = p.heads, hd = d / heads, hdp = p.hdp;
+  const int ldq = 3 * heads * hdp;
+  const int h = blockIdx.y;
+  const int nWx = p.W / ws, nW = (p.H / ws) * nWx;
+  const int win = blockIdx.x;
+  const int b = win / nW, widx = win - b * nW;
+  const int wy = widx / nWx, wx = widx - wy * nWx;
+  const float scale = rsqrtf((float)hd);
+  const int tw = 2 * ws - 1;
+
+  if (tid < 64) {
+    const int py = tid / ws, px = tid - py * ws;
+    const int r = wy * ws + py, c = wx * ws + px;
+    int orr = r + p.shift; if (orr >= p.H) orr -= p.H;
+    int occ = c + p.shift; if (occ >= p.W) occ -= p.W;
+    tok[tid] = (b * p.H + orr) * p.W + occ;
+    const int rh = r < p.H - ws ? 0 : (r < p.H - p.shift ? 1 : 2);
+    const int rw = c < p.W - ws ? 0 : (c < p.W - p.shift ? 1 : 2);
+    inf[tid] = ((rh * 3 + rw) << 16) | (py << 8) | px;
+  }
+  if (tid < tw * tw) { tbl[tid] = p.table[(size_t)tid * heads + h]; dtb[tid] = 0.f; }
+  __syncthreads();
+
+  // chunk staging: q/k/v as float4 (head-padded rows are 16-byte aligned), dO as scalars
+  auto stage = [&](int ch, bool need_v) {
+    const int col0 = ch * AB_HC;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx >> 3, c = col0 + (idx & 7) * 4;
+      const float* base = p.qkv + (size_t)tok[row] * ldq + h * hdp + min(c, hdp - 4);
+      f32x4 q4 = *reinterpret_cast<const f32x4*>(base);
+      f32x4 k4 = *reinterpret_cast<const f32x4*>(base + heads * hdp);
+      f32x4 v4 = need_v ? *reinterpret_cast<const f32x4*>(base + 2 * heads * hdp) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = c + e < hd;
+        q4[e] = ok ? q4[e] * scale : 0.f;
+        k4[e] = ok ? k4[e] : 0.f;
+        v4[e] = ok ? v4[e] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(Qs + row * AB_HS + (idx & 7) * 4) = q4;
+      *reinterpret_cast<f32x4*>(Ks + row * AB_HS + (idx & 7) * 4) = k4;
+      if (need_v) *reinterpret_cast<f32x4*>(Vs + row * AB_HS + (idx & 7) * 4) = v4;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx >> 5, cl = idx & 31, c = col0 + cl;
+      const float g = p.dout[(size_t)tok[row] * d + h * hd + min(c, hd - 1)];
+      Gs[row * AB_HS + cl] = c < hd ? g : 0.f;
+    }
+  };
+
+  const int nch = (hd + AB_HC - 1) / AB_HC;
+  f32x4 s[4], dp[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { s[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int ch = 0; ch < nch; ++ch) {
+    if (ch > 0) __syncthreads();
+    stage(ch, true);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < AB_HC; kk += 16) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(Qs + (wave * 16 + fr) * AB_HS + kk + 4 * fq);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(Gs + (wave * 16 + fr) * AB_HS + kk + 4 * fq);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 kb = *reinterpret_cast<const f32x4*>(Ks + (j * 16 + fr) * AB_HS + kk + 4 * fq);
+        const f32x4 vb = *reinterpret_cast<const f32x4*>(Vs + (j * 16 + fr) * AB_HS + kk + 4 * fq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], kb[e], s[j], 0, 0, 0);
+          dp[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[e], vb[e], dp[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- softmax (row = 16 wave + 4 fq + e, key = 16 j + fr), dS, bias-table gradient ----
+  {
+    int kinf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kinf[j] = inf[j * 16 + fr];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = wave * 16 + fq * 4 + e;
+      const int qi = inf[row];
+      const int qy = (qi >> 8) & 0xff, qx = qi & 0xff, qr = qi >> 16;
+      int bi[4];
+      float mx = -1e30f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kyy = (kinf[j] >> 8) & 0xff, kxx = kinf[j] & 0xff, kr = kinf[j] >> 16;
+        bi[j] = (qy - kyy + ws - 1) * tw + (qx - kxx + ws - 1);
+        float v = s[j][e] + tbl[bi[j]];
+        if (p.shift > 0 && qr != kr) v += -100.0f;
+        s[j][e] = v;
+        mx = fmaxf(mx, v);
+      }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s[j][e] = expf(s[j][e] - mx); sum += s[j][e]; }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) sum += __shfl_xor(sum, off);
+      const float inv = 1.0f / sum;
+      float dl = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s[j][e] *= inv; dl += s[j][e] * dp[j][e]; }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) dl += __shfl_xor(dl, off);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float ds = s[j][e] * (dp[j][e] - dl);
+        Pm[row * AB_PS + j * 16 + fr] = s[j][e];
+        Dm[row * AB_PS + j * 16 + fr] = ds;
+        atomicAdd(&dtb[bi[j]], ds);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < tw * tw) atomicAdd(p.dtable + (size_t)tid * heads + h, dtb[tid]);
+
+  // ---- pass B: dq, dk, dv per 32-column chunk ----
+  for (int ch = 0; ch < nch; ++ch) {
+    if (ch > 0 || nch > 1) { __syncthreads(); stage(ch, false); __syncthreads(); }
+    f32x4 dq[2], dk[2], dv[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) { dq[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[jt] = dq[jt]; dv[jt] = dq[jt]; }
+#pragma unroll
+    for (int kk = 0; kk < 64; kk += 16) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(Dm + (wave * 16 + fr) * AB_PS + kk + 4 * fq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kr = kk + 4 * fq + e;
+        const float at = Dm[kr * AB_PS + wave * 16 + fr];     // dS^T
+        const float pt = Pm[kr * AB_PS + wave * 16 + fr];     // P^T
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          const float kb = Ks[kr * AB_HS + jt * 16 + fr];
+          const float qb = Qs[kr * AB_HS + jt * 16 + fr];
+          const float gb = Gs[kr * AB_HS + jt * 16 + fr];
+          dq[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], kb, dq[jt], 0, 0, 0);
+          dk[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, qb, dk[jt], 0, 0, 0);
+          dv[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pt, gb, dv[jt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float* dst = p.dqkv + (size_t)tok[wave * 16 + fq * 4 + e] * (3 * d) + h * hd;
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        const int c = ch * AB_HC + jt * 16 + fr;
+        if (c < hd) {
+          dst[c] = dq[jt][e] * scale;
+          dst[d + c] = dk[jt][e];
+          dst[2 * d + c] = dv[jt][e];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ elementwise
+__global__ void dact_kernel(const float* __restrict__ dy, int ld_dy, const float* __restrict__ y, int ld_y,
+                            float* __restrict__ out, int ld_out, int rows, int C, float slope) {
+  const size_t total = (size_t)rows * C;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t m = i / C;
+    const int c = (int)(i - m * C);
+    out[m * ld_out + c] = dy[m * ld_dy + c] * (y[m * ld_y + c] > 0.f ? 1.f : slope);
+  }
+}
+
+__global__ void unshuffle_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int H, int W, int F) {
+  const size_t total = (size_t)B * H * W * 4 * F;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    // iterate in SOURCE order (coalesced reads): i = ((b*2H + y2)*2W + x2)*F + c
+    const int c = (int)(i % F);
+    size_t pix = i / F;
+    const int x2 = (int)(pix % (2 * W)); pix /= 2 * W;
+    const int y2 = (int)(pix % (2 * H));
+    const int b = (int)(pix / (2 * H));
+    const int n = c * 4 + (y2 & 1) * 2 + (x2 & 1);
+    dst[(((size_t)b * H + (y2 >> 1)) * W + (x2 >> 1)) * 4 * F + n] = src[i];
+  }
+}
+
+__global__ void copy_cols_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst, int rows, int C) {
+  const size_t total = (size_t)rows * ld_dst;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t m = i / ld_dst;
+    const int c = (int)(i - m * ld_dst);
+    dst[i] = c < C ? src[m * ld_src + c] : 0.f;
+  }
+}
+
+__global__ void l1_grad_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n, float scale) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float d = a[i] - b[i];
+    out[i] = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
+  }
+}
+
+// torch.optim.Adam single-tensor arithmetic (torch/optim/adam.py _single_tensor_adam, amsgrad off, maximize off)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            size_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gs) {
+  const float step_size = lr / bc1;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float grad = g[i] * gs;
+    const float w = p[i];
+    if (wd != 0.f) grad = grad + wd * w;
+    const float mi = m[i] + (grad - m[i]) * (1.f - b1);          // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = v[i] * b2 + (1.f - b2) * grad * grad;       // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = w - step_size * (mi / denom);
+  }
+}
+
+}  // namespace
+
+int srad_launch_wgrad(int prec, const WgradParams& p, hipStream_t stream) {
+  SRAD_REQUIRE(p.M > 0 && p.N > 0 && p.Cin > 0 && p.dW, "wgrad: empty problem M=%d N=%d Cin=%d", p.M, p.N, p.Cin);
+  SRAD_REQUIRE((p.N & 3) == 0 && (p.Cin & 3) == 0 && (p.ldy & 3) == 0 && (p.ldx & 3) == 0 && (p.ycol0 & 3) == 0 &&
+                   ((uintptr_t)p.dY & 15) == 0 && ((uintptr_t)p.X & 15) == 0,
+               "wgrad: operands need channel counts / strides that are multiples of 4 floats (N=%d Cin=%d ldy=%d ldx=%d)", p.N, p.Cin, p.ldy, p.ldx);
+  SRAD_REQUIRE(p.n_real > 0 && p.n_real <= p.N && p.cin_real > 0 && p.cin_real <= p.Cin, "wgrad: bad real extents");
+  SRAD_REQUIRE(p.ntaps == 1 || p.ntaps == 9, "wgrad: ntaps must be 1 or 9");
+  if (p.ntaps == 9 || p.stride != 1)
+    SRAD_REQUIRE(p.Ho > 0 && p.Wo > 0 && p.Hi > 0 && p.Wi > 0 && p.M % (p.Ho * p.Wo) == 0, "wgrad: bad conv geometry");
+  SRAD_REQUIRE(!p.row_scale || p.rps > 0, "wgrad: row_scale needs rows-per-sample");
+  return prec == SRAD_PREC_BF16 ? launch_wgrad<SRAD_PREC_BF16>(p, stream) : launch_wgrad<SRAD_PREC_F32>(p, stream);
+}
+
+int srad_launch_ln_bwd(const LnBwdParams& p, hipStream_t stream) {
+  SRAD_REQUIRE(p.rows > 0 && p.C > 0 && p.C <= 64 * LNB_J, "ln_bwd: channel count %d unsupported (1..%d)", p.C, 64 * LNB_J);
+  SRAD_REQUIRE(p.dxn && p.x && p.gamma && p.out, "ln_bwd: null argument");
+  SradProfScope prof(stream, SRAD_K_LN_BWD, 16.0 * p.rows * p.C, 4.0 * p.rows * p.C * (3 + (p.dres ? 1 : 0) + (p.accumulate ? 1 : 0)));
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3((p.rows + LNB_RPW - 1) / LNB_RPW), dim3(256), 0, stream, p);
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}
+
+int srad_launch_window_attn_bwd(const AttnBwdParams& p, hipStream_t stream) {
+  SRAD_REQUIRE(p.ws == 8, "window_attn_bwd: the training path supports window size 8 only (got %d)", p.ws);
+  SRAD_REQUIRE(p.H % p.ws == 0 && p.W % p.ws == 0, "window_attn_bwd: %dx%d not a multiple of the window", p.H, p.W);
+  SRAD_REQUIRE(p.d % p.heads == 0 && p.hdp % 4 == 0 && p.hdp >= p.d / p.heads, "window_attn_bwd: bad head geometry");
+  SRAD_REQUIRE(p.shift >= 0 && p.shift < p.ws, "window_attn_bwd: bad shift %d", p.shift);
+  static bool configured = false;
+  if (!configured) {
+    SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)AB_LDS));
+    configured = true;
+  }
+  const int nW = (p.H / p.ws) * (p.W / p.ws);
+  const double T = (double)p.B * p.H * p.W;
+  SradProfScope prof(stream, SRAD_K_ATTN_BWD, 10.0 * T * 64 * p.d, 4.0 * T * 8 * p.d);
+  hipLaunchKernelGGL(window_attn_bwd_kernel, dim3(p.B * nW, p.heads), dim3(256), AB_LDS, stream, p);
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}
+
+int srad_launch_dact(const float* dy, int ld_dy, const float* y, int ld_y, float* out, int ld_out, int rows, int C,
+                     float slope, hipStream_t stream) {
+  const size_t total = (size_t)rows * C;
+  SradProfScope prof(stream, SRAD_K_MISC, 1.0 * total, 12.0 * total);
+  hipLaunchKernelGGL(dact_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, ld_dy, y, ld_y, out, ld_out, rows, C, slope);
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}
+
+int srad_launch_unshuffle(const float* src, float* dst, int B, int H, int W, int F, hipStream_t stream) {
+  const size_t total = (size_t)B * H * W * 4 * F;
+  SradProfScope prof(stream, SRAD_K_LAYOUT, 0.0, 8.0 * total);
+  hipLaunchKernelGGL(unshuffle_kernel, dim3(grid_for(total)), dim3(256), 0, stream, src, dst, B, H, W, F);
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}
+
+int srad_launch_copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int rows, int C, hipStream_t stream) {
+  const size_t total = (size_t)rows * ld_dst;
+  SradProfScope prof(stream, SRAD_K_LAYOUT, 0.0, 4.0 * total + 4.0 * rows * C);
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(total)), dim3(256), 0, stream, src, ld_src, dst, ld_dst, rows, C);
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}
+
+int srad_launch_l1_grad(const float* a, const float* b, float* out, size_t n, float scale, hipStream_t stream) {
+  SradProfScope prof(stream, SRAD_K_OPTIM, 2.0 * n, 12.0 * n);
+  hipLaunchKernelGGL(l1_grad_kernel, dim3(grid_for(n)), dim3(256), 0, stream, a, b, out, n, scale);
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}
+
+int srad_launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int step, float grad_scale, hipStream_t stream) {
+  SRAD_REQUIRE(step >= 1, "adam: step counts from 1 (got %d)", step);
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  SradProfScope prof(stream, SRAD_K_OPTIM, 12.0 * n, 28.0 * n);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                     weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}

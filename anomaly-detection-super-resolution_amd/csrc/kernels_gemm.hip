@@ -18,6 +18,10 @@ template <> struct PrecT<SRAD_PREC_BF16> { using type = __bf16; static constexpr
 template <> struct PrecT<SRAD_PREC_F32>  { using type = float;  static constexpr int PAD = 4; };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// d/dx of the exact-erf GELU: Phi(x) + x * phi(x)
+__device__ __forceinline__ float dgelu_erf(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
 
 // CPS = 32-wide K chunks per stage.  A whole stage (up to CPS*32 columns of K for the BM rows of A
 // and the BN rows of W) is loaded with every load in flight at once, written to LDS, and consumed by
@@ -325,6 +329,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] += bv[j];
+  if (p.Ypre) {                                       // training: keep the pre-activation (GELU backward needs it)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + wm0 + i * 16 + fq * 4 + e;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          if (m < p.M && ncol[j] < p.N) p.Ypre[(unsigned)(m * p.ldy + p.yoff) + (unsigned)ncol[j]] = acc[i][j][e];
+      }
+  }
   if (p.act == SRAD_ACT_GELU) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -382,10 +397,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
           }
         }
       }
+      float rs = p.alpha;
+      if (p.row_scale) rs *= p.row_scale[mc / p.rps];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        float v = acc[i][j][e] * p.alpha;
-        if (p.R) v += rv[i][e][j];
+        float v = acc[i][j][e] * rs;
+        if (p.R) {
+          const float r = rv[i][e][j];
+          if (p.rmode == SRAD_RMODE_ADD) v += r;
+          else if (p.rmode == SRAD_RMODE_DGELU) v *= dgelu_erf(r);
+          else v *= r > 0.f ? 1.f : p.slope;
+        }
         if (m_ok && ncol[j] < p.N) {
           p.Y[yrow + ycol[j]] = v;
           if constexpr (SPECIAL) {
@@ -417,6 +439,22 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, void* __restri
     }
     float v = 0.f;
     if (n < N && sc >= 0 && sc < Cin) v = src[((size_t)n * Cin + sc) * ntaps + tap];
+    reinterpret_cast<T*>(dst)[i] = (T)v;
+  }
+}
+
+// Transposed packing for the data gradient: dst row = input channel c, column = output channel n, tap mirrored.
+template <int PREC>
+__global__ void pack_weight_t_kernel(const float* __restrict__ src, void* __restrict__ dst, int N, int Cin, int ntaps,
+                                     int Rp, int Kp) {
+  using T = typename PrecT<PREC>::type;
+  const size_t total = (size_t)Rp * ntaps * Kp;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % Kp);
+    const int tap = (int)((i / Kp) % ntaps);
+    const int c = (int)(i / ((size_t)Kp * ntaps));
+    float v = 0.f;
+    if (n < N && c < Cin) v = src[((size_t)n * Cin + c) * ntaps + (ntaps - 1 - tap)];
     reinterpret_cast<T*>(dst)[i] = (T)v;
   }
 }
@@ -521,4 +559,19 @@ int srad_launch_pack_weight_padded(int prec, const float* src, void* dst, int n,
 
 int srad_launch_pack_weight(int prec, const float* src, void* dst, int n, int cin, int ntaps, hipStream_t stream) {
   return srad_launch_pack_weight_padded(prec, src, dst, n, cin, ntaps, n, 0, 0, stream);
+}
+
+int srad_launch_pack_weight_transposed(int prec, const float* src, void* dst, int n, int cin, int ntaps, int n_pad,
+                                       int cin_pad, hipStream_t stream) {
+  SRAD_REQUIRE(n_pad >= n && cin_pad >= cin, "pack_weight_transposed: bad padding");
+  const int Rp = srad_np(cin_pad), Kp = srad_cp(n_pad);
+  const size_t total = (size_t)Rp * ntaps * Kp;
+  const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+  SradProfScope prof(stream, SRAD_K_PACK, 0.0, 4.0 * n * cin * ntaps + (prec == SRAD_PREC_BF16 ? 2.0 : 4.0) * total);
+  if (prec == SRAD_PREC_BF16)
+    hipLaunchKernelGGL((pack_weight_t_kernel<SRAD_PREC_BF16>), dim3(blocks), dim3(256), 0, stream, src, dst, n, cin, ntaps, Rp, Kp);
+  else
+    hipLaunchKernelGGL((pack_weight_t_kernel<SRAD_PREC_F32>), dim3(blocks), dim3(256), 0, stream, src, dst, n, cin, ntaps, Rp, Kp);
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
 }

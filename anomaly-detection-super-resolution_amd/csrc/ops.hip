@@ -135,6 +135,54 @@ int srad_bench_mlp_block(int M, int d, int m, int no, const float* attn, const f
   return SRAD_OK;
 }
 
+int srad_op_wgrad(int precision, const float* dy, int ldy, const float* x, int ldx, int B, int Hi, int Wi, int N,
+                  int Cin, int ntaps, int stride, const float* row_scale, float alpha, float* dw, float* db,
+                  void* stream) {
+  SRAD_REQUIRE(dy && x && dw, "op_wgrad: null argument");
+  SRAD_REQUIRE(stride == 1 || stride == 2, "op_wgrad: stride must be 1 or 2");
+  WgradParams p{};
+  const int pad = ntaps == 9 ? 1 : 0, k = ntaps == 9 ? 3 : 1;
+  p.Hi = Hi; p.Wi = Wi; p.Ho = (Hi + 2 * pad - k) / stride + 1; p.Wo = (Wi + 2 * pad - k) / stride + 1; p.stride = stride;
+  p.dY = dy; p.ldy = ldy; p.X = x; p.ldx = ldx; p.M = B * p.Ho * p.Wo;
+  p.N = N; p.Cin = Cin; p.n_real = N; p.cin_real = Cin; p.ntaps = ntaps;
+  p.row_scale = row_scale; p.rps = p.Ho * p.Wo; p.alpha = alpha; p.dW = dw; p.db = db;
+  return srad_launch_wgrad(precision, p, reinterpret_cast<hipStream_t>(stream));
+}
+
+int srad_op_dgrad(int precision, const float* dy, int ldy, int B, int H, int W, int N, const float* w, int Cin,
+                  int ntaps, const float* r, int ldr, int rmode, float slope, float alpha, const float* row_scale,
+                  float* dx, int ldx, void* scratch, size_t scratch_bytes, void* stream) {
+  SRAD_REQUIRE(dy && w && dx && scratch, "op_dgrad: null argument");
+  SRAD_REQUIRE((N & 3) == 0 && (Cin & 3) == 0, "op_dgrad: N and Cin must be multiples of 4");
+  const size_t need = srad_packed_bytes(precision, Cin, N, ntaps);
+  SRAD_REQUIRE(scratch_bytes >= need, "op_dgrad: scratch %zu bytes, %zu needed", scratch_bytes, need);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  SRAD_TRY(srad_launch_pack_weight_transposed(precision, w, scratch, N, Cin, ntaps, N, Cin, s));
+  GemmParams p{};
+  p.Hi = p.Ho = H; p.Wi = p.Wo = W; p.stride = 1;
+  p.X = dy; p.ldx = ldy; p.M = B * H * W; p.Cin = N; p.Cp = srad_cp(N); p.ntaps = ntaps; p.ln_eps = 1e-5f;
+  p.Wp = scratch; p.N = Cin; p.slope = slope; p.alpha = alpha;
+  p.R = r; p.ldr = ldr; p.rmode = rmode; p.row_scale = row_scale; p.rps = H * W;
+  p.Y = dx; p.ldy = ldx;
+  return srad_launch_gemm(precision, p, s);
+}
+
+int srad_op_layernorm_bwd(const float* dxn, const float* x, int ldx, const float* gamma, const float* dres, float* out,
+                          int accumulate, float* dgamma, float* dbeta, int rows, int C, void* stream) {
+  SRAD_REQUIRE(dxn && x && gamma && out, "op_layernorm_bwd: null argument");
+  LnBwdParams l{};
+  l.dxn = dxn; l.ld_dxn = C; l.x = x; l.ldx = ldx; l.gamma = gamma; l.dres = dres; l.ld_dres = C;
+  l.out = out; l.ld_out = C; l.accumulate = accumulate; l.dgamma = dgamma; l.dbeta = dbeta; l.rows = rows; l.C = C; l.eps = 1e-5f;
+  return srad_launch_ln_bwd(l, reinterpret_cast<hipStream_t>(stream));
+}
+
+int srad_op_window_attn_bwd(const float* qkv, const float* dout, float* dqkv, const float* table, float* dtable, int B,
+                            int H, int W, int ws, int shift, int d, int heads, int hdp, void* stream) {
+  SRAD_REQUIRE(qkv && dout && dqkv && table && dtable, "op_window_attn_bwd: null argument");
+  AttnBwdParams a{qkv, dout, dqkv, table, dtable, B, H, W, ws, shift, d, heads, hdp};
+  return srad_launch_window_attn_bwd(a, reinterpret_cast<hipStream_t>(stream));
+}
+
 size_t srad_op_gemm_scratch_bytes(int precision, int N, int Cin, int ntaps) {
   return srad_packed_bytes(precision, N, Cin, ntaps);
 }

@@ -70,7 +70,14 @@ struct GemmParams {
   int hsplit_hd;   // > 0: column n is stored at (n / hsplit_hd) * hsplit_hdp + n % hsplit_hd, i.e. every
   int hsplit_hdp;  //      head's slice is padded to hsplit_hdp floats (the attention kernel's input layout)
   float* pool;     // optional [B][N] per-image column sums of the stored values (atomicAdd)
+  // ---- training extensions (all off when zero) ----
+  int rmode;                 // how R enters: 0 v = act(acc)*alpha*rs + R (residual); 1 v = acc*alpha*rs * gelu'(R);
+                             //               2 v = acc*alpha*rs * (R > 0 ? 1 : slope)   (backward through an activation)
+  const float* row_scale;    // optional per-sample factor rs = row_scale[m / rps] (DropPath keep mask / keep_prob)
+  int rps;                   // rows per sample
+  float* Ypre;               // optional second output: acc + bias before the activation (same ldy / yoff as Y)
 };
+enum { SRAD_RMODE_ADD = 0, SRAD_RMODE_DGELU = 1, SRAD_RMODE_DLRELU = 2 };
 
 int srad_launch_gemm(int prec, const GemmParams& p, hipStream_t stream);
 
@@ -87,6 +94,10 @@ int srad_launch_pack_weight(int prec, const float* src, void* dst, int n, int ci
 // the packed geometry is that of (n_pad, (cin / grp_real) * grp_pad)
 int srad_launch_pack_weight_padded(int prec, const float* src, void* dst, int n, int cin, int ntaps, int n_pad,
                                    int grp_real, int grp_pad, hipStream_t stream);
+// Data-gradient operand: the same tensor packed as the weight of the transposed convolution,
+// dst[c][8 - tap][n] (taps mirrored for 3x3, identity for 1x1), geometry (rows cin_pad, columns n_pad).
+int srad_launch_pack_weight_transposed(int prec, const float* src, void* dst, int n, int cin, int ntaps, int n_pad,
+                                       int cin_pad, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------
 // Window attention (DRCT): qkv [T][3d] -> out [T][d], tokens in raster order per image.
@@ -135,6 +146,61 @@ bool srad_qkv_attn_supported(int prec, int ws, int H, int W, int d, int heads);
 int srad_launch_qkv_attn(const QkvAttnParams& p, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------
+// Backward kernels (kernels_bwd.hip) - the training path of reference src/trainer.py:152-222.
+// ------------------------------------------------------------------------------------------
+// Weight gradient of a Linear / conv layer, accumulated (atomicAdd) into the PyTorch-layout fp32 tensor:
+//   dW[n][c][tap] += alpha * sum_m rs(m) * dY[m][ycol0 + n] * A(m, tap, c),   db[n] += alpha * sum_m rs(m) * dY[m][ycol0 + n]
+// with A the forward's row gather (identity for Linear, the 3x3 / strided window for convs).
+struct WgradParams {
+  const float* dY; int ldy, ycol0;
+  const float* X; int ldx;
+  int M, N, Cin, ntaps;        // N, Cin: padded to multiples of 4 as stored in dY / X
+  int n_real, cin_real;        // extents of dW (columns/rows beyond are padding and never written)
+  int Hi, Wi, Ho, Wo, stride;  // conv geometry (M = B*Ho*Wo); ignored for ntaps == 1 && stride == 1
+  const float* row_scale; int rps;
+  float alpha;
+  float* dW;                   // [n_real][cin_real][ntaps]
+  float* db;                   // [n_real] or null
+};
+int srad_launch_wgrad(int prec, const WgradParams& p, hipStream_t stream);
+
+// LayerNorm backward over rows: out (+)= dLN(dxn; x, gamma) + dres ; dgamma/dbeta += column sums (atomicAdd)
+struct LnBwdParams {
+  const float* dxn; int ld_dxn;
+  const float* x; int ldx;
+  const float* gamma;
+  const float* dres; int ld_dres;    // optional gradient arriving over the residual path
+  float* out; int ld_out; int accumulate;
+  float* dgamma; float* dbeta;
+  int rows, C; float eps;
+};
+int srad_launch_ln_bwd(const LnBwdParams& p, hipStream_t stream);
+
+// Shifted-window attention backward (window size 8): recomputes P from the saved head-padded q|k|v.
+struct AttnBwdParams {
+  const float* qkv;    // [T][3][heads][hdp] as written by the forward
+  const float* dout;   // [T][d] gradient of the attention output (pre-proj)
+  float* dqkv;         // [T][3*d] compact q | k | v gradients (plain Linear output order)
+  const float* table;  // [(2ws-1)^2][heads]
+  float* dtable;       // accumulated (atomicAdd)
+  int B, H, W, ws, shift, d, heads, hdp;
+};
+int srad_launch_window_attn_bwd(const AttnBwdParams& p, hipStream_t stream);
+
+// out[m][c] = dy[m*ld_dy + c] * (y[m*ld_y + c] > 0 ? 1 : slope), c < C  (backward through (Leaky)ReLU)
+int srad_launch_dact(const float* dy, int ld_dy, const float* y, int ld_y, float* out, int ld_out, int rows, int C,
+                     float slope, hipStream_t stream);
+// inverse of PixelShuffle(2) on NHWC: src [B][2H][2W][F] -> dst [B*H*W][4F], channel n = c*4 + dy*2 + dx
+int srad_launch_unshuffle(const float* src, float* dst, int B, int H, int W, int F, hipStream_t stream);
+// dst[m][0..ld_dst) = src[m][0..C) followed by zeros
+int srad_launch_copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int rows, int C, hipStream_t stream);
+// out = scale * sign(a - b)
+int srad_launch_l1_grad(const float* a, const float* b, float* out, size_t n, float scale, hipStream_t stream);
+// torch.optim.Adam (L2-style weight decay) on flat fp32 buffers; grad_scale multiplies the gradient first
+int srad_launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int step, float grad_scale, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------
 // misc kernels
 // ------------------------------------------------------------------------------------------
 int srad_launch_layernorm(const float* x, int ldx, float* y, int ldy, int rows, int C,
@@ -152,7 +218,8 @@ int srad_launch_nhwc_to_nchw(const float* x, int ldx, float* y, int B, int C, in
 // ------------------------------------------------------------------------------------------
 enum {
   SRAD_K_GEMM_BN64 = 0, SRAD_K_GEMM_BN32, SRAD_K_GEMM_BN16, SRAD_K_ATTN, SRAD_K_LAYERNORM,
-  SRAD_K_LAYOUT, SRAD_K_PACK, SRAD_K_SCORE, SRAD_K_MISC, SRAD_K_MLP_BLOCK, SRAD_K_QKV_ATTN, SRAD_K_COUNT
+  SRAD_K_LAYOUT, SRAD_K_PACK, SRAD_K_SCORE, SRAD_K_MISC, SRAD_K_MLP_BLOCK, SRAD_K_QKV_ATTN,
+  SRAD_K_WGRAD, SRAD_K_ATTN_BWD, SRAD_K_LN_BWD, SRAD_K_OPTIM, SRAD_K_COUNT
 };
 struct SradProfScope {
   hipStream_t s; int active;

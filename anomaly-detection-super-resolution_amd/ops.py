@@ -87,3 +87,75 @@ def layernorm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor) -> torch.Tensor
     L.check(L.lib().srad_op_layernorm(L.dptr(x), x.stride(0), L.dptr(y), y.stride(0), x.shape[0], x.shape[1],
                                       L.dptr(g), L.dptr(b), L.current_stream_ptr()), "op_layernorm")
     return y
+
+
+# ----------------------------------------------------------------------------------- backward operators
+def wgrad(dy: torch.Tensor, x: torch.Tensor, N: int, Cin: int, *, ntaps: int = 1, B: int = 1, H: int = 0, W: int = 0,
+          stride: int = 1, row_scale: Optional[torch.Tensor] = None, alpha: float = 1.0, bias: bool = True,
+          precision: str = "fp32"):
+    """Weight / bias gradient of Linear (ntaps 1) or a 3x3 conv: dy [B*Ho*Wo, >=N], x [B*H*W, >=Cin] NHWC rows.
+    Returns (dW [N, Cin, ntaps], db [N] or None), freshly zeroed and accumulated into by the kernel."""
+    _need_cuda(dy, x)
+    assert dy.stride(1) == 1 and x.stride(1) == 1 and N % 4 == 0 and Cin % 4 == 0
+    if ntaps == 1 and stride == 1:
+        B, H, W = 1, 1, x.shape[0]
+    dw = torch.zeros(N, Cin, ntaps, dtype=torch.float32, device=x.device)
+    db = torch.zeros(N, dtype=torch.float32, device=x.device) if bias else None
+    L.check(L.lib().srad_op_wgrad(L.PRECISIONS[precision], L.dptr(dy), dy.stride(0), L.dptr(x), x.stride(0), B, H, W, N,
+                                  Cin, ntaps, stride, L.dptr(row_scale), alpha, L.dptr(dw), L.dptr(db),
+                                  L.current_stream_ptr()), "op_wgrad")
+    return dw, db
+
+
+def dgrad(dy: torch.Tensor, weight: torch.Tensor, *, B: int = 1, H: int = 0, W: int = 0, r: Optional[torch.Tensor] = None,
+          rmode: int = 0, slope: float = 0.0, alpha: float = 1.0, row_scale: Optional[torch.Tensor] = None,
+          precision: str = "fp32") -> torch.Tensor:
+    """Data gradient dx = dy . W of Linear / 3x3 stride-1 conv (weight [N, Cin] or [N, Cin, 3, 3])."""
+    _need_cuda(dy, weight)
+    ntaps = 9 if weight.dim() == 4 and weight.shape[-1] == 3 else 1
+    N, Cin = weight.shape[0], weight.shape[1]
+    w = weight.detach().reshape(N, Cin, ntaps).float().contiguous()
+    if ntaps == 1:
+        B, H, W = 1, 1, dy.shape[0]
+    dx = torch.empty(dy.shape[0], Cin, dtype=torch.float32, device=dy.device)
+    prec = L.PRECISIONS[precision]
+    nbytes = L.lib().srad_op_gemm_scratch_bytes(prec, Cin, N, ntaps)
+    scratch = torch.empty(nbytes + 256, dtype=torch.uint8, device=dy.device)
+    off = (-scratch.data_ptr()) % 256
+    L.check(L.lib().srad_op_dgrad(prec, L.dptr(dy), dy.stride(0), B, H, W, N, L.dptr(w), Cin, ntaps, L.dptr(r),
+                                  0 if r is None else r.stride(0), rmode, slope, alpha, L.dptr(row_scale), L.dptr(dx),
+                                  dx.stride(0), C.c_void_p(scratch.data_ptr() + off), C.c_size_t(nbytes),
+                                  L.current_stream_ptr()), "op_dgrad")
+    return dx
+
+
+def layernorm_bwd(dxn: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, dres: Optional[torch.Tensor] = None,
+                  out: Optional[torch.Tensor] = None):
+    """Returns (dx (+ dres, + out if given), dgamma, dbeta)."""
+    _need_cuda(dxn, x, gamma)
+    rows, Cc = dxn.shape
+    acc = out is not None
+    if out is None:
+        out = torch.empty(rows, Cc, dtype=torch.float32, device=x.device)
+    dg = torch.zeros(Cc, dtype=torch.float32, device=x.device)
+    db = torch.zeros(Cc, dtype=torch.float32, device=x.device)
+    L.check(L.lib().srad_op_layernorm_bwd(L.dptr(dxn.contiguous()), L.dptr(x), x.stride(0), L.dptr(gamma),
+                                          L.dptr(None if dres is None else dres.contiguous()), L.dptr(out), 1 if acc else 0,
+                                          L.dptr(dg), L.dptr(db), rows, Cc, L.current_stream_ptr()), "op_layernorm_bwd")
+    return out, dg, db
+
+
+def window_attention_bwd(qkv: torch.Tensor, dout: torch.Tensor, table: torch.Tensor, B: int, H: int, W: int, ws: int,
+                         shift: int, heads: int):
+    """Backward of window_attention: qkv [T, 3d] (reference column order), dout [T, d] -> (dqkv [T, 3d], dtable)."""
+    _need_cuda(qkv, dout, table)
+    d = qkv.shape[1] // 3
+    hd = d // heads
+    hdp = (hd + 3) // 4 * 4
+    padded = torch.nn.functional.pad(qkv.reshape(-1, 3 * heads, hd).float(), (0, hdp - hd)).reshape(-1, 3 * heads * hdp).contiguous()
+    dqkv = torch.empty(qkv.shape[0], 3 * d, dtype=torch.float32, device=qkv.device)
+    dtable = torch.zeros_like(table, dtype=torch.float32).contiguous()
+    L.check(L.lib().srad_op_window_attn_bwd(L.dptr(padded), L.dptr(dout.contiguous()), L.dptr(dqkv), L.dptr(table.contiguous()),
+                                            L.dptr(dtable), B, H, W, ws, shift, d, heads, hdp, L.current_stream_ptr()),
+            "op_window_attn_bwd")
+    return dqkv, dtable

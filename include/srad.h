@@ -67,6 +67,40 @@ int srad_drct_forward(srad_drct_t* h, const float* x, int B, int H, int W, float
 /* FLOPs (2 per MAC) of one forward at this shape, for roofline accounting */
 int srad_drct_flops(const srad_drct_t* h, int B, int H, int W, double* flops);
 
+/* ------------------------------------------------------------------ DRCT training step (src/trainer.py:152-222)
+ * loss.backward() and optimizer.step() for the DRCT model.  Parameters and gradients live in two flat fp32
+ * device buffers owned by the caller (PyTorch parameters / .grad are views into them): entry idx of
+ * srad_drct_param_info starts at srad_drct_train_param_offset(idx) floats, total srad_drct_train_param_floats. */
+int srad_drct_train_param_floats(srad_drct_t* h, int64_t* total);
+int srad_drct_train_param_offset(srad_drct_t* h, int idx, int64_t* off_floats);
+/* second caller-owned arena: transposed weight packs for the data gradients (bind after srad_drct_bind_arena) */
+int srad_drct_train_arena_bytes(srad_drct_t* h, size_t* bytes);
+int srad_drct_train_bind(srad_drct_t* h, void* train_arena, size_t bytes);
+/* refresh all packed weights from the flat fp32 parameters: call after loading and after every optimizer step */
+int srad_drct_sync_params(srad_drct_t* h, const float* dev_flat_params, void* stream);
+int srad_drct_train_workspace_bytes(const srad_drct_t* h, int B, int H, int W, size_t* bytes);
+/* model.train() forward (src/drct.py:886-898 with DropPath 107-133 active): keep_scale is a device array
+ * [2 * n_rdg * 5][B] of per-sample factors floor(keep + U) / keep (rows 2j / 2j+1: attention / MLP branch of
+ * block j), or NULL for no DropPath.  Leaves the saved activations in `workspace` for srad_drct_backward. */
+int srad_drct_forward_train(srad_drct_t* h, const float* x, int B, int H, int W, float* y, const float* keep_scale,
+                            void* workspace, size_t workspace_bytes, void* stream);
+/* loss.backward() (src/trainer.py:198): dy = dLoss/dy [B,C,H*s,W*s]; parameter gradients are ACCUMULATED into
+ * dev_flat_grad; dx (optional) receives dLoss/dx.  on_bucket (optional) is called on the host as soon as the
+ * last kernel writing gradient bucket b has been enqueued (buckets: srad_drct_bucket_range, in completion
+ * order) so a data-parallel caller can start that bucket's all-reduce while the backward continues. */
+typedef void (*srad_bucket_fn)(void* user, int bucket);
+int srad_drct_num_buckets(const srad_drct_t* h);
+int srad_drct_bucket_range(srad_drct_t* h, int bucket, int64_t* off_floats, int64_t* n_floats);
+int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, const float* keep_scale, float* dx,
+                       float* dev_flat_grad, void* workspace, size_t workspace_bytes, void* stream,
+                       srad_bucket_fn on_bucket, void* user);
+/* gradient seed of nn.L1Loss(reduction='mean') (src/loss.py:84): out = scale * sign(a - b), scale = 1/numel */
+int srad_l1_grad(const float* a, const float* b, float* out, int64_t n, float scale, void* stream);
+/* torch.optim.Adam.step on flat buffers (src/trainer.py:49-59; L2 weight decay, amsgrad off); step counts from 1;
+ * grad_scale multiplies the gradient first (1/world_size after a summing all-reduce) */
+int srad_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
 /* ------------------------------------------------------------------ DRN-L (src/drn.py:160-270) */
 typedef struct srad_drn srad_drn_t;
 typedef struct {
@@ -144,6 +178,25 @@ int srad_op_window_attn(int precision, const float* qkv, float* out, const float
 /* nn.LayerNorm over the last dimension, eps 1e-5 (src/drct.py:798,833) */
 int srad_op_layernorm(const float* x, int ldx, float* y, int ldy, int rows, int C, const float* g, const float* b,
                       void* stream);
+
+/* Backward operators (autograd of the rows above).
+ * Weight/bias gradient of Linear / conv: dw[N][Cin][taps] += alpha * dy^T A(x), db[N] += alpha * colsum(dy);
+ * dy [B*Ho*Wo][ldy], x [B*Hi*Wi][ldx]; N, Cin multiples of 4; row_scale optional per-sample factor [B]. */
+int srad_op_wgrad(int precision, const float* dy, int ldy, const float* x, int ldx, int B, int Hi, int Wi, int N,
+                  int Cin, int ntaps, int stride, const float* row_scale, float alpha, float* dw, float* db,
+                  void* stream);
+/* Data gradient dx = (dy . w) * alpha * row_scale (* gelu'(r) if rmode 1, * lrelu'(r) if rmode 2), stride 1:
+ * the forward GEMM on the transposed pack of w [N][Cin][taps]; scratch >= srad_op_gemm_scratch_bytes(p, Cin, N, taps) */
+int srad_op_dgrad(int precision, const float* dy, int ldy, int B, int H, int W, int N, const float* w, int Cin,
+                  int ntaps, const float* r, int ldr, int rmode, float slope, float alpha, const float* row_scale,
+                  float* dx, int ldx, void* scratch, size_t scratch_bytes, void* stream);
+/* LayerNorm backward: out (+)= dLN(dxn; x, gamma) + dres; dgamma / dbeta accumulated */
+int srad_op_layernorm_bwd(const float* dxn, const float* x, int ldx, const float* gamma, const float* dres, float* out,
+                          int accumulate, float* dgamma, float* dbeta, int rows, int C, void* stream);
+/* Window attention backward (window size 8): qkv head-padded as for srad_op_window_attn, dout [T][d],
+ * dqkv [T][3d] compact, dtable accumulated */
+int srad_op_window_attn_bwd(const float* qkv, const float* dout, float* dqkv, const float* table, float* dtable, int B,
+                            int H, int W, int ws, int shift, int d, int heads, int hdp, void* stream);
 
 /* ------------------------------------------------------------------ diagnostics
  * Per-kernel-class device timing with HIP events on the launch stream (bench.py's roofline numbers). */

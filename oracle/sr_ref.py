@@ -92,8 +92,11 @@ def window_attention(sd, p: str, x: torch.Tensor, ws: int, heads: int, mask) -> 
 def swin_block(sd, p: str, x: torch.Tensor, H: int, W: int, ws: int, heads: int,
                shift: int, keep=None) -> torch.Tensor:
     """src/drct.py:472-512.  x: [B, H*W, C].  ``keep`` (optional [B] tensor of 0/1 divided
-    by keep_prob) restates DropPath in training mode (drct.py:107-119); None = eval."""
+    by keep_prob, or a pair of them: the module's drop_path is CALLED twice per block, drct.py:509-510,
+    so the attention and MLP branches draw independent masks) restates DropPath in training mode
+    (drct.py:107-119); None = eval."""
     B, L, C = x.shape
+    keep_a, keep_m = keep if isinstance(keep, (tuple, list)) else (keep, keep)
     shortcut = x
     x = F.layer_norm(x, (C,), _t(sd, p + "norm1.weight"), _t(sd, p + "norm1.bias"), 1e-5)
     x = x.view(B, H, W, C)
@@ -106,15 +109,15 @@ def swin_block(sd, p: str, x: torch.Tensor, H: int, W: int, ws: int, heads: int,
     if shift > 0:
         x = torch.roll(x, shifts=(shift, shift), dims=(1, 2))
     x = x.view(B, H * W, C)
-    if keep is not None:
-        x = x * keep.view(B, 1, 1)
+    if keep_a is not None:
+        x = x * keep_a.view(B, 1, 1)
     x = shortcut + x
     y = F.layer_norm(x, (C,), _t(sd, p + "norm2.weight"), _t(sd, p + "norm2.bias"), 1e-5)
     y = F.linear(y, _t(sd, p + "mlp.fc1.weight"), _t(sd, p + "mlp.fc1.bias"))
     y = F.gelu(y)                                   # exact erf GELU (drct.py:175,184-190)
     y = F.linear(y, _t(sd, p + "mlp.fc2.weight"), _t(sd, p + "mlp.fc2.bias"))
-    if keep is not None:
-        y = y * keep.view(B, 1, 1)
+    if keep_m is not None:
+        y = y * keep_m.view(B, 1, 1)
     return x + y
 
 
