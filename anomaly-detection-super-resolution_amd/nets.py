@@ -195,9 +195,13 @@ class _EngineModule(nn.Module):
             raise ValueError(f"expected {channels} channels, got {x.shape[1]}")
         if not x.is_cuda:
             raise RuntimeError("srad_amd runs on the GPU only (HIP engine); got a CPU tensor - there is no CPU fallback")
-        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("the HIP backward pass is not built yet: call under torch.no_grad() / .eval()")
+        if self.training and torch.is_grad_enabled() and not self._can_train():
+            raise NotImplementedError(f"{type(self).__name__}: the HIP backward pass is not built for this model: "
+                                      "call under torch.no_grad() / .eval()")
         return x.detach().to(torch.float32).contiguous()
+
+    def _can_train(self) -> bool:
+        return False
 
     def flops(self, B: int, H: int, W: int) -> float:
         dev = next(self.parameters()).device
@@ -205,6 +209,23 @@ class _EngineModule(nn.Module):
         f = C.c_double()
         L.check(self._fn("flops")(self._handle, B, H, W, C.byref(f)), "flops")
         return f.value
+
+
+class _DrctTrainFn(torch.autograd.Function):
+    """autograd seam of the training step: forward = srad_drct_forward_train, backward = srad_drct_backward.
+    Parameter gradients are written straight into the module's flat gradient buffer (``p.grad`` views);
+    only dLoss/dx travels through autograd.  One forward may be outstanding per module."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, module):
+        ctx.module = module
+        ctx.need_dx = x.requires_grad
+        return module._forward_train(x.detach().to(torch.float32).contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = ctx.module._backward(dy.to(torch.float32).contiguous(), ctx.need_dx)
+        return dx, None, None
 
 
 # ------------------------------------------------------------------ DRCT
@@ -232,6 +253,7 @@ class DRCT(_EngineModule):
         self.window_size = cfg.window_size
         self.upscale = cfg.upscale
         self.img_range = cfg.img_range
+        self.drop_path_rate = float(getattr(opt, "drop_path_rate", 0.1))      # src/drct.py:736
         prec = precision or getattr(opt, "precision", "fp32")
         graph = getattr(opt, "use_graph", True) if use_graph is None else use_graph
         self._init_engine(S.drct_spec(cfg), cfg, prec, graph)
@@ -244,7 +266,129 @@ class DRCT(_EngineModule):
         L.check(L.lib().srad_drct_create(C.byref(cc), C.byref(h)), "drct_create")
         return h
 
+    # -- training (C ABI srad_drct_forward_train / srad_drct_backward) ------------------------
+    def _can_train(self) -> bool:
+        return True
+
+    def enable_training(self) -> "DRCT":
+        """Re-home every parameter into ONE flat fp32 device buffer (``p.data`` become views, state-dict and
+        optimizers keep working) with a twin flat gradient buffer (``p.grad`` views), and bind the engine's
+        training arena.  Call after the module is on its GPU; moving it afterwards needs another call."""
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("srad_amd trains on the GPU only (HIP engine); move the model with .cuda() first")
+        self._ensure_handle(dev)
+        h = self._handle
+        total = C.c_int64()
+        L.check(L.lib().srad_drct_train_param_floats(h, C.byref(total)), "train_param_floats")
+        flat = torch.zeros(total.value, dtype=torch.float32, device=dev)
+        grad = torch.zeros(total.value, dtype=torch.float32, device=dev)
+        views = []
+        off = C.c_int64()
+        with torch.no_grad():
+            for i, (name, numel) in enumerate(self._engine_params):
+                L.check(L.lib().srad_drct_train_param_offset(h, i, C.byref(off)), "train_param_offset")
+                p = self.get_parameter(name)
+                v = flat[off.value:off.value + numel].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                g = grad[off.value:off.value + numel].view(p.shape)
+                p.grad = g
+                views.append((p, g))
+        nbytes = C.c_size_t()
+        L.check(L.lib().srad_drct_train_arena_bytes(h, C.byref(nbytes)), "train_arena_bytes")
+        self._tarena = torch.zeros(nbytes.value + 256, dtype=torch.uint8, device=dev)
+        tp, tb = self._aligned(self._tarena)
+        L.check(L.lib().srad_drct_train_bind(h, tp, tb), "train_bind")
+        self.flat_params, self.flat_grads, self._grad_views = flat, grad, views
+        self._synced_version = None
+        self._train_ws = {}
+        self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+        self._param_cache = None
+        self.keep_scale_override = None     # tests: explicit DropPath factors [2 * n_blocks, B]
+        self.on_bucket = None               # data-parallel hook: callable(bucket index), see GradReducer
+        nb = L.lib().srad_drct_num_buckets(h)
+        a, b = C.c_int64(), C.c_int64()
+        self.grad_buckets = []
+        for i in range(nb):
+            L.check(L.lib().srad_drct_bucket_range(h, i, C.byref(a), C.byref(b)), "bucket_range")
+            self.grad_buckets.append((a.value, b.value))
+        return self
+
+    def mark_params_dirty(self) -> None:
+        """Tell the engine the flat parameters were changed by something that does not bump tensor versions
+        (the fused Adam kernel)."""
+        self._synced_version = None
+
+    def _sync_flat(self) -> None:
+        if getattr(self, "flat_params", None) is None:
+            raise RuntimeError("DRCT: call enable_training() before a training-mode forward")
+        ver = self.flat_params._version
+        if self._synced_version != ver:
+            L.check(L.lib().srad_drct_sync_params(self._handle, L.dptr(self.flat_params), L.current_stream_ptr()), "sync_params")
+            self._synced_version = ver
+            self._tags = None               # the eval path re-checks its own tags
+
+    def zero_grad(self, set_to_none: bool = False) -> None:   # noqa: D401 - nn.Module signature
+        if getattr(self, "flat_grads", None) is not None:
+            self.flat_grads.zero_()
+            for p, g in self._grad_views:
+                p.grad = g
+        else:
+            super().zero_grad(set_to_none)
+
+    def drop_path_keep_probs(self) -> torch.Tensor:
+        """keep_prob of every Swin block: all five blocks of RDG i use dpr[i * depth] of
+        linspace(0, rate, sum(depths)) (src/drct.py:819,829,332)."""
+        c = self.cfg
+        rates = S.DRCTConfig.drop_path_probs(type("R", (), dict(n_rdg=c.n_rdg, depth_per_rdg=c.depth_per_rdg,
+                                                                 drop_path_rate=self.drop_path_rate))())
+        return (1.0 - torch.tensor(rates, dtype=torch.float32)).repeat_interleave(5)
+
+    def _forward_train(self, x: torch.Tensor) -> torch.Tensor:
+        dev = x.device
+        B, _, H, W = x.shape
+        self._sync_flat()
+        key = (B, H, W)
+        if key not in self._train_ws:
+            nbytes = C.c_size_t()
+            L.check(L.lib().srad_drct_train_workspace_bytes(self._handle, B, H, W, C.byref(nbytes)), "train_workspace_bytes")
+            self._train_ws = {key: torch.empty(nbytes.value + 256, dtype=torch.uint8, device=dev)}
+        wp, wb = self._aligned(self._train_ws[key])
+        keep = self.keep_scale_override
+        if keep is None and self.drop_path_rate > 0:
+            kp = self.drop_path_keep_probs().to(dev).repeat_interleave(2)[:, None]        # [2 * blocks, 1]
+            keep = torch.floor(kp + torch.rand(kp.shape[0], B, device=dev)) / kp         # drct.py:107-119
+        self._keep = None if keep is None else keep.to(device=dev, dtype=torch.float32).contiguous()
+        s = self.upscale
+        y = torch.empty(B, self.cfg.in_chans, H * s, W * s, dtype=torch.float32, device=dev)
+        L.check(L.lib().srad_drct_forward_train(self._handle, L.dptr(x), B, H, W, L.dptr(y), L.dptr(self._keep), wp, wb,
+                                                L.current_stream_ptr()), "drct_forward_train")
+        self._train_shape = key
+        return y
+
+    def _backward(self, dy: torch.Tensor, need_dx: bool) -> Optional[torch.Tensor]:
+        B, H, W = self._train_shape
+        if self._grad_views[0][0].grad is None:          # optimizer.zero_grad(set_to_none=True) dropped the views
+            self.zero_grad()
+        wp, wb = self._aligned(self._train_ws[(B, H, W)])
+        dx = torch.empty(B, self.cfg.in_chans, H, W, dtype=torch.float32, device=dy.device) if need_dx else None
+        cb = L.BUCKET_FN(lambda user, b: self.on_bucket(b)) if self.on_bucket is not None else L.BUCKET_FN(0)
+        L.check(L.lib().srad_drct_backward(self._handle, L.dptr(dy), B, H, W, L.dptr(self._keep), L.dptr(dx),
+                                           L.dptr(self.flat_grads), wp, wb, L.current_stream_ptr(), cb, None), "drct_backward")
+        return dx
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.training and torch.is_grad_enabled():
+            if not x.is_cuda:
+                raise RuntimeError("srad_amd runs on the GPU only (HIP engine); got a CPU tensor - there is no CPU fallback")
+            if x.dim() != 4 or x.shape[1] != self.cfg.in_chans:
+                raise ValueError(f"expected a [B, {self.cfg.in_chans}, H, W] tensor")
+            if x.shape[2] % self.window_size or x.shape[3] % self.window_size:
+                raise ValueError(f"input {x.shape[2]}x{x.shape[3]} must be a multiple of the window size {self.window_size}")
+            if getattr(self, "flat_params", None) is None:
+                self.enable_training()
+            return _DrctTrainFn.apply(x, self._anchor, self)
         x = self._check_input(x, self.cfg.in_chans)
         dev = x.device
         B, _, H, W = x.shape

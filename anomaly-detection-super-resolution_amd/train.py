@@ -1,0 +1,134 @@
+"""Training step around the HIP engine (reference src/trainer.py:49-83,152-222): fused Adam on the flat
+parameter buffer, the cosine schedule, the data-parallel gradient reducer, and ``train_step``.
+
+Data parallelism (BASELINE config C4): one process per GPU, every rank holds the full model and its own
+slice of the minibatch; the only exchange is the gradient all-reduce.  The engine's backward reports each
+gradient bucket (one per RDG, in completion order) as soon as its last kernel is enqueued; ``GradReducer``
+then all-reduces that contiguous slice of the flat gradient buffer on a second stream while the backward
+of the earlier layers is still running.  With the ``nccl`` backend that is RCCL over xGMI.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+class FusedAdam:
+    """torch.optim.Adam arithmetic (src/trainer.py:49-59: betas (0.9, 0.999), eps 1e-8, L2 weight decay)
+    as ONE kernel over the model's flat parameter buffer (C ABI ``srad_adam_step``)."""
+
+    def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        if getattr(model, "flat_params", None) is None:
+            model.enable_training()
+        self.model = model
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), tuple(betas), float(eps), float(weight_decay)
+        self.exp_avg = torch.zeros_like(model.flat_params)
+        self.exp_avg_sq = torch.zeros_like(model.flat_params)
+        self.step_count = 0
+        self.param_groups = [{"lr": self.lr}]          # what lr schedulers read / write
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        self.model.zero_grad()
+
+    def step(self, grad_scale: float = 1.0) -> None:
+        m = self.model
+        self.step_count += 1
+        lr = float(self.param_groups[0]["lr"])
+        L.check(L.lib().srad_adam_step(L.dptr(m.flat_params), L.dptr(m.flat_grads), L.dptr(self.exp_avg),
+                                       L.dptr(self.exp_avg_sq), m.flat_params.numel(), lr, self.betas[0], self.betas[1],
+                                       self.eps, self.weight_decay, self.step_count, grad_scale,
+                                       L.current_stream_ptr()), "adam_step")
+        m.mark_params_dirty()
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "lr": self.param_groups[0]["lr"]}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.param_groups[0]["lr"] = float(sd["lr"])
+
+
+def cosine_lr(base_lr: float, epoch: int, t_max: float, eta_min: float) -> float:
+    """CosineAnnealingLR closed form (src/trainer.py:76-83: T_max = epochs, stepped once per epoch)."""
+    return eta_min + (base_lr - eta_min) * (1.0 + math.cos(math.pi * epoch / t_max)) / 2.0
+
+
+def bucket_slices(buckets, world_size: int):
+    """[(offset, length)] of the flat gradient buffer per bucket - host logic shared with the CPU tests."""
+    return [(int(a), int(n)) for a, n in buckets if n > 0]
+
+
+class GradReducer:
+    """Bucketed gradient all-reduce overlapped with the backward.  ``attach(model)`` installs the engine's
+    bucket hook; ``finish()`` (after backward) makes the compute stream wait for the reductions.  Gradients
+    are SUMMED; the 1/world_size goes into the optimizer's ``grad_scale``."""
+
+    def __init__(self, process_group=None, overlap: bool = True):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.overlap = overlap
+        self.comm_stream = None
+        self.model = None
+        self._pending = []
+
+    def attach(self, model) -> "GradReducer":
+        self.model = model
+        if self.world > 1:
+            model.on_bucket = self._on_bucket
+        return self
+
+    def _on_bucket(self, b: int) -> None:
+        off, n = self.model.grad_buckets[b]
+        if n <= 0:
+            return
+        g = self.model.flat_grads[off:off + n]
+        if g.is_cuda and self.overlap:
+            if self.comm_stream is None:
+                self.comm_stream = torch.cuda.Stream(device=g.device)
+            self.comm_stream.wait_stream(torch.cuda.current_stream())     # bucket b is final on the compute stream
+            with torch.cuda.stream(self.comm_stream):
+                self.dist.all_reduce(g, group=self.group)
+        else:
+            self.dist.all_reduce(g, group=self.group)
+
+    def reduce_all(self, flat_grads: torch.Tensor, buckets) -> None:
+        """Non-overlapped form (also what the gloo CPU test drives): reduce every bucket in order."""
+        if self.world == 1:
+            return
+        for off, n in bucket_slices(buckets, self.world):
+            self.dist.all_reduce(flat_grads[off:off + n], group=self.group)
+
+    def finish(self) -> None:
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+
+def train_step(model, lr_img: torch.Tensor, hr_img: torch.Tensor, optimizer: FusedAdam,
+               reducer: Optional[GradReducer] = None) -> torch.Tensor:
+    """One iteration of Trainer.train for DRCT (src/trainer.py:161-205): zero_grad, forward, L1 loss,
+    backward, (all-reduce,) Adam.  Returns the loss as a 0-d device tensor (no host sync)."""
+    from . import metrics as M
+    optimizer.zero_grad()
+    sr = model._forward_train(lr_img)
+    loss = M.l1_loss(sr, hr_img)
+    dy = torch.empty_like(sr)
+    L.check(L.lib().srad_l1_grad(L.dptr(sr), L.dptr(hr_img), L.dptr(dy), sr.numel(), 1.0 / sr.numel(),
+                                 L.current_stream_ptr()), "l1_grad")
+    model._backward(dy, need_dx=False)
+    if reducer is not None:
+        reducer.finish()
+    optimizer.step(grad_scale=reducer.grad_scale if reducer is not None else 1.0)
+    return loss

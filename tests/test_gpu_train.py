@@ -1,0 +1,175 @@
+"""GPU: the DRCT training step through the C ABI.
+ * gradients under nn.L1Loss against the fixtures the reference's autograd produced (G7) - every parameter's
+   L2 norm plus eight full tensors and dLoss/dx;
+ * training-mode forward/backward with explicit DropPath masks against autograd of the oracle;
+ * fused Adam step == torch.optim.Adam on the same gradients; loss goes down over a few steps;
+ * bf16 mode gradients close to the fp32 ones.
+Bars: fp32 mode 1e-3 relative (north_star), per-tensor max error relative to that tensor's max."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import drct_case, rel_err
+from tests.test_gpu_drct import Opt
+
+pytestmark = pytest.mark.gpu
+
+
+def build_train(cfg, sd, precision, drop_path_rate=0.0):
+    from srad_amd.nets import DRCT
+    o = Opt(cfg, precision, use_graph=False)
+    o.drop_path_rate = drop_path_rate
+    m = DRCT(o).cuda()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m.train()
+    m.enable_training()
+    return m
+
+
+def test_gradients_match_reference_autograd_golden(sr_golden):
+    g = sr_golden
+    name = "drct_r2_rgb_x4"
+    cfg, sd, x, y = drct_case(g, name)
+    m = build_train(cfg, sd, "fp32")
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    hr = torch.from_numpy(g[name + "/hr"]).cuda()
+    out = m(xt)
+    assert rel_err(out.detach().cpu().numpy(), y) < 2e-4              # training forward == eval forward (no DropPath)
+    loss = F.l1_loss(out, hr)
+    assert abs(float(loss.detach()) - float(g[name + "/loss"])) < 1e-5 * abs(float(g[name + "/loss"]))
+    loss.backward()
+    assert rel_err(xt.grad.cpu().numpy(), g[name + "/grad_x"]) < 1e-3
+    grads = dict(m.named_parameters())
+    for k in [k for k in g.files if k.startswith(name + "/grad/")]:
+        pname = k[len(name + "/grad/"):]
+        e = rel_err(grads[pname].grad.cpu().numpy(), g[k])
+        assert e < 1e-3, (pname, e)
+    names = [str(n) for n in g[name + "/grad_names"]]
+    l2 = g[name + "/grad_l2"]
+    worst = 0.0
+    for n, ref in zip(names, l2):
+        mine = float(grads[n].grad.double().pow(2).sum().sqrt())
+        worst = max(worst, abs(mine - ref) / max(ref, 1e-12))
+        assert abs(mine - ref) <= 1e-3 * max(ref, 1e-9), (n, mine, ref)
+    print("worst relative L2-norm error over", len(names), "parameter tensors:", worst)
+
+
+@pytest.mark.parametrize("gray", [True, False])
+def test_training_forward_backward_with_droppath_matches_oracle(gray):
+    from oracle import sr_ref as R
+    from srad_amd import spec as S
+    cfg = S.DRCTConfig(in_chans=1 if gray else 3, img_size=16, window_size=8, upscale=2 if gray else 4, n_rdg=2)
+    sd = S.synth_state(S.drct_spec(cfg), seed=77, gain=1.0, cfg=cfg)
+    B, H, W = 3, 16, 24
+    x = S.synth_image("tr", (B, cfg.in_chans, H, W), seed=5)
+    hr = S.synth_image("tr/hr", (B, cfg.in_chans, H * cfg.upscale, W * cfg.upscale), seed=6)
+    gen = torch.Generator().manual_seed(1)
+    keep = torch.floor(0.7 + torch.rand(2 * cfg.n_rdg * 5, B, generator=gen)) / 0.7        # independent per branch
+    # oracle (torch CPU autograd)
+    sdt = {k: torch.from_numpy(np.asarray(v)).clone().requires_grad_(np.asarray(v).dtype == np.float32) for k, v in sd.items()}
+    keeps = [[(keep[2 * (i * 5 + k)], keep[2 * (i * 5 + k) + 1]) for k in range(5)] for i in range(cfg.n_rdg)]
+    xr = torch.from_numpy(x).requires_grad_(True)
+    ref = R.drct_forward(sdt, xr, cfg, keeps=keeps)
+    F.l1_loss(ref, torch.from_numpy(hr)).backward()
+    # engine
+    m = build_train(cfg, sd, "fp32", drop_path_rate=0.1)
+    m.keep_scale_override = keep.cuda()
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    out = m(xt)
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < 2e-4
+    F.l1_loss(out, torch.from_numpy(hr).cuda()).backward()
+    assert rel_err(xt.grad.cpu().numpy(), xr.grad.numpy()) < 1e-3
+    worst = ("", 0.0)
+    for n, p in m.named_parameters():
+        e = rel_err(p.grad.cpu().numpy(), sdt[n].grad.numpy())
+        if e > worst[1]:
+            worst = (n, e)
+        assert e < 1e-3, (n, e)
+    print("worst parameter-gradient error:", worst)
+    # a second backward accumulates (PyTorch semantics), zero_grad clears
+    g1 = m.flat_grads.clone()
+    out = m(xt)
+    F.l1_loss(out, torch.from_numpy(hr).cuda()).backward()
+    assert float((m.flat_grads - 2 * g1).abs().max()) <= 1e-4 * float(g1.abs().max())
+    m.zero_grad()
+    assert float(m.flat_grads.abs().max()) == 0.0
+
+
+def test_random_droppath_masks_have_reference_statistics():
+    from srad_amd import spec as S
+    cfg = S.DRCTConfig(in_chans=1, img_size=16, window_size=8, upscale=2, n_rdg=3)
+    sd = S.synth_state(S.drct_spec(cfg), seed=3, gain=1.0, cfg=cfg)
+    m = build_train(cfg, sd, "fp32", drop_path_rate=0.5)
+    kp = m.drop_path_keep_probs()
+    assert kp.shape == (15,) and float(kp[0]) == 1.0 and abs(float(kp[-1]) - (1 - 0.5 * 12 / 17)) < 1e-6
+    x = torch.rand(64, 1, 8, 8, device="cuda") * 255
+    with torch.enable_grad():
+        m(x)
+    k = m._keep.cpu()
+    assert k.shape == (30, 64)
+    assert torch.all(k[:10] == 1.0)                                 # RDG 0: rate 0 -> Identity
+    vals = k[-1].unique()
+    assert all(abs(float(v)) < 1e-6 or abs(float(v) - 1 / float(kp[-1])) < 1e-5 for v in vals)
+    assert 0.3 < float((k[-10:] > 0).float().mean()) < 0.95          # keep_prob ~ 0.65
+
+
+def test_fused_adam_training_reduces_loss_and_matches_torch_adam(sr_golden):
+    from srad_amd.train import FusedAdam, train_step
+    name = "drct_r2_rgb_x4"
+    cfg, sd, x, y = drct_case(sr_golden, name)
+    hr = torch.from_numpy(sr_golden[name + "/hr"]).cuda()
+    xt = torch.from_numpy(x).cuda()
+    m = build_train(cfg, sd, "fp32")
+    opt = FusedAdam(m, lr=1e-4)
+    # reference arithmetic: torch.optim.Adam over the same (view) parameters, driven by the same gradients
+    m2 = build_train(cfg, sd, "fp32")
+    opt2 = torch.optim.Adam(m2.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0)
+    losses = []
+    for it in range(4):
+        losses.append(float(train_step(m, xt, hr, opt)))
+        # Adam normalises every gradient to +-lr, so noise-level differences in near-zero gradients (atomics
+        # ordering) would flip whole steps: both optimizers see the SAME gradient buffer.
+        m2.zero_grad()
+        m2.flat_grads.copy_(m.flat_grads)
+        opt2.step()
+        diff = float((m.flat_params - m2.flat_params).abs().max())
+        assert diff < 5e-6, (it, diff)
+    print("losses", losses)
+    assert losses[-1] < losses[0]
+    # the updated weights are what the eval path uses
+    m.eval()
+    with torch.no_grad():
+        e1 = m(xt)
+    m2.eval()
+    with torch.no_grad():
+        e2 = m2(xt)
+    assert rel_err(e1.cpu().numpy(), e2.cpu().numpy()) < 1e-4
+
+
+def test_bf16_training_gradients_close_to_fp32(sr_golden):
+    name = "drct_r2_rgb_x4"
+    cfg, sd, x, y = drct_case(sr_golden, name)
+    hr = torch.from_numpy(sr_golden[name + "/hr"]).cuda()
+    xt = torch.from_numpy(x).cuda()
+    gs = {}
+    for prec in ("fp32", "bf16"):
+        m = build_train(cfg, sd, prec)
+        F.l1_loss(m(xt), hr).backward()
+        gs[prec] = m.flat_grads.clone()
+    a, b = gs["fp32"].double(), gs["bf16"].double()
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    print("cosine(fp32 grad, bf16 grad) =", cos, " norm ratio", float(b.norm() / a.norm()))
+    assert cos > 0.99 and 0.9 < float(b.norm() / a.norm()) < 1.1
+
+
+def test_training_errors_are_reported():
+    from srad_amd import spec as S
+    from srad_amd.nets import DRCT
+    cfg = S.DRCTConfig(in_chans=1, img_size=16, window_size=4, upscale=2, n_rdg=1)
+    o = Opt(cfg, "fp32")
+    m = DRCT(o).cuda().train()
+    with pytest.raises(RuntimeError, match="window size 8"):
+        m(torch.zeros(1, 1, 8, 8, device="cuda"))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        DRCT(o).train()(torch.zeros(1, 1, 8, 8))
