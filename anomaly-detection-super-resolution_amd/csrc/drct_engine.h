@@ -28,6 +28,7 @@ struct srad_drct {
   std::vector<int64_t> flat_off;  // per table entry: offset (floats) in the flat fp32 parameter / gradient buffers
   int64_t flat_total = 0;
   std::vector<size_t> t_off;      // per table entry: byte offset of the transposed pack in the training arena
+  size_t t_wgrad_off = 0;         // byte offset of the weight-gradient split-K workspace
   size_t t_desc_off = 0;          // byte offset of the device descriptor table inside the training arena
   size_t t_bytes = 0;
   int n_sync_blocks = 0;

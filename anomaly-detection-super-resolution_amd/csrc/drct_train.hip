@@ -201,6 +201,8 @@ int srad_drct_train_arena_bytes(srad_drct_t* h, size_t* bytes) {
     }
     h->t_desc_off = off;
     off += srad_align_up(h->pt.entries.size() * sizeof(SyncDesc), 256);
+    h->t_wgrad_off = off;                       // split-K workspace of the weight-gradient kernel
+    off += srad_align_up(SRAD_WGRAD_WS_BYTES, 256);
     h->t_bytes = off;
   }
   *bytes = h->t_bytes;
@@ -411,6 +413,9 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
   const int stages = (int)h->up.size();
   int hh = H << stages, ww = W << stages;
   float* G = flat_grad;
+  WgradQueue wq;                          // split-K partials of the weight gradients, reduced once per Swin block
+  wq.ws = reinterpret_cast<float*>(h->tarena + h->t_wgrad_off);
+  wq.ws_floats = SRAD_WGRAD_WS_BYTES / sizeof(float);
 
   // dLoss/d(outn) = dy / img_range, NCHW -> NHWC (pad channels zero)           (drct.py:897)
   SRAD_TRY(srad_launch_nchw_to_nhwc(dy, w.dimg, B, c.in_chans, SRAD_IMG_CPAD, hh, ww, zero3, 1.0f / c.img_range, s));
@@ -419,7 +424,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
     float* dsrc = stages ? w.dup[stages - 1] : w.dc2;
     WgradParams g = wgrad_of(h, h->conv_last, G, w.dimg, SRAD_IMG_CPAD, 0, src, F, B * hh * ww);
     geom(g, hh, ww);
-    SRAD_TRY(srad_launch_wgrad(prec, g, s));
+    SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
     GemmParams p = dgrad_gemm(h, h->conv_last, w.dimg, SRAD_IMG_CPAD, B * hh * ww, dsrc, F);
     geom(p, hh, ww);
     SRAD_TRY(srad_launch_gemm(prec, p, s));
@@ -431,7 +436,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
     SRAD_TRY(srad_launch_unshuffle(w.dup[j], w.dus, B, hh, ww, F, s));
     WgradParams g = wgrad_of(h, h->up[j], G, w.dus, 4 * F, 0, src, F, B * hh * ww);
     geom(g, hh, ww);
-    SRAD_TRY(srad_launch_wgrad(prec, g, s));
+    SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
     GemmParams p = dgrad_gemm(h, h->up[j], w.dus, 4 * F, B * hh * ww, dsrc, F);
     geom(p, hh, ww);
     SRAD_TRY(srad_launch_gemm(prec, p, s));
@@ -440,7 +445,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
     SRAD_TRY(srad_launch_dact(w.dc2, F, w.c2, F, w.dc2, F, T, F, 0.01f, s));
     WgradParams g = wgrad_of(h, h->conv_before_up, G, w.dc2, F, 0, w.c1, E, T);
     geom(g, H, W);
-    SRAD_TRY(srad_launch_wgrad(prec, g, s));
+    SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
     GemmParams p = dgrad_gemm(h, h->conv_before_up, w.dc2, F, T, w.dc1, E);
     geom(p, H, W);
     SRAD_TRY(srad_launch_gemm(prec, p, s));
@@ -448,7 +453,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
   {  // conv_after_body(...) + x                                                 (drct.py:893)
     WgradParams g = wgrad_of(h, h->conv_after_body, G, w.dc1, E, 0, w.body, E, T);
     geom(g, H, W);
-    SRAD_TRY(srad_launch_wgrad(prec, g, s));
+    SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
     GemmParams p = dgrad_gemm(h, h->conv_after_body, w.dc1, E, T, w.dbody, E);
     geom(p, H, W);
     SRAD_TRY(srad_launch_gemm(prec, p, s));
@@ -460,8 +465,9 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
     l.dxn = w.dbody; l.ld_dxn = E; l.x = w.dense[c.n_rdg]; l.ldx = D; l.gamma = h->pt.fptr(h->norm_g);
     l.out = gn; l.ld_out = D; l.dgamma = G + h->flat_off[h->norm_g]; l.dbeta = G + h->flat_off[h->norm_b];
     l.rows = T; l.C = E; l.eps = 1e-5f;
-    SRAD_TRY(srad_launch_ln_bwd(l, s));
+    SRAD_TRY(srad_launch_ln_bwd(l, wq, s));
   }
+  SRAD_TRY(srad_wgrad_flush(wq, s));
   if (on_bucket) on_bucket(user, 0);
 
   for (int i = c.n_rdg - 1; i >= 0; --i) {
@@ -486,7 +492,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       {
         WgradParams g = wgrad_of(h, sw.adjust, G, dA, ldA, 0, sv.x2, d, T);
         g.alpha = aalpha;
-        SRAD_TRY(srad_launch_wgrad(prec, g, s));
+        SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
         GemmParams p = dgrad_gemm(h, sw.adjust, dA, ldA, T, w.dx2, d);
         p.alpha = aalpha;
         SRAD_TRY(srad_launch_gemm(prec, p, s));
@@ -496,14 +502,14 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       {
         WgradParams g = wgrad_of(h, sw.fc2, G, w.dx2, d, 0, sv.hact, sw.hidden, T);
         g.row_scale = ks2; g.rps = HW;
-        SRAD_TRY(srad_launch_wgrad(prec, g, s));
+        SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
         GemmParams p = dgrad_gemm(h, sw.fc2, w.dx2, d, T, w.dh, sw.hidden);
         p.row_scale = ks2; p.rps = HW; p.R = sv.hpre; p.ldr = sw.hidden; p.rmode = SRAD_RMODE_DGELU;
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
       {
         WgradParams g = wgrad_of(h, sw.fc1, G, w.dh, sw.hidden, 0, sv.xn2, d, T);
-        SRAD_TRY(srad_launch_wgrad(prec, g, s));
+        SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
         GemmParams p = dgrad_gemm(h, sw.fc1, w.dh, sw.hidden, T, w.dxn, d);
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
@@ -513,13 +519,13 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
         l.dres = w.dx2; l.ld_dres = d; l.out = w.dx1; l.ld_out = d;
         l.dgamma = G + h->flat_off[sw.n2g]; l.dbeta = G + h->flat_off[sw.n2b];
         l.rows = T; l.C = d; l.eps = 1e-5f;
-        SRAD_TRY(srad_launch_ln_bwd(l, s));
+        SRAD_TRY(srad_launch_ln_bwd(l, wq, s));
       }
       // ---- attention branch: x1 = x + rs1 * proj(attn(LN1(x)))                  (drct.py:477-509)
       {
         WgradParams g = wgrad_of(h, sw.proj, G, w.dx1, d, 0, sv.attn, d, T);
         g.row_scale = ks1; g.rps = HW;
-        SRAD_TRY(srad_launch_wgrad(prec, g, s));
+        SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
         GemmParams p = dgrad_gemm(h, sw.proj, w.dx1, d, T, w.dO, d);
         p.row_scale = ks1; p.rps = HW;
         SRAD_TRY(srad_launch_gemm(prec, p, s));
@@ -531,7 +537,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       }
       {
         WgradParams g = wgrad_of(h, sw.qkv, G, w.dqkv, 3 * d, 0, sv.xn1, d, T);
-        SRAD_TRY(srad_launch_wgrad(prec, g, s));
+        SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
         GemmParams p = dgrad_gemm(h, sw.qkv, w.dqkv, 3 * d, T, w.dxn, d);
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
@@ -541,8 +547,9 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
         l.dres = w.dx1; l.ld_dres = d; l.out = gc; l.ld_out = D; l.accumulate = 1;
         l.dgamma = G + h->flat_off[sw.n1g]; l.dbeta = G + h->flat_off[sw.n1b];
         l.rows = T; l.C = d; l.eps = 1e-5f;
-        SRAD_TRY(srad_launch_ln_bwd(l, s));
+        SRAD_TRY(srad_launch_ln_bwd(l, wq, s));
       }
+      SRAD_TRY(srad_wgrad_flush(wq, s));              // this block's five weight gradients, one launch
     }
     float* t = gn; gn = gc; gc = t;
     if (on_bucket) on_bucket(user, c.n_rdg - i);
@@ -553,12 +560,12 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
     l.dres = w.dc1; l.ld_dres = E; l.out = w.dfeat; l.ld_out = E;
     l.dgamma = G + h->flat_off[h->pe_g]; l.dbeta = G + h->flat_off[h->pe_b];
     l.rows = T; l.C = E; l.eps = 1e-5f;
-    SRAD_TRY(srad_launch_ln_bwd(l, s));
+    SRAD_TRY(srad_launch_ln_bwd(l, wq, s));
   }
   {  // conv_first                                                                 (drct.py:892)
     WgradParams g = wgrad_of(h, h->conv_first, G, w.dfeat, E, 0, w.xin, SRAD_IMG_CPAD, T);
     geom(g, H, W);
-    SRAD_TRY(srad_launch_wgrad(prec, g, s));
+    SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
     if (dx) {
       GemmParams p = dgrad_gemm(h, h->conv_first, w.dfeat, E, T, w.dxin, SRAD_IMG_CPAD);
       geom(p, H, W);
@@ -566,6 +573,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       SRAD_TRY(srad_launch_nhwc_to_nchw(w.dxin, SRAD_IMG_CPAD, dx, B, c.in_chans, H, W, zero3, c.img_range, s));
     }
   }
+  SRAD_TRY(srad_wgrad_flush(wq, s));
   if (on_bucket) on_bucket(user, c.n_rdg + 1);
   return SRAD_OK;
 }

@@ -6,12 +6,6 @@
 #include <string>
 #include <vector>
 
-#define SRAD_TRY(expr)            \
-  do {                            \
-    int _rc = (expr);             \
-    if (_rc) return _rc;          \
-  } while (0)
-
 struct ParamEntry {
   std::string name;
   int64_t numel;     // elements of the fp32 source tensor

@@ -10,6 +10,8 @@
 // Data gradients (dX = dY W) are not here: they are the forward GEMM of kernels_gemm.hip run on the
 // transposed packed weight (srad_launch_pack_weight_transposed).
 #include "srad_common.h"
+#include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -28,19 +30,29 @@ static inline int grid_for(size_t total) {
 //   fp32: v_mfma_f32_16x16x4_f32, k = 4 rows per step (row m0 + fq)
 //   bf16: v_mfma_f32_16x16x32_bf16, k = 32 rows per step (rows m0 + 8 fq + t, t = 0..7)
 // One workgroup = 4 waves on one 64 x 64 (n, c) tile of one tap, each wave on its own rows of the
-// workgroup's row range (split-K); waves are summed through LDS, workgroups through atomicAdd.
+// workgroup's row range (split-K); waves are summed through LDS.
+// Split-K partials go to a workspace with plain stores and are summed (fixed order: bit-reproducible
+// gradients) by wgrad_reduce_kernel, ONE launch for a batch of up to 8 layers.  Two things that were tried
+// and measured on MI355X before this: float atomicAdd into dW (device-scope atomics on a few hundred
+// addresses serialise: 60-170 us per layer) and a last-arriver reduction inside the kernel (the agent-scope
+// release/acquire fences it needs write back / invalidate a whole XCD L2 because the eight L2s are not
+// coherent with each other: 60-90 us per layer).  A kernel boundary is the cheap cross-XCD barrier.
 // ------------------------------------------------------------------------------------------
+constexpr int WG_TS = 64 * 64 + 64;          // floats per partial: the tile and its 64 bias sums
+constexpr int LNB_RPW = 32;                  // LayerNorm backward: rows per workgroup
+constexpr int LNB_J = 5;                     // 64 * 5 = 320 channels at most
+constexpr int LNB_CP = 64 * LNB_J;
+
 template <int PREC, bool CONV>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const int ksplit) {
-  __shared__ float tile[64 * 65];
-  __shared__ float dbs[64];
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const int ksplit, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];     // [4 waves][64][68] + [4][64] bias + flag
+  constexpr int TST = 68;
+  float* const dbs = wsm + 4 * 64 * TST;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int tap = blockIdx.z / ksplit, ks = blockIdx.z - tap * ksplit;
-  for (int i = tid; i < 64 * 65; i += 256) tile[i] = 0.f;
-  if (tid < 64) dbs[tid] = 0.f;
-  __syncthreads();
+  const int tile_id = (tap * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
 
   constexpr int KR = PREC == SRAD_PREC_BF16 ? 32 : 4;        // rows per wave step
   constexpr int RL = PREC == SRAD_PREC_BF16 ? 8 : 1;         // rows per lane per step
@@ -64,42 +76,60 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const i
   f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int m0 = mb + wave * KR; m0 < me; m0 += 4 * KR) {
-    f32x4 av[RL], bv[RL];
-    bool a_ok[RL], b_ok[RL];
-    float rs[RL];
-    // every load is unconditional on a clamped address; masking happens on the registers afterwards
+  // every load is unconditional on a clamped address; masking happens on the registers afterwards.
+  // The next step's loads are issued before this step's MFMAs (two register sets).
+  f32x4 av[2][RL], bv[2][RL];
+  unsigned okm[2];                    // bit t: a row valid, bit 8 + t: b row valid
+  float rs[2][RL];
+  auto load_step = [&](int m0, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
+    unsigned ok = 0u;
+    [[maybe_unused]] int bb = 0, oy = 0, ox = 0;
+    if constexpr (CONV) {                 // pixel of the lane's first row; the following rows step from it
+      const int mf = min(m0 + RL * fq, p.M - 1);
+      bb = mf / hwo;
+      const int rem = mf - bb * hwo;
+      oy = rem / p.Wo;
+      ox = rem - oy * p.Wo;
+    }
 #pragma unroll
     for (int t = 0; t < RL; ++t) {
       const int m = m0 + RL * fq + t;
       const int mc = min(m, p.M - 1);
-      a_ok[t] = m < me && n_ok;
-      av[t] = *reinterpret_cast<const f32x4*>(p.dY + (size_t)mc * p.ldy + noff);
+      av[set][t] = *reinterpret_cast<const f32x4*>(p.dY + (size_t)mc * p.ldy + noff);
       size_t xr = (size_t)mc;
       bool in = true;
       if constexpr (CONV) {
-        const int bb = mc / hwo, rem = mc - bb * hwo;
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        if (t > 0 && m < p.M) {           // next pixel in raster order
+          ++ox;
+          if (ox == p.Wo) { ox = 0; ++oy; if (oy == p.Ho) { oy = 0; ++bb; } }
+        }
         const int iy = oy * p.stride - pad + ky, ix = ox * p.stride - pad + kx;
         in = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
         xr = (size_t)((bb * p.Hi + min(max(iy, 0), p.Hi - 1)) * p.Wi + min(max(ix, 0), p.Wi - 1));
       }
-      b_ok[t] = m < me && c_ok && in;
-      bv[t] = *reinterpret_cast<const f32x4*>(p.X + xr * p.ldx + coff);
-      rs[t] = p.row_scale ? p.row_scale[mc / p.rps] : 1.f;
+      bv[set][t] = *reinterpret_cast<const f32x4*>(p.X + xr * p.ldx + coff);
+      rs[set][t] = p.row_scale ? p.row_scale[mc / p.rps] : 1.f;
+      ok |= ((m < me && n_ok) ? 1u : 0u) << t;
+      ok |= ((m < me && c_ok && in) ? 1u : 0u) << (8 + t);
     }
+    okm[set] = ok;
+  };
+  auto compute_step = [&](auto set_c) {
+    constexpr int set = decltype(set_c)::value;
+    f32x4 a[RL], b[RL];
 #pragma unroll
     for (int t = 0; t < RL; ++t) {
-      av[t] = a_ok[t] ? av[t] * rs[t] : zero4;
-      bv[t] = b_ok[t] ? bv[t] : zero4;
-      bsum += av[t];
+      a[t] = ((okm[set] >> t) & 1u) ? av[set][t] * rs[set][t] : zero4;
+      b[t] = ((okm[set] >> (8 + t)) & 1u) ? bv[set][t] : zero4;
+      bsum += a[t];
     }
     if constexpr (PREC == SRAD_PREC_BF16) {
       bf16x8 ah[4], bh[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { ah[e][t] = (__bf16)av[t][e]; bh[e][t] = (__bf16)bv[t][e]; }
+        for (int t = 0; t < 8; ++t) { ah[e][t] = (__bf16)a[t][e]; bh[e][t] = (__bf16)b[t][e]; }
 #pragma unroll
       for (int en = 0; en < 4; ++en)
 #pragma unroll
@@ -110,64 +140,201 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const i
       for (int en = 0; en < 4; ++en)
 #pragma unroll
         for (int ec = 0; ec < 4; ++ec)
-          acc[en][ec] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][en], bv[0][ec], acc[en][ec], 0, 0, 0);
+          acc[en][ec] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][en], b[0][ec], acc[en][ec], 0, 0, 0);
+    }
+  };
+
+  {
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    constexpr int ST = 4 * KR;
+    int m0 = mb + wave * KR;
+    if (m0 < me) load_step(m0, S0{});
+    while (m0 < me) {
+      if (m0 + ST < me) load_step(m0 + ST, S1{});
+      compute_step(S0{});
+      m0 += ST;
+      if (m0 >= me) break;
+      if (m0 + ST < me) load_step(m0 + ST, S0{});
+      compute_step(S1{});
+      m0 += ST;
     }
   }
 
-  // ---- sum the four waves in LDS: lane (fq, fr) element e of acc[en][ec] is (n = 16 fq + 4 e + en, c = 4 fr + ec) ----
+  // ---- the four waves' partial tiles through LDS (plain 16-byte stores): lane (fq, fr) element e of
+  //      acc[en][ec] is (n = 16 fq + 4 e + en, c = 4 fr + ec) ----
+  {
+    float* const mine = wsm + wave * 64 * TST;
 #pragma unroll
-  for (int en = 0; en < 4; ++en)
+    for (int en = 0; en < 4; ++en)
 #pragma unroll
-    for (int ec = 0; ec < 4; ++ec)
+      for (int e = 0; e < 4; ++e)
+        *reinterpret_cast<f32x4*>(mine + (16 * fq + 4 * e + en) * TST + 4 * fr) =
+            f32x4{acc[en][0][e], acc[en][1][e], acc[en][2][e], acc[en][3][e]};
+    // bias partial: sum over the four row groups fq, then lanes fq == 0 hold n = 4 fr + e
 #pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(&tile[(16 * fq + 4 * e + en) * 65 + 4 * fr + ec], acc[en][ec][e]);
-  const bool do_bias = p.db != nullptr && blockIdx.y == 0 && tap == 0;
-  if (do_bias) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(&dbs[4 * fr + e], bsum[e]);
+    for (int e = 0; e < 4; ++e) { bsum[e] += __shfl_xor(bsum[e], 16); bsum[e] += __shfl_xor(bsum[e], 32); }
+    if (fq == 0) *reinterpret_cast<f32x4*>(dbs + wave * 64 + 4 * fr) = bsum;
   }
   __syncthreads();
-  for (int idx = tid; idx < 64 * 64; idx += 256) {
-    const int nl = idx >> 6, cl = idx & 63;
-    const int n = n0 + nl, c = c0 + cl;
-    if (n < p.n_real && c < p.cin_real)
-      atomicAdd(p.dW + ((size_t)n * p.cin_real + c) * p.ntaps + tap, tile[nl * 65 + cl] * p.alpha);
+  const bool do_bias = p.db != nullptr && blockIdx.y == 0 && tap == 0;
+  // thread t owns the float4s e4 = t + 256 j of the tile (n = e4 / 16, c = 4 (e4 % 16))
+  f32x4 v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e4 = tid + 256 * j, nl = e4 >> 4, cl = (e4 & 15) * 4;
+    const float* q = wsm + nl * TST + cl;
+    v[j] = (*reinterpret_cast<const f32x4*>(q) + *reinterpret_cast<const f32x4*>(q + 64 * TST)) +
+           (*reinterpret_cast<const f32x4*>(q + 2 * 64 * TST) + *reinterpret_cast<const f32x4*>(q + 3 * 64 * TST));
   }
-  if (do_bias && tid < 64 && n0 + tid < p.n_real) atomicAdd(p.db + n0 + tid, dbs[tid] * p.alpha);
+  float vb = 0.f;
+  if (tid < 64) vb = (dbs[tid] + dbs[64 + tid]) + (dbs[128 + tid] + dbs[192 + tid]);
+
+  if (ksplit > 1) {                      // partial tile for wgrad_reduce_kernel
+    float* const mypart = part + ((size_t)tile_id * ksplit + ks) * WG_TS;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(mypart + 4 * (tid + 256 * j)) = v[j];
+    if (tid < 64) mypart[4096 + tid] = vb;
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e4 = tid + 256 * j, nl = e4 >> 4, cl = (e4 & 15) * 4;
+    const int n = n0 + nl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = c0 + cl + e;
+      if (n < p.n_real && c < p.cin_real) {
+        float* dst = p.dW + ((size_t)n * p.cin_real + c) * p.ntaps + tap;
+        *dst += v[j][e] * p.alpha;
+      }
+    }
+  }
+  if (do_bias && tid < 64 && n0 + tid < p.n_real) p.db[n0 + tid] += vb * p.alpha;
+}
+
+// One workgroup per QUARTER of a 64 x 64 output tile of one of the batch's layers (16 rows n, one float4 per
+// thread): dW += alpha * sum_k partial[k], k in fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceBatch b) {
+  const int gt = blockIdx.x >> 2, quarter = blockIdx.x & 3;
+  int it = 0;
+#pragma unroll
+  for (int i = 1; i < SRAD_WGRAD_BATCH; ++i)
+    if (i < b.count && gt >= b.it[i].tile0) it = i;
+  const WgradReduceItem& d = b.it[it];
+  const int tile_id = gt - d.tile0;
+  if (d.ntaps == 0) {
+    // LayerNorm dgamma | dbeta: partial rows [ksplit][2 * LNB_CP] written by ln_bwd_kernel, 16 columns per workgroup
+    __shared__ float red[16][17];
+    const int r = threadIdx.x >> 4, cl = threadIdx.x & 15;
+    const int col = (tile_id * 4 + quarter) * 16 + cl;                 // 0 .. 2 * LNB_CP
+    float sum = 0.f;
+    for (int k = r; k < d.ksplit; k += 16) sum += d.part[(size_t)k * (2 * LNB_CP) + col];
+    red[r][cl] = sum;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t += red[i][cl];
+      const int c = col < LNB_CP ? col : col - LNB_CP;
+      float* dst = col < LNB_CP ? d.dW : d.db;
+      if (c < d.n_real && dst) dst[c] += t;
+    }
+    return;
+  }
+  const int nx = tile_id % d.tn, cy = (tile_id / d.tn) % d.tc, tap = tile_id / (d.tn * d.tc);
+  const int tid = threadIdx.x;
+  const int e4 = quarter * 256 + tid;
+  const float* const base = d.part + (size_t)tile_id * d.ksplit * WG_TS + 4 * e4;
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 8 <= d.ksplit; k += 8) {                          // 8 loads in flight
+    f32x4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4*>(base + (size_t)(k + u) * WG_TS);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += t[u];
+  }
+  for (; k < d.ksplit; ++k) v += *reinterpret_cast<const f32x4*>(base + (size_t)k * WG_TS);
+  const int n0 = nx * 64, c0 = cy * 64;
+  const int n = n0 + (e4 >> 4), cl = (e4 & 15) * 4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = c0 + cl + e;
+    if (n < d.n_real && c < d.cin_real) {
+      float* dst = d.dW + ((size_t)n * d.cin_real + c) * d.ntaps + tap;
+      *dst += v[e] * d.alpha;
+    }
+  }
+  if (d.db != nullptr && cy == 0 && tap == 0 && tid < 16 && n0 + quarter * 16 + tid < d.n_real) {
+    const float* bb = d.part + (size_t)tile_id * d.ksplit * WG_TS + 4096 + quarter * 16 + tid;
+    float vb = 0.f;
+    for (int kk = 0; kk < d.ksplit; ++kk) vb += bb[(size_t)kk * WG_TS];
+    d.db[n0 + quarter * 16 + tid] += vb * d.alpha;
+  }
 }
 
 template <int PREC>
-int launch_wgrad(const WgradParams& p, hipStream_t s) {
+int launch_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s) {
   const bool conv = p.ntaps == 9 || p.stride != 1;
   const int tn = (p.N + 63) / 64, tc = (p.Cin + 63) / 64;
   const long tiles = (long)tn * tc * p.ntaps;
   constexpr int KR = PREC == SRAD_PREC_BF16 ? 32 : 4;
-  // enough workgroups to cover the chip a few times, but at least two steps of rows per wave
-  long ksplit = (1536 + tiles - 1) / tiles;
+  // about two workgroups per CU, at least two row steps per wave
+  long ksplit = (512 + tiles - 1) / tiles;
   const long kmax = (p.M + 8 * KR - 1) / (8 * KR);
   if (ksplit > kmax) ksplit = kmax;
   if (ksplit < 1) ksplit = 1;
+  if (const char* e = getenv("SRAD_WGRAD_KSPLIT")) ksplit = atoi(e) > 0 ? atoi(e) : ksplit;   // tools/: timing experiments
   if ((long)p.ntaps * ksplit > 65535) ksplit = 65535 / p.ntaps;
+  {  // drop empty splits: rows_per is rounded up to whole steps
+    const long rows_per = ((p.M + ksplit - 1) / ksplit + 4 * KR - 1) / (4 * KR) * (4 * KR);
+    ksplit = (p.M + rows_per - 1) / rows_per;
+  }
+  float* part = nullptr;
+  if (ksplit > 1) {
+    const size_t need = (size_t)tiles * ksplit * WG_TS;
+    SRAD_REQUIRE(q.ws && need <= q.ws_floats, "wgrad: split-K workspace too small (%zu floats needed, %zu given)", need, q.ws_floats);
+    if (q.batch.count == SRAD_WGRAD_BATCH || q.used + need > q.ws_floats) SRAD_TRY(srad_wgrad_flush(q, s));
+    part = q.ws + q.used;
+    q.used += need;
+    WgradReduceItem& it = q.batch.it[q.batch.count++];
+    it.dW = p.dW; it.db = p.db; it.part = part; it.n_real = p.n_real; it.cin_real = p.cin_real; it.ntaps = p.ntaps;
+    it.tn = tn; it.tc = tc; it.ksplit = (int)ksplit; it.tile0 = q.tiles; it.alpha = p.alpha;
+    q.tiles += (int)tiles;
+  }
   dim3 grid(tn, tc, (unsigned)(p.ntaps * ksplit));
+  constexpr size_t lds = (size_t)(4 * 64 * 68 + 4 * 64) * sizeof(float);
   const double K = (double)p.ntaps * p.cin_real;
-  SradProfScope prof(s, SRAD_K_WGRAD, 2.0 * p.M * p.n_real * K, 4.0 * p.M * (p.N + (double)p.Cin * (conv ? 1.0 : 1.0)) + 4.0 * p.n_real * K);
-  if (conv) hipLaunchKernelGGL((wgrad_kernel<PREC, true>), grid, dim3(256), 0, s, p, (int)ksplit);
-  else hipLaunchKernelGGL((wgrad_kernel<PREC, false>), grid, dim3(256), 0, s, p, (int)ksplit);
+  SradProfScope prof(s, SRAD_K_WGRAD, 2.0 * p.M * p.n_real * K, 4.0 * p.M * ((double)p.N + p.Cin) + 8.0 * p.n_real * K);
+  auto launch = [&](auto kern) -> int {
+    static bool configured = false;
+    if (!configured) {
+      SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p, (int)ksplit, part);
+    return SRAD_OK;
+  };
+  const int rc = conv ? launch(wgrad_kernel<PREC, true>) : launch(wgrad_kernel<PREC, false>);
+  if (rc) return rc;
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
 }
 
 // ------------------------------------------------------------------------------------------
-// LayerNorm backward, one wave per row, RPW rows per workgroup.  Mean / rstd are recomputed exactly as
-// the forward kernel does; dgamma / dbeta partials live in registers across the workgroup's rows.
+// LayerNorm backward, one wave per row, RPW rows per 16-wave workgroup (two rows per wave, four waves per SIMD
+// to cover the load latency).  Mean / rstd are recomputed exactly as the forward kernel does; dgamma / dbeta
+// partials live in registers across the wave's rows, are summed over the waves in LDS and left in the split-K
+// workspace for wgrad_reduce_kernel.
 // ------------------------------------------------------------------------------------------
-constexpr int LNB_RPW = 32;
-constexpr int LNB_J = 5;     // 64 * 5 = 320 channels at most
 
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdParams p) {
+// HAS_RES / ACC are template flags: a load behind a run-time test is waited for before the next one issues.
+template <bool HAS_RES, bool ACC>
+__global__ __launch_bounds__(1024) void ln_bwd_kernel(const LnBwdParams p, float* __restrict__ part) {
   __shared__ float red_g[64 * LNB_J], red_b[64 * LNB_J];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < 64 * LNB_J; i += 256) { red_g[i] = 0.f; red_b[i] = 0.f; }
+  for (int i = tid; i < 64 * LNB_J; i += 1024) { red_g[i] = 0.f; red_b[i] = 0.f; }
   __syncthreads();
   float gam[LNB_J], dg[LNB_J], db[LNB_J];
 #pragma unroll
@@ -178,7 +345,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdParams p) {
   }
   const float invC = 1.0f / (float)p.C;
   const int r_end = min(p.rows, (int)(blockIdx.x + 1) * LNB_RPW);
-  for (int row = blockIdx.x * LNB_RPW + wave; row < r_end; row += 4) {
+  for (int row = blockIdx.x * LNB_RPW + wave; row < r_end; row += 16) {
     const float* xr = p.x + (size_t)row * p.ldx;
     const float* dr = p.dxn + (size_t)row * p.ld_dxn;
     float xv[LNB_J], dy[LNB_J], rv[LNB_J], ov[LNB_J];
@@ -187,8 +354,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdParams p) {
       const int c = lane + 64 * j, cc = min(c, p.C - 1);
       const bool ok = c < p.C;
       const float a = xr[cc], b = dr[cc];
-      const float r = p.dres ? p.dres[(size_t)row * p.ld_dres + cc] : 0.f;
-      const float o = p.accumulate ? p.out[(size_t)row * p.ld_out + cc] : 0.f;
+      float r = 0.f, o = 0.f;
+      if constexpr (HAS_RES) r = p.dres[(size_t)row * p.ld_dres + cc];
+      if constexpr (ACC) o = p.out[(size_t)row * p.ld_out + cc];
       xv[j] = ok ? a : 0.f; dy[j] = ok ? b : 0.f; rv[j] = ok ? r : 0.f; ov[j] = ok ? o : 0.f;
     }
     float s = 0.f;
@@ -226,10 +394,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdParams p) {
 #pragma unroll
   for (int j = 0; j < LNB_J; ++j) { atomicAdd(&red_g[lane + 64 * j], dg[j]); atomicAdd(&red_b[lane + 64 * j], db[j]); }
   __syncthreads();
-  for (int c = tid; c < p.C; c += 256) {
-    if (p.dgamma) atomicAdd(p.dgamma + c, red_g[c]);
-    if (p.dbeta) atomicAdd(p.dbeta + c, red_b[c]);
-  }
+  // per-workgroup column sums -> workspace row; wgrad_reduce_kernel adds them up (device-scope float atomics
+  // from 256 workgroups onto the same 2 C addresses cost ~25 us per launch)
+  float* row = part + (size_t)blockIdx.x * (2 * LNB_CP);
+  if (tid < LNB_CP) { row[tid] = red_g[tid]; row[LNB_CP + tid] = red_b[tid]; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -483,7 +651,17 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 }  // namespace
 
-int srad_launch_wgrad(int prec, const WgradParams& p, hipStream_t stream) {
+int srad_wgrad_flush(WgradQueue& q, hipStream_t stream) {
+  if (q.batch.count > 0) {
+    SradProfScope prof(stream, SRAD_K_WGRAD_REDUCE, 0.0, 4.0 * q.used);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(4 * q.tiles), dim3(256), 0, stream, q.batch);
+    SRAD_CHECK_HIP(hipGetLastError());
+  }
+  q.batch.count = 0; q.tiles = 0; q.used = 0;
+  return SRAD_OK;
+}
+
+int srad_launch_wgrad(int prec, const WgradParams& p, WgradQueue& q, hipStream_t stream) {
   SRAD_REQUIRE(p.M > 0 && p.N > 0 && p.Cin > 0 && p.dW, "wgrad: empty problem M=%d N=%d Cin=%d", p.M, p.N, p.Cin);
   SRAD_REQUIRE((p.N & 3) == 0 && (p.Cin & 3) == 0 && (p.ldy & 3) == 0 && (p.ldx & 3) == 0 && (p.ycol0 & 3) == 0 &&
                    ((uintptr_t)p.dY & 15) == 0 && ((uintptr_t)p.X & 15) == 0,
@@ -493,14 +671,27 @@ int srad_launch_wgrad(int prec, const WgradParams& p, hipStream_t stream) {
   if (p.ntaps == 9 || p.stride != 1)
     SRAD_REQUIRE(p.Ho > 0 && p.Wo > 0 && p.Hi > 0 && p.Wi > 0 && p.M % (p.Ho * p.Wo) == 0, "wgrad: bad conv geometry");
   SRAD_REQUIRE(!p.row_scale || p.rps > 0, "wgrad: row_scale needs rows-per-sample");
-  return prec == SRAD_PREC_BF16 ? launch_wgrad<SRAD_PREC_BF16>(p, stream) : launch_wgrad<SRAD_PREC_F32>(p, stream);
+  return prec == SRAD_PREC_BF16 ? launch_wgrad<SRAD_PREC_BF16>(p, q, stream) : launch_wgrad<SRAD_PREC_F32>(p, q, stream);
 }
 
-int srad_launch_ln_bwd(const LnBwdParams& p, hipStream_t stream) {
-  SRAD_REQUIRE(p.rows > 0 && p.C > 0 && p.C <= 64 * LNB_J, "ln_bwd: channel count %d unsupported (1..%d)", p.C, 64 * LNB_J);
+int srad_launch_ln_bwd(const LnBwdParams& p, WgradQueue& q, hipStream_t stream) {
+  SRAD_REQUIRE(p.rows > 0 && p.C > 0 && p.C <= LNB_CP, "ln_bwd: channel count %d unsupported (1..%d)", p.C, LNB_CP);
   SRAD_REQUIRE(p.dxn && p.x && p.gamma && p.out, "ln_bwd: null argument");
+  const int nwg = (p.rows + LNB_RPW - 1) / LNB_RPW;
+  const size_t need = (size_t)nwg * 2 * LNB_CP;
+  SRAD_REQUIRE(q.ws && need <= q.ws_floats, "ln_bwd: workspace too small");
+  if (q.batch.count == SRAD_WGRAD_BATCH || q.used + need > q.ws_floats) SRAD_TRY(srad_wgrad_flush(q, stream));
+  float* part = q.ws + q.used;
+  q.used += need;
+  WgradReduceItem& it = q.batch.it[q.batch.count++];
+  it.dW = p.dgamma; it.db = p.dbeta; it.part = part; it.n_real = p.C; it.cin_real = 0; it.ntaps = 0;   // ntaps 0: column sums
+  it.tn = it.tc = 1; it.ksplit = nwg; it.tile0 = q.tiles; it.alpha = 1.f;
+  q.tiles += 2 * LNB_CP / 64;
   SradProfScope prof(stream, SRAD_K_LN_BWD, 16.0 * p.rows * p.C, 4.0 * p.rows * p.C * (3 + (p.dres ? 1 : 0) + (p.accumulate ? 1 : 0)));
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3((p.rows + LNB_RPW - 1) / LNB_RPW), dim3(256), 0, stream, p);
+  if (p.dres && p.accumulate) hipLaunchKernelGGL((ln_bwd_kernel<true, true>), dim3(nwg), dim3(1024), 0, stream, p, part);
+  else if (p.dres) hipLaunchKernelGGL((ln_bwd_kernel<true, false>), dim3(nwg), dim3(1024), 0, stream, p, part);
+  else if (p.accumulate) hipLaunchKernelGGL((ln_bwd_kernel<false, true>), dim3(nwg), dim3(1024), 0, stream, p, part);
+  else hipLaunchKernelGGL((ln_bwd_kernel<false, false>), dim3(nwg), dim3(1024), 0, stream, p, part);
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
 }

@@ -137,8 +137,9 @@ int srad_bench_mlp_block(int M, int d, int m, int no, const float* attn, const f
 
 int srad_op_wgrad(int precision, const float* dy, int ldy, const float* x, int ldx, int B, int Hi, int Wi, int N,
                   int Cin, int ntaps, int stride, const float* row_scale, float alpha, float* dw, float* db,
-                  void* stream) {
-  SRAD_REQUIRE(dy && x && dw, "op_wgrad: null argument");
+                  void* workspace, void* stream) {
+  SRAD_REQUIRE(dy && x && dw && workspace, "op_wgrad: null argument");
+  SRAD_REQUIRE(((uintptr_t)workspace & 255) == 0, "op_wgrad: workspace must be 256-byte aligned");
   SRAD_REQUIRE(stride == 1 || stride == 2, "op_wgrad: stride must be 1 or 2");
   WgradParams p{};
   const int pad = ntaps == 9 ? 1 : 0, k = ntaps == 9 ? 3 : 1;
@@ -146,8 +147,14 @@ int srad_op_wgrad(int precision, const float* dy, int ldy, const float* x, int l
   p.dY = dy; p.ldy = ldy; p.X = x; p.ldx = ldx; p.M = B * p.Ho * p.Wo;
   p.N = N; p.Cin = Cin; p.n_real = N; p.cin_real = Cin; p.ntaps = ntaps;
   p.row_scale = row_scale; p.rps = p.Ho * p.Wo; p.alpha = alpha; p.dW = dw; p.db = db;
-  return srad_launch_wgrad(precision, p, reinterpret_cast<hipStream_t>(stream));
+  WgradQueue q;
+  q.ws = reinterpret_cast<float*>(workspace);
+  q.ws_floats = SRAD_WGRAD_WS_BYTES / sizeof(float);
+  SRAD_TRY(srad_launch_wgrad(precision, p, q, reinterpret_cast<hipStream_t>(stream)));
+  return srad_wgrad_flush(q, reinterpret_cast<hipStream_t>(stream));
 }
+
+size_t srad_op_wgrad_workspace_bytes(void) { return SRAD_WGRAD_WS_BYTES; }
 
 int srad_op_dgrad(int precision, const float* dy, int ldy, int B, int H, int W, int N, const float* w, int Cin,
                   int ntaps, const float* r, int ldr, int rmode, float slope, float alpha, const float* row_scale,
@@ -168,12 +175,16 @@ int srad_op_dgrad(int precision, const float* dy, int ldy, int B, int H, int W, 
 }
 
 int srad_op_layernorm_bwd(const float* dxn, const float* x, int ldx, const float* gamma, const float* dres, float* out,
-                          int accumulate, float* dgamma, float* dbeta, int rows, int C, void* stream) {
-  SRAD_REQUIRE(dxn && x && gamma && out, "op_layernorm_bwd: null argument");
+                          int accumulate, float* dgamma, float* dbeta, int rows, int C, void* workspace, void* stream) {
+  SRAD_REQUIRE(dxn && x && gamma && out && workspace, "op_layernorm_bwd: null argument");
   LnBwdParams l{};
   l.dxn = dxn; l.ld_dxn = C; l.x = x; l.ldx = ldx; l.gamma = gamma; l.dres = dres; l.ld_dres = C;
   l.out = out; l.ld_out = C; l.accumulate = accumulate; l.dgamma = dgamma; l.dbeta = dbeta; l.rows = rows; l.C = C; l.eps = 1e-5f;
-  return srad_launch_ln_bwd(l, reinterpret_cast<hipStream_t>(stream));
+  WgradQueue q;
+  q.ws = reinterpret_cast<float*>(workspace);
+  q.ws_floats = SRAD_WGRAD_WS_BYTES / sizeof(float);
+  SRAD_TRY(srad_launch_ln_bwd(l, q, reinterpret_cast<hipStream_t>(stream)));
+  return srad_wgrad_flush(q, reinterpret_cast<hipStream_t>(stream));
 }
 
 int srad_op_window_attn_bwd(const float* qkv, const float* dout, float* dqkv, const float* table, float* dtable, int B,

@@ -32,6 +32,12 @@ int srad_set_error(int code, const char* fmt, ...);
     if (!(cond)) return srad_set_error(SRAD_ERR_ARG, __VA_ARGS__);                        \
   } while (0)
 
+#define SRAD_TRY(expr)            \
+  do {                            \
+    int _rc = (expr);             \
+    if (_rc) return _rc;          \
+  } while (0)
+
 static inline size_t srad_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int srad_round_up(int v, int a) { return (v + a - 1) / a * a; }
 
@@ -148,7 +154,7 @@ int srad_launch_qkv_attn(const QkvAttnParams& p, hipStream_t stream);
 // ------------------------------------------------------------------------------------------
 // Backward kernels (kernels_bwd.hip) - the training path of reference src/trainer.py:152-222.
 // ------------------------------------------------------------------------------------------
-// Weight gradient of a Linear / conv layer, accumulated (atomicAdd) into the PyTorch-layout fp32 tensor:
+// Weight gradient of a Linear / conv layer, accumulated (+=) into the PyTorch-layout fp32 tensor:
 //   dW[n][c][tap] += alpha * sum_m rs(m) * dY[m][ycol0 + n] * A(m, tap, c),   db[n] += alpha * sum_m rs(m) * dY[m][ycol0 + n]
 // with A the forward's row gather (identity for Linear, the 3x3 / strided window for convs).
 struct WgradParams {
@@ -162,7 +168,25 @@ struct WgradParams {
   float* dW;                   // [n_real][cin_real][ntaps]
   float* db;                   // [n_real] or null
 };
-int srad_launch_wgrad(int prec, const WgradParams& p, hipStream_t stream);
+// Split-K bookkeeping: srad_launch_wgrad() writes partial tiles into `ws` and queues the layer; srad_wgrad_flush()
+// sums the queued layers into their dW / db with one launch (automatic when 8 layers are queued or `ws` is full).
+// A queue lives on the host for the duration of one backward pass; flush before anyone reads the gradients.
+#define SRAD_WGRAD_BATCH 8
+struct WgradReduceItem {
+  float* dW; float* db; const float* part;
+  int n_real, cin_real, ntaps, tn, tc, ksplit, tile0;
+  float alpha;
+};
+struct WgradReduceBatch { WgradReduceItem it[SRAD_WGRAD_BATCH]; int count; };
+struct WgradQueue {
+  float* ws = nullptr; size_t ws_floats = 0;   // caller-owned device workspace, 16-byte aligned
+  size_t used = 0; int tiles = 0;
+  WgradReduceBatch batch{};
+};
+int srad_launch_wgrad(int prec, const WgradParams& p, WgradQueue& q, hipStream_t stream);
+int srad_wgrad_flush(WgradQueue& q, hipStream_t stream);
+
+#define SRAD_WGRAD_WS_BYTES ((size_t)256 << 20)   /* what the engines give the queue */
 
 // LayerNorm backward over rows: out (+)= dLN(dxn; x, gamma) + dres ; dgamma/dbeta += column sums (atomicAdd)
 struct LnBwdParams {
@@ -174,7 +198,10 @@ struct LnBwdParams {
   float* dgamma; float* dbeta;
   int rows, C; float eps;
 };
-int srad_launch_ln_bwd(const LnBwdParams& p, hipStream_t stream);
+
+
+// dgamma / dbeta go through the split-K queue too (per-workgroup column sums, added up at the next flush)
+int srad_launch_ln_bwd(const LnBwdParams& p, WgradQueue& q, hipStream_t stream);
 
 // Shifted-window attention backward (window size 8): recomputes P from the saved head-padded q|k|v.
 struct AttnBwdParams {
@@ -219,7 +246,7 @@ int srad_launch_nhwc_to_nchw(const float* x, int ldx, float* y, int B, int C, in
 enum {
   SRAD_K_GEMM_BN64 = 0, SRAD_K_GEMM_BN32, SRAD_K_GEMM_BN16, SRAD_K_ATTN, SRAD_K_LAYERNORM,
   SRAD_K_LAYOUT, SRAD_K_PACK, SRAD_K_SCORE, SRAD_K_MISC, SRAD_K_MLP_BLOCK, SRAD_K_QKV_ATTN,
-  SRAD_K_WGRAD, SRAD_K_ATTN_BWD, SRAD_K_LN_BWD, SRAD_K_OPTIM, SRAD_K_COUNT
+  SRAD_K_WGRAD, SRAD_K_ATTN_BWD, SRAD_K_LN_BWD, SRAD_K_OPTIM, SRAD_K_WGRAD_REDUCE, SRAD_K_COUNT
 };
 struct SradProfScope {
   hipStream_t s; int active;

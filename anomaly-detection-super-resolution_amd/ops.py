@@ -90,6 +90,19 @@ def layernorm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor) -> torch.Tensor
 
 
 # ----------------------------------------------------------------------------------- backward operators
+_WGRAD_WS = {}
+
+
+def wgrad_workspace(device) -> C.c_void_p:
+    """Zeroed-once split-K workspace of the weight-gradient kernel, one per device."""
+    key = str(device)
+    if key not in _WGRAD_WS:
+        n = L.lib().srad_op_wgrad_workspace_bytes()
+        _WGRAD_WS[key] = torch.zeros(n + 256, dtype=torch.uint8, device=device)
+    t = _WGRAD_WS[key]
+    return C.c_void_p(t.data_ptr() + (-t.data_ptr()) % 256)
+
+
 def wgrad(dy: torch.Tensor, x: torch.Tensor, N: int, Cin: int, *, ntaps: int = 1, B: int = 1, H: int = 0, W: int = 0,
           stride: int = 1, row_scale: Optional[torch.Tensor] = None, alpha: float = 1.0, bias: bool = True,
           precision: str = "fp32"):
@@ -103,7 +116,7 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, N: int, Cin: int, *, ntaps: int = 1
     db = torch.zeros(N, dtype=torch.float32, device=x.device) if bias else None
     L.check(L.lib().srad_op_wgrad(L.PRECISIONS[precision], L.dptr(dy), dy.stride(0), L.dptr(x), x.stride(0), B, H, W, N,
                                   Cin, ntaps, stride, L.dptr(row_scale), alpha, L.dptr(dw), L.dptr(db),
-                                  L.current_stream_ptr()), "op_wgrad")
+                                  wgrad_workspace(x.device), L.current_stream_ptr()), "op_wgrad")
     return dw, db
 
 
@@ -141,7 +154,8 @@ def layernorm_bwd(dxn: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, dres:
     db = torch.zeros(Cc, dtype=torch.float32, device=x.device)
     L.check(L.lib().srad_op_layernorm_bwd(L.dptr(dxn.contiguous()), L.dptr(x), x.stride(0), L.dptr(gamma),
                                           L.dptr(None if dres is None else dres.contiguous()), L.dptr(out), 1 if acc else 0,
-                                          L.dptr(dg), L.dptr(db), rows, Cc, L.current_stream_ptr()), "op_layernorm_bwd")
+                                          L.dptr(dg), L.dptr(db), rows, Cc, wgrad_workspace(x.device),
+                                          L.current_stream_ptr()), "op_layernorm_bwd")
     return out, dg, db
 
 

@@ -113,6 +113,73 @@ def anomaly_eval_leg(model, args, torch):
     return out
 
 
+def train_leg(args, torch, dist, dev, world, rank):
+    """BASELINE config C4: DRCT-L x4 training step (forward + L1 + backward + Adam), 128 px HR, 8 images per GPU
+    (global batch 8 x N), data-parallel with the per-RDG gradient buckets all-reduced over RCCL while the backward
+    runs.  Runs on every rank; returns the rank-0 summary."""
+    from srad_amd import _lib as L
+    from srad_amd.nets import DRCT
+    from srad_amd.train import FusedAdam, GradReducer, train_step
+    o = Opt()
+    o.precision, o.use_graph = args.dtype, False
+    torch.manual_seed(1)
+    m = DRCT(o).to(dev).train()
+    m.enable_training()
+    opt = FusedAdam(m, lr=1e-4)
+    red = GradReducer().attach(m) if world > 1 else None
+    B = args.train_batch
+    g = torch.Generator(device="cpu").manual_seed(100 + rank)
+    lr_img = (torch.rand(B, 1, 32, 32, generator=g) * 255.0).to(dev)
+    hr_img = (torch.rand(B, 1, 128, 128, generator=g) * 255.0).to(dev)
+    steps, warm = args.train_steps, 2
+    losses = []
+    for _ in range(warm):
+        losses.append(train_step(m, lr_img, hr_img, opt, red))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses.append(train_step(m, lr_img, hr_img, opt, red))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    out = {"workload": f"C4: DRCT-L x4 train step, 128px HR, {B} images per GPU (global batch {B * world}), L1 + Adam, DropPath 0.1",
+           "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
+           "hr_mpixels_per_s": round(world * B * 128 * 128 * steps / el / 1e6, 3),
+           "images_per_s": round(world * B * steps / el, 2),
+           "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)],
+           "grad_allreduce": ("RCCL all-reduce of %d per-RDG buckets (%.1f M fp32) overlapped with backward" %
+                              (len(m.grad_buckets), m.flat_grads.numel() / 1e6)) if world > 1 else "none (1 GPU)"}
+    if rank == 0:
+        L.prof_enable(True)
+        train_step(m, lr_img, hr_img, opt, red)
+        torch.cuda.synchronize()
+        L.prof_collect()
+        reps = 3
+        for _ in range(reps):
+            train_step(m, lr_img, hr_img, opt, red)
+        torch.cuda.synchronize()
+        prof = L.prof_collect()
+        L.prof_enable(False)
+        out["kernels"] = {k: {"launches_per_step": v["launches"] // reps, "avg_us": round(v["ms"] * 1e3 / v["launches"], 2),
+                              "ms_per_step": round(v["ms"] / reps, 3),
+                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+                          for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        fl = 3.0 * m.flops(B, 32, 32)
+        out["algorithmic_gflop_per_step"] = round(fl / 1e9, 1)
+        out["model_tflops"] = round(fl * world / (el / steps) / 1e12, 2)
+    del m, opt
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,6 +191,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-eval", action="store_true", help="skip the anomaly-eval images/s leg")
+    ap.add_argument("--no-train", action="store_true", help="skip the C4 training-step leg")
+    ap.add_argument("--train-batch", type=int, default=8)
+    ap.add_argument("--train-steps", type=int, default=10)
     args = ap.parse_args()
 
     import torch
@@ -197,6 +267,10 @@ def main():
                    "per_gpu_batch": B, "parallelism": f"image-parallel x{n_gpus} (no collective)",
                    "hipgraph": bool(opt.use_graph)},
     }
+
+    train = None if args.no_train else train_leg(args, torch, dist, dev, world, rank)
+    if train is not None:
+        result["train"] = train
 
     if rank == 0:
         flops = model.flops(B, H, W)

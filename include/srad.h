@@ -181,18 +181,22 @@ int srad_op_layernorm(const float* x, int ldx, float* y, int ldy, int rows, int 
 
 /* Backward operators (autograd of the rows above).
  * Weight/bias gradient of Linear / conv: dw[N][Cin][taps] += alpha * dy^T A(x), db[N] += alpha * colsum(dy);
- * dy [B*Ho*Wo][ldy], x [B*Hi*Wi][ldx]; N, Cin multiples of 4; row_scale optional per-sample factor [B]. */
+ * dy [B*Ho*Wo][ldy], x [B*Hi*Wi][ldx]; N, Cin multiples of 4; row_scale optional per-sample factor [B].
+ * Split-K partials are summed in a fixed order by a second kernel: results are bit-reproducible. */
 int srad_op_wgrad(int precision, const float* dy, int ldy, const float* x, int ldx, int B, int Hi, int Wi, int N,
                   int Cin, int ntaps, int stride, const float* row_scale, float alpha, float* dw, float* db,
-                  void* stream);
+                  void* workspace, void* stream);
+/* split-K workspace of srad_op_wgrad (256-byte aligned scratch, contents irrelevant, reusable by later calls on the
+ * same stream) */
+size_t srad_op_wgrad_workspace_bytes(void);
 /* Data gradient dx = (dy . w) * alpha * row_scale (* gelu'(r) if rmode 1, * lrelu'(r) if rmode 2), stride 1:
  * the forward GEMM on the transposed pack of w [N][Cin][taps]; scratch >= srad_op_gemm_scratch_bytes(p, Cin, N, taps) */
 int srad_op_dgrad(int precision, const float* dy, int ldy, int B, int H, int W, int N, const float* w, int Cin,
                   int ntaps, const float* r, int ldr, int rmode, float slope, float alpha, const float* row_scale,
                   float* dx, int ldx, void* scratch, size_t scratch_bytes, void* stream);
-/* LayerNorm backward: out (+)= dLN(dxn; x, gamma) + dres; dgamma / dbeta accumulated */
+/* LayerNorm backward: out (+)= dLN(dxn; x, gamma) + dres; dgamma / dbeta accumulated; workspace as for srad_op_wgrad */
 int srad_op_layernorm_bwd(const float* dxn, const float* x, int ldx, const float* gamma, const float* dres, float* out,
-                          int accumulate, float* dgamma, float* dbeta, int rows, int C, void* stream);
+                          int accumulate, float* dgamma, float* dbeta, int rows, int C, void* workspace, void* stream);
 /* Window attention backward (window size 8): qkv head-padded as for srad_op_window_attn, dout [T][d],
  * dqkv [T][3d] compact, dtable accumulated */
 int srad_op_window_attn_bwd(const float* qkv, const float* dout, float* dqkv, const float* table, float* dtable, int B,

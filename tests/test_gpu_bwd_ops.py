@@ -43,7 +43,7 @@ def test_wgrad_linear(dev, prec, M, K, N):
         db2 = torch.zeros(N, device=dev)
         xd, dyd, rsd = x.to(dev), dy.to(dev), rs.to(dev)
         L.check(L.lib().srad_op_wgrad(L.PRECISIONS[prec], L.dptr(dyd), dyd.stride(0), L.dptr(xd), xd.stride(0), B, 32, 32, N, K, 1, 1,
-                                      L.dptr(rsd), 0.5, L.dptr(dw2), L.dptr(db2), L.current_stream_ptr()), "op_wgrad")
+                                      L.dptr(rsd), 0.5, L.dptr(dw2), L.dptr(db2), ops.wgrad_workspace(dev), L.current_stream_ptr()), "op_wgrad")
         sc = rs.repeat_interleave(1024)[:, None] * 0.5
         assert _rel(dw2[:, :, 0], (dy * sc).t() @ x) < TOL[prec]
         assert _rel(db2, (dy * sc).sum(0)) < TOL[prec]
