@@ -115,7 +115,7 @@ _SIG = {
                                 C.c_int, C.c_int, C.c_float, C.c_float, _P, _P, C.c_int, _P, C.c_size_t, _P]),
     "srad_op_layernorm_bwd": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P]),
     "srad_op_window_attn_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                          C.c_int, C.c_int, _P]),
+                                          C.c_int, C.c_int, _P, _P]),
 }
 
 BUCKET_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int)

@@ -40,8 +40,8 @@ static inline int grid_for(size_t total) {
 // ------------------------------------------------------------------------------------------
 constexpr int WG_TS = 64 * 64 + 64;          // floats per partial: the tile and its 64 bias sums
 constexpr int LNB_RPW = 32;                  // LayerNorm backward: rows per workgroup
-constexpr int LNB_J = 5;                     // 64 * 5 = 320 channels at most
-constexpr int LNB_CP = 64 * LNB_J;
+constexpr int LNB_J4 = 2;                    // float4 chunks per lane: 2 * 256 = 512 channels at most
+constexpr int LNB_CP = 320;                  // columns of a dgamma | dbeta partial row (channel counts <= 320)
 
 template <int PREC, bool CONV>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const int ksplit, float* __restrict__ part) {
@@ -224,21 +224,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceBatc
   const WgradReduceItem& d = b.it[it];
   const int tile_id = gt - d.tile0;
   if (d.ntaps == 0) {
-    // LayerNorm dgamma | dbeta: partial rows [ksplit][2 * LNB_CP] written by ln_bwd_kernel, 16 columns per workgroup
+    // column sums: dst[c] += sum_k part[k * cin_real + c], c < n_real (LayerNorm dgamma / dbeta, bias-table
+    // gradient); 16 columns per workgroup, 16 row phases per column
     __shared__ float red[16][17];
     const int r = threadIdx.x >> 4, cl = threadIdx.x & 15;
-    const int col = (tile_id * 4 + quarter) * 16 + cl;                 // 0 .. 2 * LNB_CP
+    const int col = (tile_id * 4 + quarter) * 16 + cl;
+    const int cc = min(col, d.n_real - 1);
     float sum = 0.f;
-    for (int k = r; k < d.ksplit; k += 16) sum += d.part[(size_t)k * (2 * LNB_CP) + col];
+    for (int k = r; k < d.ksplit; k += 16) sum += d.part[(size_t)k * d.cin_real + cc];
     red[r][cl] = sum;
     __syncthreads();
-    if (threadIdx.x < 16) {
+    if (threadIdx.x < 16 && col < d.n_real) {
       float t = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) t += red[i][cl];
-      const int c = col < LNB_CP ? col : col - LNB_CP;
-      float* dst = col < LNB_CP ? d.dW : d.db;
-      if (c < d.n_real && dst) dst[c] += t;
+      d.dW[col] += t * d.alpha;
     }
     return;
   }
@@ -330,74 +330,87 @@ int launch_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 
 // HAS_RES / ACC are template flags: a load behind a run-time test is waited for before the next one issues.
+// One wave per row, 32 rows per 4-wave workgroup.
+// Lane l owns channels [4 l, 4 l + 4) and [256 + 4 l, 256 + 4 l + 4): 16-byte loads, two per tensor per row.
 template <bool HAS_RES, bool ACC>
-__global__ __launch_bounds__(1024) void ln_bwd_kernel(const LnBwdParams p, float* __restrict__ part) {
-  __shared__ float red_g[64 * LNB_J], red_b[64 * LNB_J];
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdParams p, float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float red[4][2][512];      // per wave: dgamma | dbeta partial rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < 64 * LNB_J; i += 1024) { red_g[i] = 0.f; red_b[i] = 0.f; }
-  __syncthreads();
-  float gam[LNB_J], dg[LNB_J], db[LNB_J];
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  int cofs[LNB_J4];
+  bool cok[LNB_J4];
+  f32x4 gam[LNB_J4], dg[LNB_J4], db[LNB_J4];
 #pragma unroll
-  for (int j = 0; j < LNB_J; ++j) {
-    const int c = lane + 64 * j;
-    gam[j] = p.gamma[min(c, p.C - 1)];
-    dg[j] = 0.f; db[j] = 0.f;
+  for (int j = 0; j < LNB_J4; ++j) {
+    const int c = 4 * lane + 256 * j;
+    cok[j] = c < p.C;                          // C % 4 == 0: a float4 is all in or all out
+    cofs[j] = min(c, p.C - 4);
+    gam[j] = *reinterpret_cast<const f32x4*>(p.gamma + cofs[j]);
+    dg[j] = z4; db[j] = z4;
   }
   const float invC = 1.0f / (float)p.C;
   const int r_end = min(p.rows, (int)(blockIdx.x + 1) * LNB_RPW);
-  for (int row = blockIdx.x * LNB_RPW + wave; row < r_end; row += 16) {
-    const float* xr = p.x + (size_t)row * p.ldx;
-    const float* dr = p.dxn + (size_t)row * p.ld_dxn;
-    float xv[LNB_J], dy[LNB_J], rv[LNB_J], ov[LNB_J];
+  for (int row = blockIdx.x * LNB_RPW + wave; row < r_end; row += 4) {
+    f32x4 xv[LNB_J4], dy[LNB_J4], rv[LNB_J4], ov[LNB_J4];
 #pragma unroll
-    for (int j = 0; j < LNB_J; ++j) {
-      const int c = lane + 64 * j, cc = min(c, p.C - 1);
-      const bool ok = c < p.C;
-      const float a = xr[cc], b = dr[cc];
-      float r = 0.f, o = 0.f;
-      if constexpr (HAS_RES) r = p.dres[(size_t)row * p.ld_dres + cc];
-      if constexpr (ACC) o = p.out[(size_t)row * p.ld_out + cc];
-      xv[j] = ok ? a : 0.f; dy[j] = ok ? b : 0.f; rv[j] = ok ? r : 0.f; ov[j] = ok ? o : 0.f;
+    for (int j = 0; j < LNB_J4; ++j) {
+      xv[j] = *reinterpret_cast<const f32x4*>(p.x + (size_t)row * p.ldx + cofs[j]);
+      dy[j] = *reinterpret_cast<const f32x4*>(p.dxn + (size_t)row * p.ld_dxn + cofs[j]);
+      rv[j] = z4; ov[j] = z4;
+      if constexpr (HAS_RES) rv[j] = *reinterpret_cast<const f32x4*>(p.dres + (size_t)row * p.ld_dres + cofs[j]);
+      if constexpr (ACC) ov[j] = *reinterpret_cast<const f32x4*>(p.out + (size_t)row * p.ld_out + cofs[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < LNB_J4; ++j) {
+      xv[j] = cok[j] ? xv[j] : z4;
+      dy[j] = cok[j] ? dy[j] : z4;
     }
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < LNB_J; ++j) s += xv[j];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    for (int j = 0; j < LNB_J4; ++j) s += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]);
+    s = srad_wave_sum(s);
     const float mean = s * invC;
     float v = 0.f;
+    f32x4 xh[LNB_J4], gy[LNB_J4];
 #pragma unroll
-    for (int j = 0; j < LNB_J; ++j) { const float d = (lane + 64 * j) < p.C ? xv[j] - mean : 0.f; v += d * d; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    for (int j = 0; j < LNB_J4; ++j) {
+      xh[j] = cok[j] ? xv[j] - mean : z4;
+      v += (xh[j][0] * xh[j][0] + xh[j][1] * xh[j][1]) + (xh[j][2] * xh[j][2] + xh[j][3] * xh[j][3]);
+    }
+    v = srad_wave_sum(v);
     const float rstd = rsqrtf(v * invC + p.eps);
-    float xh[LNB_J], gy[LNB_J];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < LNB_J; ++j) {
-      const bool ok = (lane + 64 * j) < p.C;
-      xh[j] = ok ? (xv[j] - mean) * rstd : 0.f;
+    for (int j = 0; j < LNB_J4; ++j) {
+      xh[j] = xh[j] * rstd;
       gy[j] = dy[j] * gam[j];
-      s1 += gy[j]; s2 += gy[j] * xh[j];
-      dg[j] += dy[j] * xh[j]; db[j] += dy[j];
+      const f32x4 t = gy[j] * xh[j];
+      s1 += (gy[j][0] + gy[j][1]) + (gy[j][2] + gy[j][3]);
+      s2 += (t[0] + t[1]) + (t[2] + t[3]);
+      dg[j] += dy[j] * xh[j];
+      db[j] += dy[j];
     }
+    s1 = srad_wave_sum(s1) * invC;
+    s2 = srad_wave_sum(s2) * invC;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-    s1 *= invC; s2 *= invC;
-    float* orow = p.out + (size_t)row * p.ld_out;
-#pragma unroll
-    for (int j = 0; j < LNB_J; ++j) {
-      const int c = lane + 64 * j;
-      if (c < p.C) orow[c] = rstd * (gy[j] - s1 - xh[j] * s2) + rv[j] + ov[j];
+    for (int j = 0; j < LNB_J4; ++j) {
+      const f32x4 o4 = (gy[j] - s1 - xh[j] * s2) * rstd + rv[j] + ov[j];
+      if (cok[j]) *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.ld_out + 4 * lane + 256 * j) = o4;
     }
   }
+  // LDS float atomics cost ~13 us here (measured); plain 16-byte stores per wave, then a 4-way sum
 #pragma unroll
-  for (int j = 0; j < LNB_J; ++j) { atomicAdd(&red_g[lane + 64 * j], dg[j]); atomicAdd(&red_b[lane + 64 * j], db[j]); }
+  for (int j = 0; j < LNB_J4; ++j) {
+    *reinterpret_cast<f32x4*>(&red[wave][0][4 * lane + 256 * j]) = dg[j];
+    *reinterpret_cast<f32x4*>(&red[wave][1][4 * lane + 256 * j]) = db[j];
+  }
   __syncthreads();
-  // per-workgroup column sums -> workspace row; wgrad_reduce_kernel adds them up (device-scope float atomics
-  // from 256 workgroups onto the same 2 C addresses cost ~25 us per launch)
+  // per-workgroup column sums -> workspace row [dgamma LNB_CP | dbeta LNB_CP]; wgrad_reduce_kernel adds them up
   float* row = part + (size_t)blockIdx.x * (2 * LNB_CP);
-  if (tid < LNB_CP) { row[tid] = red_g[tid]; row[LNB_CP + tid] = red_b[tid]; }
+  for (int i = tid; i < 2 * LNB_CP; i += 256) {
+    const int which = i >= LNB_CP ? 1 : 0, c = i - which * LNB_CP;
+    row[i] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -411,7 +424,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const LnBwdParams p, float
 constexpr int AB_HC = 32, AB_HS = AB_HC + 4, AB_PS = 64 + 4;
 constexpr size_t AB_LDS = (size_t)(4 * 64 * AB_HS + 2 * 64 * AB_PS + 2 * 256) * sizeof(float) + 2 * 64 * sizeof(int);
 
-__global__ __launch_bounds__(256) void window_attn_bwd_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(256) void window_attn_bwd_kernel(const AttnBwdParams p, float* __restrict__ tpart) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* Qs = reinterpret_cast<float*>(smem);
   float* Ks = Qs + 64 * AB_HS;
@@ -446,7 +459,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const AttnBwdParam
     const int rw = c < p.W - ws ? 0 : (c < p.W - p.shift ? 1 : 2);
     inf[tid] = ((rh * 3 + rw) << 16) | (py << 8) | px;
   }
-  if (tid < tw * tw) { tbl[tid] = p.table[(size_t)tid * heads + h]; dtb[tid] = 0.f; }
+  if (tid < tw * tw) tbl[tid] = p.table[(size_t)tid * heads + h];
   __syncthreads();
 
   // chunk staging: q/k/v as float4 (head-padded rows are 16-byte aligned), dO as scalars
@@ -544,12 +557,21 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const AttnBwdParam
         const float ds = s[j][e] * (dp[j][e] - dl);
         Pm[row * AB_PS + j * 16 + fr] = s[j][e];
         Dm[row * AB_PS + j * 16 + fr] = ds;
-        atomicAdd(&dtb[bi[j]], ds);
       }
     }
   }
   __syncthreads();
-  if (tid < tw * tw) atomicAdd(p.dtable + (size_t)tid * heads + h, dtb[tid]);
+  // bias-table gradient of this (window, head): entry t = (dy + 7) * 15 + (dx + 7) collects dS[q][k] over all query
+  // positions q whose key k = q - (dy, dx) lies in the window (<= 64 terms), read from the dS tile - no atomics.
+  // The row goes to the split-K workspace; wgrad_reduce_kernel sums the windows.
+  if (tid < tw * tw) {
+    const int dy = tid / tw - (ws - 1), dx = tid - (tid / tw) * tw - (ws - 1);
+    float acc = 0.f;
+    for (int qy = max(0, dy); qy < min(ws, ws + dy); ++qy)
+      for (int qx = max(0, dx); qx < min(ws, ws + dx); ++qx)
+        acc += Dm[(qy * ws + qx) * AB_PS + (qy - dy) * ws + (qx - dx)];
+    tpart[(size_t)win * (tw * tw * heads) + (size_t)tid * heads + h] = acc;
+  }
 
   // ---- pass B: dq, dk, dv per 32-column chunk ----
   for (int ch = 0; ch < nch; ++ch) {
@@ -674,29 +696,40 @@ int srad_launch_wgrad(int prec, const WgradParams& p, WgradQueue& q, hipStream_t
   return prec == SRAD_PREC_BF16 ? launch_wgrad<SRAD_PREC_BF16>(p, q, stream) : launch_wgrad<SRAD_PREC_F32>(p, q, stream);
 }
 
+static int queue_colsum(WgradQueue& q, float* dst, const float* part, int ncols, int row_stride, int rows, float alpha,
+                        hipStream_t stream) {
+  if (q.batch.count == SRAD_WGRAD_BATCH) SRAD_TRY(srad_wgrad_flush(q, stream));
+  WgradReduceItem& it = q.batch.it[q.batch.count++];
+  it.dW = dst; it.db = nullptr; it.part = part; it.n_real = ncols; it.cin_real = row_stride; it.ntaps = 0;   // ntaps 0: column sums
+  it.tn = it.tc = 1; it.ksplit = rows; it.tile0 = q.tiles; it.alpha = alpha;
+  q.tiles += (ncols + 63) / 64;
+  return SRAD_OK;
+}
+
 int srad_launch_ln_bwd(const LnBwdParams& p, WgradQueue& q, hipStream_t stream) {
-  SRAD_REQUIRE(p.rows > 0 && p.C > 0 && p.C <= LNB_CP, "ln_bwd: channel count %d unsupported (1..%d)", p.C, LNB_CP);
+  SRAD_REQUIRE(p.rows > 0 && p.C >= 4 && p.C <= LNB_CP && (p.C & 3) == 0, "ln_bwd: channel count %d unsupported (4..%d, multiple of 4)", p.C, LNB_CP);
+  SRAD_REQUIRE(((p.ldx | p.ld_dxn | p.ld_out | (p.dres ? p.ld_dres : 0)) & 3) == 0 &&
+                   (((uintptr_t)p.x | (uintptr_t)p.dxn | (uintptr_t)p.out | (uintptr_t)p.dres | (uintptr_t)p.gamma) & 15) == 0,
+               "ln_bwd: rows must be 16-byte aligned (strides multiples of 4 floats)");
   SRAD_REQUIRE(p.dxn && p.x && p.gamma && p.out, "ln_bwd: null argument");
   const int nwg = (p.rows + LNB_RPW - 1) / LNB_RPW;
   const size_t need = (size_t)nwg * 2 * LNB_CP;
   SRAD_REQUIRE(q.ws && need <= q.ws_floats, "ln_bwd: workspace too small");
-  if (q.batch.count == SRAD_WGRAD_BATCH || q.used + need > q.ws_floats) SRAD_TRY(srad_wgrad_flush(q, stream));
+  if (q.batch.count + 2 > SRAD_WGRAD_BATCH || q.used + need > q.ws_floats) SRAD_TRY(srad_wgrad_flush(q, stream));
   float* part = q.ws + q.used;
   q.used += need;
-  WgradReduceItem& it = q.batch.it[q.batch.count++];
-  it.dW = p.dgamma; it.db = p.dbeta; it.part = part; it.n_real = p.C; it.cin_real = 0; it.ntaps = 0;   // ntaps 0: column sums
-  it.tn = it.tc = 1; it.ksplit = nwg; it.tile0 = q.tiles; it.alpha = 1.f;
-  q.tiles += 2 * LNB_CP / 64;
+  if (p.dgamma) SRAD_TRY(queue_colsum(q, p.dgamma, part, p.C, 2 * LNB_CP, nwg, 1.f, stream));
+  if (p.dbeta) SRAD_TRY(queue_colsum(q, p.dbeta, part + LNB_CP, p.C, 2 * LNB_CP, nwg, 1.f, stream));
   SradProfScope prof(stream, SRAD_K_LN_BWD, 16.0 * p.rows * p.C, 4.0 * p.rows * p.C * (3 + (p.dres ? 1 : 0) + (p.accumulate ? 1 : 0)));
-  if (p.dres && p.accumulate) hipLaunchKernelGGL((ln_bwd_kernel<true, true>), dim3(nwg), dim3(1024), 0, stream, p, part);
-  else if (p.dres) hipLaunchKernelGGL((ln_bwd_kernel<true, false>), dim3(nwg), dim3(1024), 0, stream, p, part);
-  else if (p.accumulate) hipLaunchKernelGGL((ln_bwd_kernel<false, true>), dim3(nwg), dim3(1024), 0, stream, p, part);
-  else hipLaunchKernelGGL((ln_bwd_kernel<false, false>), dim3(nwg), dim3(1024), 0, stream, p, part);
+  if (p.dres && p.accumulate) hipLaunchKernelGGL((ln_bwd_kernel<true, true>), dim3(nwg), dim3(256), 0, stream, p, part);
+  else if (p.dres) hipLaunchKernelGGL((ln_bwd_kernel<true, false>), dim3(nwg), dim3(256), 0, stream, p, part);
+  else if (p.accumulate) hipLaunchKernelGGL((ln_bwd_kernel<false, true>), dim3(nwg), dim3(256), 0, stream, p, part);
+  else hipLaunchKernelGGL((ln_bwd_kernel<false, false>), dim3(nwg), dim3(256), 0, stream, p, part);
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
 }
 
-int srad_launch_window_attn_bwd(const AttnBwdParams& p, hipStream_t stream) {
+int srad_launch_window_attn_bwd(const AttnBwdParams& p, WgradQueue& q, hipStream_t stream) {
   SRAD_REQUIRE(p.ws == 8, "window_attn_bwd: the training path supports window size 8 only (got %d)", p.ws);
   SRAD_REQUIRE(p.H % p.ws == 0 && p.W % p.ws == 0, "window_attn_bwd: %dx%d not a multiple of the window", p.H, p.W);
   SRAD_REQUIRE(p.d % p.heads == 0 && p.hdp % 4 == 0 && p.hdp >= p.d / p.heads, "window_attn_bwd: bad head geometry");
@@ -709,8 +742,15 @@ int srad_launch_window_attn_bwd(const AttnBwdParams& p, hipStream_t stream) {
   }
   const int nW = (p.H / p.ws) * (p.W / p.ws);
   const double T = (double)p.B * p.H * p.W;
+  const int ncols = 225 * p.heads, nwin = p.B * nW;
+  const size_t need = (size_t)nwin * ncols;
+  SRAD_REQUIRE(q.ws && need <= q.ws_floats, "window_attn_bwd: workspace too small");
+  if (q.used + need > q.ws_floats) SRAD_TRY(srad_wgrad_flush(q, stream));
+  float* tpart = q.ws + q.used;
+  q.used += need;
+  SRAD_TRY(queue_colsum(q, p.dtable, tpart, ncols, ncols, nwin, 1.f, stream));
   SradProfScope prof(stream, SRAD_K_ATTN_BWD, 10.0 * T * 64 * p.d, 4.0 * T * 8 * p.d);
-  hipLaunchKernelGGL(window_attn_bwd_kernel, dim3(p.B * nW, p.heads), dim3(256), AB_LDS, stream, p);
+  hipLaunchKernelGGL(window_attn_bwd_kernel, dim3(p.B * nW, p.heads), dim3(256), AB_LDS, stream, p, tpart);
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
 }

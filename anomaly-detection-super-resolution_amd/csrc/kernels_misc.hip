@@ -74,26 +74,42 @@ extern "C" int srad_prof_collect(int64_t* launches, double* ms, double* flops, d
 namespace {
 
 // One wave per row: LayerNorm over C contiguous channels (reference nn.LayerNorm, eps 1e-5;
-// src/drct.py:798,833 patch_embed.norm / norm).
+// src/drct.py:798,833 patch_embed.norm / norm).  Rows are 16-byte aligned and C % 4 == 0, so lane l holds
+// channels [4 l, 4 l + 4) and [256 + 4 l, ..): the row is read once with 16-byte loads and stays in registers.
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y,
                                                         int ldy, int rows, int C, const float* __restrict__ g,
                                                         const float* __restrict__ b, float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float* xr = x + (size_t)row * ldx;
-  float s = 0.f;
-  for (int c = lane; c < C; c += 64) s += xr[c];
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 xv[2], gv[2], bv[2];
+  bool ok[2];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  for (int j = 0; j < 2; ++j) {
+    const int c = 4 * lane + 256 * j, cc = min(c, C - 4);
+    ok[j] = c < C;
+    xv[j] = *reinterpret_cast<const f32x4*>(x + (size_t)row * ldx + cc);
+    gv[j] = *reinterpret_cast<const f32x4*>(g + cc);
+    bv[j] = *reinterpret_cast<const f32x4*>(b + cc);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { xv[j] = ok[j] ? xv[j] : z4; s += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]); }
+  s = srad_wave_sum(s);
   const float mean = s / (float)C;
   float v = 0.f;
-  for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; v += d * d; }
+  f32x4 d[2];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  for (int j = 0; j < 2; ++j) {
+    d[j] = ok[j] ? xv[j] - mean : z4;
+    v += (d[j][0] * d[j][0] + d[j][1] * d[j][1]) + (d[j][2] * d[j][2] + d[j][3] * d[j][3]);
+  }
+  v = srad_wave_sum(v);
   const float rstd = rsqrtf(v / (float)C + eps);
-  float* yr = y + (size_t)row * ldy;
-  for (int c = lane; c < C; c += 64) yr[c] = (xr[c] - mean) * rstd * g[c] + b[c];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    if (ok[j]) *reinterpret_cast<f32x4*>(y + (size_t)row * ldy + 4 * lane + 256 * j) = d[j] * rstd * gv[j] + bv[j];
 }
 
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int Cpad, int HW,
@@ -132,7 +148,9 @@ static inline int grid_for(size_t total) {
 
 int srad_launch_layernorm(const float* x, int ldx, float* y, int ldy, int rows, int C, const float* g, const float* b,
                           float eps, hipStream_t stream) {
-  SRAD_REQUIRE(rows > 0 && C > 0, "layernorm: empty input");
+  SRAD_REQUIRE(rows > 0 && C >= 4 && C <= 512 && (C & 3) == 0, "layernorm: channel count %d unsupported (4..512, multiple of 4)", C);
+  SRAD_REQUIRE(((ldx | ldy) & 3) == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)g | (uintptr_t)b) & 15) == 0,
+               "layernorm: rows must be 16-byte aligned (strides multiples of 4 floats)");
   SradProfScope prof(stream, SRAD_K_LAYERNORM, 8.0 * rows * C, 8.0 * rows * C);
   hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, y, ldy, rows, C, g, b, eps);
   SRAD_CHECK_HIP(hipGetLastError());

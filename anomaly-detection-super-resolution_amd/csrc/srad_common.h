@@ -20,6 +20,25 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 int srad_set_error(int code, const char* fmt, ...);
+
+#if defined(__HIPCC__)
+// Sum over the 64 lanes of a wave, result in every lane.  The first four butterfly steps are DPP lane swizzles
+// (VALU speed: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror); only the last two cross a 16-lane
+// row and go through ds_bpermute.  A plain __shfl_xor chain is six dependent LDS round trips.
+template <int CTRL>
+__device__ __forceinline__ float srad_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float srad_wave_sum(float v) {
+  v += srad_dpp<0xB1>(v);
+  v += srad_dpp<0x4E>(v);
+  v += srad_dpp<0x141>(v);
+  v += srad_dpp<0x140>(v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+#endif
 #define SRAD_CHECK_HIP(expr)                                                              \
   do {                                                                                    \
     hipError_t _e = (expr);                                                               \
@@ -169,9 +188,9 @@ struct WgradParams {
   float* db;                   // [n_real] or null
 };
 // Split-K bookkeeping: srad_launch_wgrad() writes partial tiles into `ws` and queues the layer; srad_wgrad_flush()
-// sums the queued layers into their dW / db with one launch (automatic when 8 layers are queued or `ws` is full).
+// sums the queued layers into their dW / db with one launch (automatic when the batch or `ws` is full).
 // A queue lives on the host for the duration of one backward pass; flush before anyone reads the gradients.
-#define SRAD_WGRAD_BATCH 8
+#define SRAD_WGRAD_BATCH 12
 struct WgradReduceItem {
   float* dW; float* db; const float* part;
   int n_real, cin_real, ntaps, tn, tc, ksplit, tile0;
@@ -212,7 +231,7 @@ struct AttnBwdParams {
   float* dtable;       // accumulated (atomicAdd)
   int B, H, W, ws, shift, d, heads, hdp;
 };
-int srad_launch_window_attn_bwd(const AttnBwdParams& p, hipStream_t stream);
+int srad_launch_window_attn_bwd(const AttnBwdParams& p, WgradQueue& q, hipStream_t stream);   // dtable via the queue
 
 // out[m][c] = dy[m*ld_dy + c] * (y[m*ld_y + c] > 0 ? 1 : slope), c < C  (backward through (Leaky)ReLU)
 int srad_launch_dact(const float* dy, int ld_dy, const float* y, int ld_y, float* out, int ld_out, int rows, int C,

@@ -170,6 +170,7 @@ def window_attention_bwd(qkv: torch.Tensor, dout: torch.Tensor, table: torch.Ten
     dqkv = torch.empty(qkv.shape[0], 3 * d, dtype=torch.float32, device=qkv.device)
     dtable = torch.zeros_like(table, dtype=torch.float32).contiguous()
     L.check(L.lib().srad_op_window_attn_bwd(L.dptr(padded), L.dptr(dout.contiguous()), L.dptr(dqkv), L.dptr(table.contiguous()),
-                                            L.dptr(dtable), B, H, W, ws, shift, d, heads, hdp, L.current_stream_ptr()),
+                                            L.dptr(dtable), B, H, W, ws, shift, d, heads, hdp, wgrad_workspace(qkv.device),
+                                            L.current_stream_ptr()),
             "op_window_attn_bwd")
     return dqkv, dtable

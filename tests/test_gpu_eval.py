@@ -84,11 +84,21 @@ def test_model_checkpoint_surface(tmp_path):
     assert make_model(opt) is None
 
 
-def test_training_mode_is_refused_until_backward_exists():
+def test_training_mode_drct_trains_drn_is_refused():
+    """DRCT has the HIP backward (tests/test_gpu_train.py); DRN's is not built: a training-mode forward with grad
+    enabled must say so instead of silently returning a graph-less tensor."""
     from srad_amd import options as Opt
     from srad_amd.model import Model
     opt = Opt.build_opt('drct', 'grid', 64, 4)
     opt.depths, opt.num_heads = (6,), (6,)
+    opt.img_size, opt.window_size = 32, 8
+    m = Model(opt, None)
+    m.train()
+    y = m(torch.rand(1, 1, 16, 16, device='cuda') * 255)
+    assert y.requires_grad and tuple(y.shape) == (1, 1, 64, 64)
+    y.mean().backward()
+    assert float(m.model.flat_grads.abs().sum()) > 0
+    opt = Opt.build_opt('drn-l', 'grid', 64, 4)
     m = Model(opt, None)
     m.train()
     with pytest.raises(NotImplementedError, match="backward"):
