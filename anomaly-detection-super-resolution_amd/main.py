@@ -1,11 +1,13 @@
-"""CLI entry with the reference's flags (src/main.py:390-474).  Inference / evaluation of existing
-checkpoints runs on the HIP engine; the training step (fwd + L1 + backward + Adam, data-parallel over
-RCCL) is the next row of the build (DESIGN.md "What comes next") and exits with a clear message."""
+"""CLI entry with the reference's flags (src/main.py:390-474).  ``--model-type drct`` trains on the HIP engine
+(forward + L1 + backward + fused Adam; under ``python -m torch.distributed.run`` the minibatch is sharded over the
+ranks and gradients are all-reduced over RCCL while the backward runs).  ``--test-only`` evaluates an existing run.
+DRN training needs the DRN backward, which is not built yet, and says so."""
 from __future__ import annotations
 
+import os
 import sys
 
-from .options import parse_train_args
+from .options import build_opt, parse_train_args
 
 
 def main(argv=None):
@@ -14,11 +16,30 @@ def main(argv=None):
           f"Resolution: {args.resolution}\nScale: {args.scale}")
     if args.device == 'cpu':
         raise SystemExit("--device cpu is the reference's own path; this build has no CPU fallback")
-    if not args.test_only:
-        raise SystemExit("training on the HIP engine is not built yet (backward kernels + fused Adam + RCCL "
-                         "all-reduce are the next rows, see DESIGN.md); use --test-only or srad_amd.evaluate")
-    from . import evaluate
-    return evaluate.main([a for a in (argv if argv is not None else sys.argv[1:]) if a != '--test-only'])
+    if args.test_only:
+        from . import evaluate
+        return evaluate.main([a for a in (argv if argv is not None else sys.argv[1:]) if a != '--test-only'])
+    if args.model_type != 'drct':
+        raise SystemExit("training --model-type drn-l on the HIP engine is not built yet (DRN backward + dual-regression "
+                         "loss are the next rows, see DESIGN.md); --model-type drct trains, --test-only evaluates")
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    torch.manual_seed(1)                                     # src/main.py:89
+    data_root = args.data_root if getattr(args, "data_root", None) else "auto"
+    save = os.path.join(args.save_dir, args.model_type, f"{args.dataset}_{args.classe}_{args.resolution}_X{args.scale}")
+    opt = build_opt(args.model_type, args.classe, args.resolution, args.scale, batch_size=args.batch_size,
+                    dtype=getattr(args, "dtype", "bf16"), data_root=data_root, save=save, epochs=args.epochs,
+                    no_augment=getattr(args, "no_augment", True))
+    from .trainer import train_drct
+    out = train_drct(opt)
+    if world > 1:
+        dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

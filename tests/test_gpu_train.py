@@ -173,3 +173,47 @@ def test_training_errors_are_reported():
         m(torch.zeros(1, 1, 8, 8, device="cuda"))
     with pytest.raises(RuntimeError, match="GPU only"):
         DRCT(o).train()(torch.zeros(1, 1, 8, 8))
+
+
+def test_trainer_mirror_runs_epochs_on_a_png_folder(tmp_path):
+    """src/trainer.py's loop end to end on the folder layout src/data.py reads: HR + LR_4 PNGs -> two epochs of
+    L1 training (fused Adam, cosine schedule) on a 2-RDG DRCT, checkpoints written, eval forward uses the new weights."""
+    from PIL import Image
+    from srad_amd import options as Opt
+    from srad_amd.model import Model
+    from srad_amd.trainer import FolderPairs, Trainer
+    rng = np.random.default_rng(0)
+    d = tmp_path / "grid" / "train" / "good"
+    (d / "HR").mkdir(parents=True)
+    (d / "LR_4").mkdir()
+    yy, xx = np.mgrid[0:128, 0:128]
+    for i in range(8):
+        hr = (127 + 90 * np.sin(xx / (3.0 + i)) * np.cos(yy / (4.0 + 0.5 * i)) + rng.normal(0, 4, (128, 128))).clip(0, 255).astype(np.uint8)
+        lr = hr.reshape(32, 4, 32, 4).mean((1, 3)).round().astype(np.uint8)
+        Image.fromarray(hr).save(d / "HR" / f"{i:03d}.png")
+        Image.fromarray(lr).save(d / "LR_4" / f"{i:03d}.png")
+    opt = Opt.build_opt('drct', 'grid', 128, 4, batch_size=4, dtype='fp32', data_root=str(tmp_path), save=str(tmp_path / "run"), epochs=2)
+    opt.depths, opt.num_heads, opt.print_every = (6, 6), (6, 6), 1
+    assert opt.lr == 1e-4 and (opt.beta1, opt.beta2, opt.epsilon, opt.weight_decay) == (0.9, 0.999, 1e-8, 0.0)
+    torch.manual_seed(1)
+    model = Model(opt, None)
+    ds = FolderPairs(opt.data_dir, 4, 1)
+    assert len(ds) == 8
+    t = Trainer(opt, ds, model, val_set=ds)
+    lrs = []
+    while not t.terminate():
+        lrs.append(t.scheduler.get_last_lr()[0])
+        t.train()
+        model.save(opt.save, is_best=True)
+    assert len(t.loss_log) == 2 and t.loss_log[1] < t.loss_log[0]
+    assert lrs[0] == 1e-4 and abs(lrs[1] - (1e-7 + (1e-4 - 1e-7) * 0.5)) < 1e-10      # cosine, T_max = 2 epochs
+    psnr, ssim = t.test()
+    assert np.isfinite(psnr) and 0 < ssim <= 1.0
+    sd = torch.load(tmp_path / "run" / "model" / "model_best.pt", weights_only=True)
+    assert set(sd) == set(model.state_dict())
+    m2 = Model(opt, None)
+    m2.load(str(tmp_path / "run" / "model" / "model_latest.pt"))
+    x = torch.rand(1, 1, 32, 32, device="cuda") * 255
+    model.eval(), m2.eval()
+    with torch.no_grad():
+        assert torch.allclose(model(x), m2(x), rtol=1e-5, atol=1e-3)

@@ -95,3 +95,72 @@ def test_image_parallel_sharding_gloo_world2(n):
     assert sorted(res[0][0] + res[1][0]) == list(range(n)) and not set(res[0][0]) & set(res[1][0])
     assert res[1][1] is None
     assert res[0][1] == [[float(i), float(i * i), float(-i)] for i in range(n)]
+
+
+# ----------------------------------------------------------------------------------- data-parallel training (C4)
+class _FakeModel:
+    """What GradReducer needs of the engine module: a flat gradient buffer and its bucket table."""
+
+    def __init__(self, n, buckets):
+        self.flat_grads = torch.zeros(n)
+        self.grad_buckets = buckets
+        self.on_bucket = None
+
+
+def _ddp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from srad_amd.train import GradReducer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    buckets = [(700, 300), (300, 400), (0, 300), (1000, 0)]          # completion order, incl. an empty bucket
+    m = _FakeModel(1000, buckets)
+    red = GradReducer(overlap=True).attach(m)
+    assert m.on_bucket is not None and red.grad_scale == 1.0 / world
+    g = torch.Generator().manual_seed(rank)
+    local = torch.randn(1000, generator=g)
+    m.flat_grads.copy_(local)
+    for b in range(len(buckets)):            # what srad_drct_backward's hook does, bucket by bucket
+        m.on_bucket(b)
+    red.finish()
+    hooked = m.flat_grads.clone()
+    m.flat_grads.copy_(local)
+    red.reduce_all(m.flat_grads, buckets)   # the non-overlapped form
+    q.put((rank, local.tolist(), hooked.tolist(), m.flat_grads.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_buckets_allreduce_gloo_world2():
+    """world_size 2 over gloo: after the bucket hooks every rank holds the SUM of both ranks' gradients in every
+    bucket (the 1/world goes into the optimizer's grad_scale), and the hook path equals the plain path."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        r, local, hooked, plain = q.get(timeout=120)
+        res[r] = (np.array(local), np.array(hooked), np.array(plain))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    total = res[0][0] + res[1][0]
+    for r in (0, 1):
+        assert np.allclose(res[r][1], total, atol=1e-6)
+        assert np.array_equal(res[r][1], res[r][2])
+
+
+def test_cosine_schedule_matches_torch():
+    from srad_amd.train import cosine_lr
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=1e-4)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, 30.0, eta_min=1e-7)      # src/trainer.py:76-83
+    for epoch in range(31):
+        assert abs(cosine_lr(1e-4, epoch, 30.0, 1e-7) - sch.get_last_lr()[0]) < 1e-12
+        opt.step()
+        sch.step()
