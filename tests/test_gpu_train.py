@@ -217,3 +217,64 @@ def test_trainer_mirror_runs_epochs_on_a_png_folder(tmp_path):
     model.eval(), m2.eval()
     with torch.no_grad():
         assert torch.allclose(model(x), m2(x), rtol=1e-5, atol=1e-3)
+
+
+def _dp_worker(rank, world, port, cfg_tuple, seed, x, hr, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from srad_amd import spec as S
+    from srad_amd.train import FusedAdam, GradReducer, train_step
+    cfg = S.DRCTConfig(*cfg_tuple)
+    sd = S.synth_state(S.drct_spec(cfg), seed=seed, gain=1.0, cfg=cfg)
+    m = build_train(cfg, sd, "fp32")
+    opt = FusedAdam(m, lr=1e-4)
+    red = GradReducer().attach(m)
+    xs, hs = torch.from_numpy(x[rank::world]).cuda(), torch.from_numpy(hr[rank::world]).cuda()
+    loss = train_step(m, xs, hs, opt, red)
+    torch.cuda.synchronize()
+    q.put((rank, float(loss), m.flat_grads.cpu().numpy(), m.flat_params.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_two_ranks_equals_one_rank_on_the_full_batch():
+    """Two processes (one GPU, gloo) each take half of a 4-image batch; the bucket hooks all-reduce the gradients while
+    the backward runs.  Summed gradients / world and the updated weights must equal the single-process step on the
+    whole batch (L1 'mean' over the batch = mean of the per-shard means)."""
+    import socket
+    import torch.multiprocessing as mp
+    from srad_amd import spec as S
+    from srad_amd.train import FusedAdam, train_step
+    cfg_tuple = (1, 16, 8, 2, 180, 2)        # in_chans, img_size, window, upscale, embed_dim, n_rdg
+    cfg = S.DRCTConfig(*cfg_tuple)
+    x = S.synth_image("dp", (4, 1, 16, 16), seed=5)
+    hr = S.synth_image("dp/hr", (4, 1, 32, 32), seed=6)
+    sd = S.synth_state(S.drct_spec(cfg), seed=9, gain=1.0, cfg=cfg)
+    m = build_train(cfg, sd, "fp32")
+    opt = FusedAdam(m, lr=1e-4)
+    loss = float(train_step(m, torch.from_numpy(x).cuda(), torch.from_numpy(hr).cuda(), opt))
+    g_ref, p_ref = m.flat_grads.cpu().numpy(), m.flat_params.cpu().numpy()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, cfg_tuple, 9, x, hr, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        r, l, g, pp = q.get(timeout=300)
+        res[r] = (l, g, pp)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert abs(0.5 * (res[0][0] + res[1][0]) - loss) < 1e-4 * abs(loss)
+    assert np.array_equal(res[0][1], res[1][1])                       # both ranks hold the same summed gradients
+    gmax = np.abs(g_ref).max()
+    assert np.abs(res[0][1] * 0.5 - g_ref).max() < 2e-4 * gmax
+    # Adam turns noise-level gradients into +-lr steps; compare where the gradient is clearly non-zero
+    big = np.abs(g_ref) > 1e-3 * gmax
+    assert np.abs(res[0][2] - p_ref)[big].max() < 2e-5
