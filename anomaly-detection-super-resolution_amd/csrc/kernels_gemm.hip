@@ -10,6 +10,7 @@
 //   BF16 mode: v_mfma_f32_16x16x32_bf16, fp32 accumulate.
 //   F32  mode: v_mfma_f32_16x16x4_f32 (exact fp32 fma chain) - the parity mode.
 #include "srad_common.h"
+#include <stdlib.h>
 
 namespace {
 

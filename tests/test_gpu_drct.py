@@ -109,3 +109,41 @@ def test_fused_mlp_block_matches_unfused_path(sr_golden, monkeypatch):
     assert np.abs(fused - unfused).max() / rng < 1e-2
     assert np.abs(fused - y).max() / rng < 3e-2
     assert 10 * np.log10(rng ** 2 / np.mean((fused - y).astype(np.float64) ** 2)) > 35.0
+
+
+def test_c5_window64_attention_geometry_matches_oracle():
+    """BASELINE config C5 runs DRCT with window_size = img_size // 4 = 64 (src/main.py:286): N = 4096 tokens per
+    window, 64 key chunks in the attention kernel, shift 32.  Parity against the CPU oracle on a 64 x 128 LR image
+    (two windows, so the shifted blocks see the 0 / -100 mask) with a 1-RDG model in fp32 mode."""
+    from oracle import sr_ref as R
+    from srad_amd import spec as S
+    cfg = S.DRCTConfig(in_chans=1, img_size=256, window_size=64, upscale=4, n_rdg=1)
+    sd = S.synth_state(S.drct_spec(cfg), seed=64, gain=1.0, cfg=cfg)
+    x = S.synth_image("c5", (1, 1, 64, 128), seed=3)
+    with torch.no_grad():
+        ref = R.drct_forward(sd, torch.from_numpy(x), cfg).numpy()
+        out = build(cfg, sd, "fp32")(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert out.shape == (1, 1, 256, 512)
+    assert rel_err(out, ref) < 1e-3, rel_err(out, ref)
+
+
+def test_c5_full_shape_bf16_close_to_fp32_mode():
+    """C5 at full size: DRCT-L (12 RDG), one 1024 px HR tile = LR [1, 1, 256, 256], window 64 (65536 tokens, 16
+    windows of 4096).  No CPU reference at this size: the bf16 path must stay within the bf16 bar of the exact-fp32
+    path, and a second call must reproduce the first bit for bit."""
+    from srad_amd import spec as S
+    cfg = S.DRCTConfig(in_chans=1, img_size=256, window_size=64, upscale=4, n_rdg=12)
+    sd = S.synth_state(S.drct_spec(cfg), seed=65, gain=1.0, cfg=cfg)
+    x = torch.from_numpy(S.synth_image("c5full", (1, 1, 256, 256), seed=4)).cuda()
+    with torch.no_grad():
+        y32 = build(cfg, sd, "fp32")(x)
+        m16 = build(cfg, sd, "bf16")
+        y16 = m16(x)
+        y16b = m16(x)
+    assert tuple(y32.shape) == (1, 1, 1024, 1024) and bool(torch.isfinite(y32).all())
+    assert torch.equal(y16, y16b)
+    rng = float(y32.max() - y32.min())
+    err = (y16 - y32).abs()
+    psnr = 10 * np.log10(rng ** 2 / float((err.double() ** 2).mean()))
+    print("C5 full shape: bf16 vs fp32 mode max err / range", float(err.max()) / rng, "psnr", psnr)
+    assert float(err.max()) / rng < 3e-2 and psnr > 35.0
