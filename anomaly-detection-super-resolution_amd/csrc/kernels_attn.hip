@@ -49,10 +49,10 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p, co
   T* Vs = Ks + 64 * HS;
   T* Ps = Vs + 64 * HS;
   int* tokq = reinterpret_cast<int*>(Ps + 64 * KS);
-  int* tokk = tokq + 64;
-  int* infq = tokk + 64;             // packed (region << 16) | (py << 8) | px
-  int* infk = infq + 64;
-  float* tbl = reinterpret_cast<float*>(infk + 64);
+  int* infq = tokq + 64;             // packed (region << 16) | (py << 8) | px
+  int* tokk = infq + 64;             // [3][64]: key chunks kc, kc + 1 (loads in flight), kc + 2 (being computed)
+  int* infk = tokk + 3 * 64;         // [3][64]
+  float* tbl = reinterpret_cast<float*>(infk + 3 * 64);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
@@ -67,6 +67,9 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p, co
   const float scale = rsqrtf((float)hd);
   const int tw = 2 * ws - 1;
 
+  auto fexp = [](float x) -> float {     // bf16 mode: v_exp_f32 (2 ulp); fp32 (parity) mode: libm expf
+    if constexpr (PREC == SRAD_PREC_BF16) return __expf(x); else return expf(x);
+  };
   auto token_info = [&](int pos, int& tok, int& inf) {
     const int py = pos / ws, px = pos - py * ws;
     const int r = wy * ws + py, c = wx * ws + px;              // coordinates in the shifted image
@@ -78,8 +81,8 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p, co
     inf = ((rh * 3 + rw) << 16) | (py << 8) | px;
   };
 
-  // tokens of the query tile (threads 0..63) and of the first key chunk (threads 64..127)
-  if (tid < 128) {
+  // tokens of the query tile (threads 0..63) and of the first two key chunks (threads 64..191)
+  if (tid < 192) {
     const int pos = tid < 64 ? q0 + tid : tid - 64;
     int tok = 0, inf = 0;
     if (pos < N) token_info(pos, tok, inf);
@@ -127,23 +130,26 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p, co
 #pragma unroll
   for (int e = 0; e < 4; ++e) { mrow[e] = -1e30f; lrow[e] = 0.f; qinf[e] = infq[wave * 16 + fq * 4 + e]; }
 
+  // Key chunks are software-pipelined: while chunk kc is being multiplied, the K / V rows of chunk kc + 1 are in
+  // flight in registers and the token list of chunk kc + 2 is being written (three-slot ring in LDS).
   const int nchunk = (N + 63) / 64;
   for (int kc = 0; kc < nchunk; ++kc) {
     const int k0 = kc * 64;
-    if (kc > 0) {
-      __syncthreads();                     // previous chunk fully consumed
-      if (tid < 64) {
-        int tok = 0, inf = 0;
-        if (k0 + tid < N) token_info(k0 + tid, tok, inf);
-        tokk[tid] = tok; infk[tid] = inf;
-      }
-      __syncthreads();
-      load_tile(tokk, 1, kv);
-      load_tile(tokk, 2, vv);
-    }
+    const int* const infk_c = infk + (kc % 3) * 64;
+    if (kc > 0) __syncthreads();           // previous chunk fully consumed (K / V / token slot (kc + 2) % 3 free)
     store_tile(Ks, k0, 1.f, kv);
     store_tile(Vs, k0, 1.f, vv);
     __syncthreads();
+    if (kc + 1 < nchunk) {
+      const int* tk = tokk + ((kc + 1) % 3) * 64;
+      load_tile(tk, 1, kv);
+      load_tile(tk, 2, vv);
+    }
+    if (kc + 2 < nchunk && tid < 64) {
+      int tok = 0, inf = 0;
+      if (k0 + 128 + tid < N) token_info(k0 + 128 + tid, tok, inf);
+      tokk[((kc + 2) % 3) * 64 + tid] = tok; infk[((kc + 2) % 3) * 64 + tid] = inf;
+    }
 
     // ---- S = Q K^T for this wave's 16 query rows x 64 keys ----
     f32x4 s[4];
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p, co
     int kinf[4];
     bool kval[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { kinf[j] = infk[j * 16 + fr]; kval[j] = (k0 + j * 16 + fr) < N; }
+    for (int j = 0; j < 4; ++j) { kinf[j] = infk_c[j * 16 + fr]; kval[j] = (k0 + j * 16 + fr) < N; }
     float pmax[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -196,19 +202,17 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p, co
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) pmax[e] = fmaxf(pmax[e], __shfl_xor(pmax[e], off));
+      pmax[e] = srad_row16_max(pmax[e]);          // DPP lane swizzles, no LDS round trips
       const float mnew = fmaxf(mrow[e], pmax[e]);
-      const float alpha = expf(mrow[e] - mnew);
+      const float alpha = fexp(mrow[e] - mnew);
       float rs = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float pv = kval[j] ? expf(s[j][e] - mnew) : 0.f;
+        const float pv = kval[j] ? fexp(s[j][e] - mnew) : 0.f;
         s[j][e] = pv;
         rs += pv;
       }
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) rs += __shfl_xor(rs, off);
+      rs = srad_row16_sum(rs);
       lrow[e] = lrow[e] * alpha + rs;
       mrow[e] = mnew;
 #pragma unroll
@@ -216,7 +220,8 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p, co
 #pragma unroll
       for (int j = 0; j < 4; ++j) Ps[(wave * 16 + fq * 4 + e) * KS + j * 16 + fr] = (T)s[j][e];
     }
-    __syncthreads();
+    // a wave reads back only the 16 rows of P it has just written: LDS operations of one wave complete in
+    // order, so no workgroup barrier is needed here
 
     // ---- O += P V ----
     if constexpr (PREC == SRAD_PREC_BF16) {
@@ -277,7 +282,7 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
   constexpr int HDP = NT_O * 16, HS = HDP + PAD, KS = 64 + PAD;
   const int N = p.ws * p.ws;
   const int tw = 2 * p.ws - 1;
-  size_t base = (size_t)(3 * 64 * HS + 64 * KS) * sizeof(T) + 4 * 64 * sizeof(int);
+  size_t base = (size_t)(3 * 64 * HS + 64 * KS) * sizeof(T) + 8 * 64 * sizeof(int);
   base = srad_align_up(base, 16);
   const int tbl_in_lds = (base + (size_t)tw * tw * 4) <= 150 * 1024 ? 1 : 0;
   const size_t lds = base + (tbl_in_lds ? (size_t)tw * tw * 4 : 0);

@@ -539,19 +539,16 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const AttnBwdParam
         s[j][e] = v;
         mx = fmaxf(mx, v);
       }
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+      mx = srad_row16_max(mx);
       float sum = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) { s[j][e] = expf(s[j][e] - mx); sum += s[j][e]; }
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) sum += __shfl_xor(sum, off);
+      sum = srad_row16_sum(sum);
       const float inv = 1.0f / sum;
       float dl = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) { s[j][e] *= inv; dl += s[j][e] * dp[j][e]; }
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) dl += __shfl_xor(dl, off);
+      dl = srad_row16_sum(dl);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float ds = s[j][e] * (dp[j][e] - dl);

@@ -149,8 +149,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
       s += (v[0] + v[1]) + (v[2] + v[3]);
       ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     }
-#pragma unroll
-    for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+    { s = srad_row8_sum(s); ss = srad_row8_sum(ss); }
     const float mu = s / (float)d;
     const float rstd = rsqrtf(fmaxf(ss / (float)d - mu * mu, 0.f) + 1e-5f);
     __syncthreads();                                              // gamma / beta staged
@@ -246,13 +245,11 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
         sc[j][e] = v;
         mx = fmaxf(mx, v);
       }
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+      mx = srad_row16_max(mx);
       float rs = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) { const float pv = __expf(sc[j][e] - mx); sc[j][e] = pv; rs += pv; }
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) rs += __shfl_xor(rs, off);
+      rs = srad_row16_sum(rs);
       if (fr == 0) lsum[wave * 16 + fq * 4 + e] = rs;
 #pragma unroll
       for (int j = 0; j < 4; ++j) Ps[(wave * 16 + fq * 4 + e) * QA_LDP + j * 16 + fr] = (__bf16)sc[j][e];

@@ -259,8 +259,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         s += (vw[0] + vw[1]) + (vw[2] + vw[3]);
         ss += (vw[0] * vw[0] + vw[1] * vw[1]) + (vw[2] * vw[2] + vw[3] * vw[3]);
       }
-#pragma unroll
-      for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+      { s = srad_row8_sum(s); ss = srad_row8_sum(ss); }
       const float mean = s / (float)p.Cin;
       ln_mu[i] = mean;
       ln_rs[i] = rsqrtf(fmaxf(ss / (float)p.Cin - mean * mean, 0.f) + p.ln_eps);

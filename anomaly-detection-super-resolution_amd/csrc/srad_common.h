@@ -29,6 +29,28 @@ template <int CTRL>
 __device__ __forceinline__ float srad_dpp(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
+// Butterfly over the 16 lanes of a DPP row (the lanes that share lane >> 4), result in all 16: VALU only.
+__device__ __forceinline__ float srad_row16_sum(float v) {
+  v += srad_dpp<0xB1>(v);
+  v += srad_dpp<0x4E>(v);
+  v += srad_dpp<0x141>(v);
+  v += srad_dpp<0x140>(v);
+  return v;
+}
+// ... over aligned groups of 8 lanes
+__device__ __forceinline__ float srad_row8_sum(float v) {
+  v += srad_dpp<0xB1>(v);
+  v += srad_dpp<0x4E>(v);
+  v += srad_dpp<0x141>(v);
+  return v;
+}
+__device__ __forceinline__ float srad_row16_max(float v) {
+  v = fmaxf(v, srad_dpp<0xB1>(v));
+  v = fmaxf(v, srad_dpp<0x4E>(v));
+  v = fmaxf(v, srad_dpp<0x141>(v));
+  v = fmaxf(v, srad_dpp<0x140>(v));
+  return v;
+}
 __device__ __forceinline__ float srad_wave_sum(float v) {
   v += srad_dpp<0xB1>(v);
   v += srad_dpp<0x4E>(v);
