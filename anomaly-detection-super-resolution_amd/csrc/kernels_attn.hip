@@ -34,23 +34,31 @@ __device__ __forceinline__ void store4(typename AT<PREC>::type* dst, f32x4 v) {
   }
 }
 
-template <int PREC, int NT_O>
-__global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p, const int tbl_in_lds) {
+// TBL_LDS (bias table staged in LDS, every window size up to 64) is a template flag: as a run-time flag the
+// sixteen look-ups per lane and chunk became branchy flat loads, each waited for before the next.
+// NW = waves per workgroup = 16-query slabs per workgroup: 4 for windows of up to 64 tokens, 8 above (the K / V
+// chunk and the bias table in LDS are then shared by 128 queries and two waves per SIMD hide each other's latency).
+template <int PREC, int NT_O, bool TBL_LDS, int NW>
+__global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p) {
   using T = typename AT<PREC>::type;
   constexpr int PAD = AT<PREC>::PAD;
   constexpr int HDP = NT_O * 16;
   constexpr int HS = HDP + PAD;      // Q/K/V row stride (elements)
   constexpr int KS = 64 + PAD;       // P row stride
   constexpr int V4R = HDP / 4;       // float4 per staged row
-  constexpr int NLV = 64 * V4R / 256;  // float4 per thread per 64-row tile
+  constexpr int NT = NW * 64;        // threads
+  constexpr int BQ = NW * 16;        // query rows per workgroup
+  constexpr int NLV = 64 * V4R / NT; // float4 per thread per 64-row K / V chunk
+  constexpr int NLQ = BQ * V4R / NT; // float4 per thread for the query tile
+  static_assert(NLV >= 1 && NLV * NT == 64 * V4R, "K / V chunk must divide over the threads");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* Qs = reinterpret_cast<T*>(smem);
-  T* Ks = Qs + 64 * HS;
+  T* Ks = Qs + BQ * HS;
   T* Vs = Ks + 64 * HS;
   T* Ps = Vs + 64 * HS;
-  int* tokq = reinterpret_cast<int*>(Ps + 64 * KS);
-  int* infq = tokq + 64;             // packed (region << 16) | (py << 8) | px
-  int* tokk = infq + 64;             // [3][64]: key chunks kc, kc + 1 (loads in flight), kc + 2 (being computed)
+  int* tokq = reinterpret_cast<int*>(Ps + BQ * KS);
+  int* infq = tokq + BQ;             // packed (region << 24) | (py * (2 ws - 1) + px)
+  int* tokk = infq + BQ;             // [3][64]: key chunks kc, kc + 1 (loads in flight), kc + 2 (being computed)
   int* infk = tokk + 3 * 64;         // [3][64]
   float* tbl = reinterpret_cast<float*>(infk + 3 * 64);
 
@@ -63,7 +71,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p, co
   const int win = blockIdx.z;
   const int b = win / nW, widx = win - b * nW;
   const int wy = widx / nWx, wx = widx - wy * nWx;
-  const int q0 = blockIdx.x * 64;
+  const int q0 = blockIdx.x * BQ;
   const float scale = rsqrtf((float)hd);
   const int tw = 2 * ws - 1;
 
@@ -78,36 +86,38 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p, co
     tok = (b * p.H + orr) * p.W + occ;
     const int rh = r < p.H - ws ? 0 : (r < p.H - p.shift ? 1 : 2);
     const int rw = c < p.W - ws ? 0 : (c < p.W - p.shift ? 1 : 2);
-    inf = ((rh * 3 + rw) << 16) | (py << 8) | px;
+    inf = ((rh * 3 + rw) << 24) | (py * tw + px);        // shift-mask region | linear position in the bias table
   };
 
-  // tokens of the query tile (threads 0..63) and of the first two key chunks (threads 64..191)
-  if (tid < 192) {
-    const int pos = tid < 64 ? q0 + tid : tid - 64;
+  // tokens of the query tile (threads 0 .. BQ-1) and of the first two key chunks (the next 128 threads)
+  if (tid < BQ + 128) {
+    const int pos = tid < BQ ? q0 + tid : tid - BQ;
     int tok = 0, inf = 0;
     if (pos < N) token_info(pos, tok, inf);
-    if (tid < 64) { tokq[tid] = tok; infq[tid] = inf; }
-    else { tokk[tid - 64] = tok; infk[tid - 64] = inf; }
+    if (tid < BQ) { tokq[tid] = tok; infq[tid] = inf; }
+    else { tokk[tid - BQ] = tok; infk[tid - BQ] = inf; }
   }
-  if (tbl_in_lds)
-    for (int i = tid; i < tw * tw; i += 256) tbl[i] = p.table[(size_t)i * heads + h];
+  if constexpr (TBL_LDS)
+    for (int i = tid; i < tw * tw; i += NT) tbl[i] = p.table[(size_t)i * heads + h];
   __syncthreads();
 
   // All global loads are unconditional on clamped addresses and masked by a multiply afterwards:
   // a load inside a per-element branch is waited for before the next one issues.
-  f32x4 qv[NLV], kv[NLV], vv[NLV];
-  auto load_tile = [&](const int* toks, int which, f32x4 (&dst)[NLV]) {
+  f32x4 qv[NLQ], kv[NLV], vv[NLV];
+  auto load_tile = [&](const int* toks, int which, auto& dst) {
+    constexpr int NL = sizeof(dst) / sizeof(f32x4);
 #pragma unroll
-    for (int i = 0; i < NLV; ++i) {
-      const int idx = tid + 256 * i;
+    for (int i = 0; i < NL; ++i) {
+      const int idx = tid + NT * i;
       const int row = idx / V4R, c = (idx - row * V4R) * 4;
       dst[i] = *reinterpret_cast<const f32x4*>(p.qkv + (size_t)toks[row] * ldq + (which * heads + h) * hdp + min(c, hdp - 4));
     }
   };
-  auto store_tile = [&](T* base, int first, float mul, const f32x4 (&src)[NLV]) {
+  auto store_tile = [&](T* base, int first, float mul, const auto& src) {
+    constexpr int NL = sizeof(src) / sizeof(f32x4);
 #pragma unroll
-    for (int i = 0; i < NLV; ++i) {
-      const int idx = tid + 256 * i;
+    for (int i = 0; i < NL; ++i) {
+      const int idx = tid + NT * i;
       const int row = idx / V4R, c = (idx - row * V4R) * 4;
       const float rk = (first + row < N) ? mul : 0.f;
       f32x4 m;
@@ -186,13 +196,16 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p, co
     float pmax[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int qy = (qinf[e] >> 8) & 0xff, qx = qinf[e] & 0xff, qr = qinf[e] >> 16;
+      // bias index (qy - ky + ws - 1) * tw + (qx - kx + ws - 1) = lin_q - lin_k + (ws - 1) * (tw + 1)
+      const int aq = (qinf[e] & 0xffffff) + (ws - 1) * (tw + 1), qr = qinf[e] >> 24;
       float mx = -1e30f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int ky = (kinf[j] >> 8) & 0xff, kx = kinf[j] & 0xff, kr = kinf[j] >> 16;
-        const int bi = (qy - ky + ws - 1) * tw + (qx - kx + ws - 1);
-        float v = s[j][e] + (tbl_in_lds ? tbl[bi] : p.table[(size_t)bi * heads + h]);
+        const int kr = kinf[j] >> 24;
+        const int bi = aq - (kinf[j] & 0xffffff);
+        float bias;
+        if constexpr (TBL_LDS) bias = tbl[bi]; else bias = p.table[(size_t)bi * heads + h];
+        float v = s[j][e] + bias;
         if (p.shift > 0 && qr != kr) v += -100.0f;
         if (!kval[j]) v = -1e30f;
         s[j][e] = v;
@@ -275,39 +288,50 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p, co
   }
 }
 
-template <int PREC, int NT_O>
+template <int PREC, int NT_O, int NW>
 int launch_attn(const AttnParams& p, hipStream_t stream) {
   using T = typename AT<PREC>::type;
   constexpr int PAD = AT<PREC>::PAD;
-  constexpr int HDP = NT_O * 16, HS = HDP + PAD, KS = 64 + PAD;
+  constexpr int HDP = NT_O * 16, HS = HDP + PAD, KS = 64 + PAD, BQ = NW * 16;
   const int N = p.ws * p.ws;
   const int tw = 2 * p.ws - 1;
-  size_t base = (size_t)(3 * 64 * HS + 64 * KS) * sizeof(T) + 8 * 64 * sizeof(int);
+  size_t base = (size_t)((BQ + 128) * HS + BQ * KS) * sizeof(T) + (2 * BQ + 6 * 64) * sizeof(int);
   base = srad_align_up(base, 16);
   const int tbl_in_lds = (base + (size_t)tw * tw * 4) <= 150 * 1024 ? 1 : 0;
   const size_t lds = base + (tbl_in_lds ? (size_t)tw * tw * 4 : 0);
-  auto kern = window_attn_kernel<PREC, NT_O>;
-  static size_t configured = 0;
-  if (lds > configured) {
+  auto kern = tbl_in_lds ? window_attn_kernel<PREC, NT_O, true, NW> : window_attn_kernel<PREC, NT_O, false, NW>;
+  static size_t configured[2] = {0, 0};
+  if (lds > configured[tbl_in_lds]) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = lds;
+    configured[tbl_in_lds] = lds;
   }
   const int nW = (p.H / p.ws) * (p.W / p.ws);
-  dim3 grid((N + 63) / 64, p.heads, p.B * nW);
+  dim3 grid((N + BQ - 1) / BQ, p.heads, p.B * nW);
   const double Ttok = (double)p.B * p.H * p.W;
   SradProfScope prof(stream, SRAD_K_ATTN, 4.0 * Ttok * N * p.d, 4.0 * Ttok * 4 * p.d);   // q,k,v read + out written
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p, tbl_in_lds);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, p);
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
+}
+
+template <int PREC, int NT_O>
+int launch_attn_nw(const AttnParams& p, hipStream_t stream) {
+  using T = typename AT<PREC>::type;
+  constexpr int HS = NT_O * 16 + AT<PREC>::PAD, KS = 64 + AT<PREC>::PAD;
+  // 128-query workgroups when the window has that many tokens and their tiles + the bias table fit in LDS
+  const int tw = 2 * p.ws - 1;
+  const size_t lds8 = (size_t)((128 + 128) * HS + 128 * KS) * sizeof(T) + (2 * 128 + 6 * 64) * sizeof(int) + 16 + (size_t)tw * tw * 4;
+  if (p.ws * p.ws >= 128 && lds8 <= 150 * 1024) return launch_attn<PREC, NT_O, 8>(p, stream);
+  return launch_attn<PREC, NT_O, 4>(p, stream);
 }
 
 template <int PREC>
 int launch_attn_prec(const AttnParams& p, hipStream_t stream) {
   const int hd = p.d / p.heads;
-  if (hd <= 32) return launch_attn<PREC, 2>(p, stream);
-  if (hd <= 64) return launch_attn<PREC, 4>(p, stream);
-  if (hd <= 96) return launch_attn<PREC, 6>(p, stream);
-  if (hd <= 128) return launch_attn<PREC, 8>(p, stream);
+  if (hd <= 32) return launch_attn_nw<PREC, 2>(p, stream);
+  if (hd <= 64) return launch_attn_nw<PREC, 4>(p, stream);
+  if (hd <= 96) return launch_attn_nw<PREC, 6>(p, stream);
+  if (hd <= 128) return launch_attn_nw<PREC, 8>(p, stream);
   return srad_set_error(SRAD_ERR_ARG, "window_attn: head_dim %d > 128 unsupported", hd);
 }
 
