@@ -180,6 +180,45 @@ def train_leg(args, torch, dist, dev, world, rank):
     return out
 
 
+def c5_leg(args, torch, dev):
+    """BASELINE config C5: DRCT-L eval on one 1024 px HR tile (LR [1,1,256,256], window 64 -> 4096-token windows)."""
+    from srad_amd import _lib as L
+    from srad_amd.nets import DRCT
+    o = Opt()
+    o.img_size, o.window_size, o.precision, o.use_graph = 256, 64, args.dtype, True
+    torch.manual_seed(1)
+    m = DRCT(o).to(dev).eval()
+    x = torch.rand(1, 1, 256, 256, device=dev) * 255.0
+    steps = 5
+    with torch.no_grad():
+        for _ in range(3):
+            m(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m(x)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        m.use_graph = False
+        L.prof_enable(True)
+        m(x)
+        torch.cuda.synchronize()
+        L.prof_collect()
+        m(x)
+        torch.cuda.synchronize()
+        prof = L.prof_collect()
+        L.prof_enable(False)
+    fl = m.flops(1, 256, 256)
+    out = {"workload": "C5: DRCT-L x4 forward, one 1024 px HR tile (LR [1,1,256,256]), window 64", "ms_per_tile": round(dt * 1e3, 2),
+           "hr_mpixels_per_s": round(1024 * 1024 / dt / 1e6, 2), "algorithmic_gflop": round(fl / 1e9, 1),
+           "model_tflops": round(fl / dt / 1e12, 1),
+           "kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
+                       for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}
+    del m
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -268,9 +307,11 @@ def main():
                    "hipgraph": bool(opt.use_graph)},
     }
 
-    train = None if args.no_train else train_leg(args, torch, dist, dev, world, rank)
-    if train is not None:
-        result["train"] = train
+    if not args.no_train:
+        try:
+            result["train"] = train_leg(args, torch, dist, dev, world, rank)
+        except Exception as e:          # the headline line must survive a failure of this extra leg
+            result["train"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         flops = model.flops(B, H, W)
@@ -344,6 +385,7 @@ def main():
             result["max_rel_err_vs_cpu_fp32"] = float(f"{err:.3e}")
         if n_gpus == 1 and not args.no_eval:
             result["anomaly_eval"] = anomaly_eval_leg(model, args, torch)
+            result["eval_1024px_tile"] = c5_leg(args, torch, dev)
         print(json.dumps(result))
     if world > 1:
         dist.barrier()
