@@ -73,6 +73,17 @@ _SIG = {
     "srad_drn_workspace_bytes": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "srad_drn_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P), C.c_int, _P, C.c_size_t, _P]),
     "srad_drn_flops": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "srad_drn_train_param_floats": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "srad_drn_train_param_offset": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
+    "srad_drn_train_arena_bytes": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
+    "srad_drn_train_bind": (C.c_int, [_P, _P, C.c_size_t]),
+    "srad_drn_sync_params": (C.c_int, [_P, _P, _P]),
+    "srad_drn_train_workspace_bytes": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "srad_drn_forward_train": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P), C.c_int, _P, C.c_size_t, _P]),
+    "srad_drn_backward": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
+    "srad_dual_backward_workspace_bytes": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "srad_dual_backward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P,
+                                     C.c_size_t, C.c_int, _P]),
     "srad_dual_workspace_bytes": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "srad_dual_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, _P, C.c_int, C.c_int, C.c_int, _P, _P,
                                     C.c_size_t, C.c_int, _P]),

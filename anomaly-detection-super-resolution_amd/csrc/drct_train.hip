@@ -13,65 +13,9 @@
 //   * weight gradients accumulate (atomicAdd) into the flat gradient buffer: zero it per step.
 #include <math.h>
 #include <stdlib.h>
-#include <type_traits>
-
 #include "drct_engine.h"
 
-struct SyncDesc {
-  long long src_off;    // floats into the flat parameter buffer
-  long long dst_off;    // bytes into the forward arena
-  long long tdst_off;   // bytes into the training arena (-1: no transposed pack)
-  int packed, n, cin, ntaps, Np, Cp, tRp, tKp;
-  long long numel;
-  unsigned blk0, nblk;
-};
-
 namespace {
-
-constexpr int SYNC_EPB = 2048;   // elements per block of the sync kernel
-
-template <int PREC>
-__global__ __launch_bounds__(256) void sync_params_kernel(const SyncDesc* __restrict__ descs, int ndesc,
-                                                          const float* __restrict__ flat, char* __restrict__ arena,
-                                                          char* __restrict__ tarena) {
-  using T = typename std::conditional<PREC == SRAD_PREC_BF16, __bf16, float>::type;
-  // binary search: last descriptor with blk0 <= blockIdx.x
-  int lo = 0, hi = ndesc - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (descs[mid].blk0 <= blockIdx.x) lo = mid; else hi = mid - 1;
-  }
-  const SyncDesc d = descs[lo];
-  const long long base = (long long)(blockIdx.x - d.blk0) * SYNC_EPB;
-  const float* src = flat + d.src_off;
-  if (!d.packed) {
-    float* dst = reinterpret_cast<float*>(arena + d.dst_off);
-    for (long long i = base + threadIdx.x; i < base + SYNC_EPB && i < d.numel; i += 256) dst[i] = src[i];
-    return;
-  }
-  const long long ftotal = (long long)d.Np * d.ntaps * d.Cp;
-  T* dst = reinterpret_cast<T*>(arena + d.dst_off);
-  for (long long i = base + threadIdx.x; i < base + SYNC_EPB && i < ftotal; i += 256) {
-    const int c = (int)(i % d.Cp);
-    const int tap = (int)((i / d.Cp) % d.ntaps);
-    const int n = (int)(i / ((long long)d.Cp * d.ntaps));
-    float v = 0.f;
-    if (n < d.n && c < d.cin) v = src[((long long)n * d.cin + c) * d.ntaps + tap];
-    dst[i] = (T)v;
-  }
-  if (d.tdst_off >= 0) {
-    const long long ttotal = (long long)d.tRp * d.ntaps * d.tKp;
-    T* tdst = reinterpret_cast<T*>(tarena + d.tdst_off);
-    for (long long i = base + threadIdx.x; i < base + SYNC_EPB && i < ttotal; i += 256) {
-      const int n = (int)(i % d.tKp);
-      const int tap = (int)((i / d.tKp) % d.ntaps);
-      const int c = (int)(i / ((long long)d.tKp * d.ntaps));
-      float v = 0.f;
-      if (n < d.n && c < d.cin) v = src[((long long)n * d.cin + c) * d.ntaps + (d.ntaps - 1 - tap)];
-      tdst[i] = (T)v;
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------ workspace
 struct BlockSave { float *xn1, *qkv, *attn, *x1, *xn2, *hpre, *hact, *x2; };
@@ -136,7 +80,7 @@ GemmParams dgrad_gemm(const srad_drct* h, const ConvW& c, const float* dY, int l
   const int npad = srad_round_up(c.n, 4), cpad = srad_round_up(c.cin, 4);
   p.X = dY; p.ldx = ldy; p.M = M; p.Cin = npad; p.Cp = srad_cp(npad); p.ntaps = c.ntaps;
   p.stride = 1; p.ln_eps = 1e-5f;
-  p.Wp = h->tarena + h->t_off[c.w]; p.N = cpad; p.bias = nullptr;
+  p.Wp = h->ts.tarena + h->ts.t_off[c.w]; p.N = cpad; p.bias = nullptr;
   p.alpha = 1.f; p.Y = dX; p.ldy = ldx;
   return p;
 }
@@ -146,15 +90,15 @@ WgradParams wgrad_of(const srad_drct* h, const ConvW& c, float* flat_grad, const
   p.dY = dY; p.ldy = ldy; p.ycol0 = ycol0; p.X = X; p.ldx = ldx; p.M = M;
   p.N = srad_round_up(c.n, 4); p.Cin = srad_round_up(c.cin, 4); p.ntaps = c.ntaps;
   p.n_real = c.n; p.cin_real = c.cin; p.stride = 1; p.alpha = 1.f;
-  p.dW = flat_grad + h->flat_off[c.w];
-  p.db = c.b >= 0 ? flat_grad + h->flat_off[c.b] : nullptr;
+  p.dW = flat_grad + h->ts.flat_off[c.w];
+  p.db = c.b >= 0 ? flat_grad + h->ts.flat_off[c.b] : nullptr;
   return p;
 }
 void geom(GemmParams& p, int H, int W) { p.Hi = p.Ho = H; p.Wi = p.Wo = W; }
 void geom(WgradParams& p, int H, int W) { p.Hi = p.Ho = H; p.Wi = p.Wo = W; }
 
 int train_check(const srad_drct* h, int B, int H, int W) {
-  SRAD_REQUIRE(h->train_ready, "drct training: call srad_drct_train_bind() and srad_drct_sync_params() first");
+  SRAD_REQUIRE(h->ts.ready, "drct training: call srad_drct_train_bind() and srad_drct_sync_params() first");
   SRAD_REQUIRE(B > 0 && H > 0 && W > 0, "drct training: empty input");
   SRAD_REQUIRE(h->cfg.window_size == 8, "drct training: window size 8 only (got %d)", h->cfg.window_size);
   SRAD_REQUIRE(H % 8 == 0 && W % 8 == 0, "drct training: input %dx%d is not a multiple of the window size 8", H, W);
@@ -169,100 +113,35 @@ extern "C" {
 
 int srad_drct_train_param_floats(srad_drct_t* h, int64_t* total) {
   SRAD_REQUIRE(h && total, "train_param_floats: null argument");
-  if (h->flat_off.empty()) {
-    int64_t off = 0;
-    for (const ParamEntry& e : h->pt.entries) {
-      h->flat_off.push_back(off);
-      off += (e.numel + 63) / 64 * 64;
-    }
-    h->flat_total = off;
-  }
-  *total = h->flat_total;
-  return SRAD_OK;
+  return train_param_floats(h->pt, h->ts, total);
 }
 
 int srad_drct_train_param_offset(srad_drct_t* h, int idx, int64_t* off_floats) {
   int64_t tot = 0;
-  SRAD_TRY(srad_drct_train_param_floats(h, &tot));
+  SRAD_REQUIRE(h, "train_param_offset: null argument");
+  SRAD_TRY(train_param_floats(h->pt, h->ts, &tot));
   SRAD_REQUIRE(off_floats && idx >= 0 && idx < (int)h->pt.entries.size(), "train_param_offset: index %d out of range", idx);
-  *off_floats = h->flat_off[idx];
+  *off_floats = h->ts.flat_off[idx];
   return SRAD_OK;
 }
 
 int srad_drct_train_arena_bytes(srad_drct_t* h, size_t* bytes) {
   SRAD_REQUIRE(h && bytes, "train_arena_bytes: null argument");
-  int64_t tot = 0;
-  SRAD_TRY(srad_drct_train_param_floats(h, &tot));
-  if (h->t_off.empty()) {
-    size_t off = 0;
-    for (const ParamEntry& e : h->pt.entries) {
-      h->t_off.push_back(off);
-      if (e.packed) off += srad_align_up(srad_packed_bytes(h->pt.prec, srad_round_up(e.cin, 4), srad_round_up(e.n, 4), e.ntaps), 256);
-    }
-    h->t_desc_off = off;
-    off += srad_align_up(h->pt.entries.size() * sizeof(SyncDesc), 256);
-    h->t_wgrad_off = off;                       // split-K workspace of the weight-gradient kernel
-    off += srad_align_up(SRAD_WGRAD_WS_BYTES, 256);
-    h->t_bytes = off;
-  }
-  *bytes = h->t_bytes;
-  return SRAD_OK;
+  return train_arena_bytes(h->pt, h->ts, bytes);
 }
 
-// Binds the caller-owned training arena (transposed weight packs + the descriptor table of the sync kernel).
-// Synchronous (one small host-to-device copy); call once after srad_drct_bind_arena.
+// Binds the caller-owned training arena (transposed weight packs + the descriptor table of the sync kernel +
+// the split-K workspace).  Synchronous; call once after srad_drct_bind_arena.
 int srad_drct_train_bind(srad_drct_t* h, void* train_arena, size_t bytes) {
-  SRAD_REQUIRE(h && train_arena, "train_bind: null argument");
-  size_t need = 0;
-  SRAD_TRY(srad_drct_train_arena_bytes(h, &need));
-  SRAD_REQUIRE(bytes >= need, "train_bind: %zu bytes given, %zu needed", bytes, need);
-  SRAD_REQUIRE(((uintptr_t)train_arena & 255) == 0, "train_bind: arena must be 256-byte aligned");
-  if (!h->pt.arena) return srad_set_error(SRAD_ERR_STATE, "train_bind: bind the forward arena first");
-  std::vector<SyncDesc> descs;
-  unsigned blk = 0;
-  for (size_t i = 0; i < h->pt.entries.size(); ++i) {
-    const ParamEntry& e = h->pt.entries[i];
-    SyncDesc d{};
-    d.src_off = h->flat_off[i]; d.dst_off = (long long)e.off; d.tdst_off = -1;
-    d.packed = e.packed; d.numel = e.numel;
-    long long work = e.numel;
-    if (e.packed) {
-      SRAD_REQUIRE(e.grp_pad == 0 && (e.n_pad == 0 || e.n_pad == e.n), "train_bind: padded layers are not trainable");
-      d.n = e.n; d.cin = e.cin; d.ntaps = e.ntaps; d.Np = srad_np(e.n); d.Cp = srad_cp(e.cin);
-      d.tRp = srad_np(srad_round_up(e.cin, 4)); d.tKp = srad_cp(srad_round_up(e.n, 4));
-      d.tdst_off = (long long)h->t_off[i];
-      const long long f = (long long)d.Np * d.ntaps * d.Cp, t = (long long)d.tRp * d.ntaps * d.tKp;
-      work = f > t ? f : t;
-    }
-    d.blk0 = blk;
-    d.nblk = (unsigned)((work + SYNC_EPB - 1) / SYNC_EPB);
-    if (d.nblk == 0) d.nblk = 1;
-    blk += d.nblk;
-    descs.push_back(d);
-  }
-  h->n_sync_blocks = (int)blk;
-  h->tarena = reinterpret_cast<char*>(train_arena);
-  SRAD_CHECK_HIP(hipMemcpy(h->tarena + h->t_desc_off, descs.data(), descs.size() * sizeof(SyncDesc), hipMemcpyHostToDevice));
-  h->train_ready = false;
-  return SRAD_OK;
+  SRAD_REQUIRE(h, "train_bind: null argument");
+  return train_bind(h->pt, h->ts, train_arena, bytes);
 }
 
 // Refreshes every packed weight (forward and transposed) and raw parameter from the flat fp32 master buffer:
 // one launch, to be called after each optimizer step (and once after loading a checkpoint).
 int srad_drct_sync_params(srad_drct_t* h, const float* flat_params, void* stream) {
-  SRAD_REQUIRE(h && flat_params, "sync_params: null argument");
-  if (!h->tarena) return srad_set_error(SRAD_ERR_STATE, "sync_params: no training arena bound");
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const SyncDesc* descs = reinterpret_cast<const SyncDesc*>(h->tarena + h->t_desc_off);
-  SradProfScope prof(s, SRAD_K_PACK, 0.0, 4.0 * h->flat_total + 2.0 * (h->pt.bytes + h->t_bytes));
-  if (h->pt.prec == SRAD_PREC_BF16)
-    hipLaunchKernelGGL((sync_params_kernel<SRAD_PREC_BF16>), dim3(h->n_sync_blocks), dim3(256), 0, s, descs,
-                       (int)h->pt.entries.size(), flat_params, h->pt.arena, h->tarena);
-  else
-    hipLaunchKernelGGL((sync_params_kernel<SRAD_PREC_F32>), dim3(h->n_sync_blocks), dim3(256), 0, s, descs,
-                       (int)h->pt.entries.size(), flat_params, h->pt.arena, h->tarena);
-  SRAD_CHECK_HIP(hipGetLastError());
-  h->train_ready = true;
+  SRAD_REQUIRE(h, "sync_params: null argument");
+  SRAD_TRY(train_sync_params(h->pt, h->ts, flat_params, reinterpret_cast<hipStream_t>(stream)));
   h->gc.reset();
   return SRAD_OK;
 }
@@ -280,12 +159,12 @@ int srad_drct_num_buckets(const srad_drct_t* h) { return h ? h->cfg.n_rdg + 2 : 
 int srad_drct_bucket_range(srad_drct_t* h, int bucket, int64_t* off_floats, int64_t* n_floats) {
   SRAD_REQUIRE(h && off_floats && n_floats, "bucket_range: null argument");
   int64_t tot = 0;
-  SRAD_TRY(srad_drct_train_param_floats(h, &tot));
+  SRAD_TRY(train_param_floats(h->pt, h->ts, &tot));
   const int R = h->cfg.n_rdg;
   SRAD_REQUIRE(bucket >= 0 && bucket < R + 2, "bucket_range: bucket %d out of range", bucket);
-  auto start_of_rdg = [&](int i) { return i < R ? h->flat_off[h->blocks[i * 5].n1g] : h->flat_off[h->norm_g]; };
+  auto start_of_rdg = [&](int i) { return i < R ? h->ts.flat_off[h->blocks[i * 5].n1g] : h->ts.flat_off[h->norm_g]; };
   int64_t a, b;
-  if (bucket == 0) { a = h->flat_off[h->norm_g]; b = tot; }
+  if (bucket == 0) { a = h->ts.flat_off[h->norm_g]; b = tot; }
   else if (bucket <= R) { const int i = R - bucket; a = start_of_rdg(i); b = start_of_rdg(i + 1); }
   else { a = 0; b = start_of_rdg(0); }
   *off_floats = a; *n_floats = b - a;
@@ -413,9 +292,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
   const int stages = (int)h->up.size();
   int hh = H << stages, ww = W << stages;
   float* G = flat_grad;
-  WgradQueue wq;                          // split-K partials of the weight gradients, reduced once per Swin block
-  wq.ws = reinterpret_cast<float*>(h->tarena + h->t_wgrad_off);
-  wq.ws_floats = SRAD_WGRAD_WS_BYTES / sizeof(float);
+  WgradQueue wq = train_wgrad_queue(h->ts);   // split-K partials of the weight gradients, reduced once per Swin block
 
   // dLoss/d(outn) = dy / img_range, NCHW -> NHWC (pad channels zero)           (drct.py:897)
   SRAD_TRY(srad_launch_nchw_to_nhwc(dy, w.dimg, B, c.in_chans, SRAD_IMG_CPAD, hh, ww, zero3, 1.0f / c.img_range, s));
@@ -463,7 +340,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
   {  // norm                                                                      (drct.py:881)
     LnBwdParams l{};
     l.dxn = w.dbody; l.ld_dxn = E; l.x = w.dense[c.n_rdg]; l.ldx = D; l.gamma = h->pt.fptr(h->norm_g);
-    l.out = gn; l.ld_out = D; l.dgamma = G + h->flat_off[h->norm_g]; l.dbeta = G + h->flat_off[h->norm_b];
+    l.out = gn; l.ld_out = D; l.dgamma = G + h->ts.flat_off[h->norm_g]; l.dbeta = G + h->ts.flat_off[h->norm_b];
     l.rows = T; l.C = E; l.eps = 1e-5f;
     SRAD_TRY(srad_launch_ln_bwd(l, wq, s));
   }
@@ -517,7 +394,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
         LnBwdParams l{};
         l.dxn = w.dxn; l.ld_dxn = d; l.x = sv.x1; l.ldx = d; l.gamma = h->pt.fptr(sw.n2g);
         l.dres = w.dx2; l.ld_dres = d; l.out = w.dx1; l.ld_out = d;
-        l.dgamma = G + h->flat_off[sw.n2g]; l.dbeta = G + h->flat_off[sw.n2b];
+        l.dgamma = G + h->ts.flat_off[sw.n2g]; l.dbeta = G + h->ts.flat_off[sw.n2b];
         l.rows = T; l.C = d; l.eps = 1e-5f;
         SRAD_TRY(srad_launch_ln_bwd(l, wq, s));
       }
@@ -531,7 +408,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
       {
-        AttnBwdParams a{sv.qkv, w.dO, w.dqkv, h->pt.fptr(sw.table), G + h->flat_off[sw.table], B, H, W, c.window_size,
+        AttnBwdParams a{sv.qkv, w.dO, w.dqkv, h->pt.fptr(sw.table), G + h->ts.flat_off[sw.table], B, H, W, c.window_size,
                         sw.shift, d, sw.heads, hdp};
         SRAD_TRY(srad_launch_window_attn_bwd(a, wq, s));
       }
@@ -545,7 +422,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
         LnBwdParams l{};
         l.dxn = w.dxn; l.ld_dxn = d; l.x = cur; l.ldx = D; l.gamma = h->pt.fptr(sw.n1g);
         l.dres = w.dx1; l.ld_dres = d; l.out = gc; l.ld_out = D; l.accumulate = 1;
-        l.dgamma = G + h->flat_off[sw.n1g]; l.dbeta = G + h->flat_off[sw.n1b];
+        l.dgamma = G + h->ts.flat_off[sw.n1g]; l.dbeta = G + h->ts.flat_off[sw.n1b];
         l.rows = T; l.C = d; l.eps = 1e-5f;
         SRAD_TRY(srad_launch_ln_bwd(l, wq, s));
       }
@@ -558,7 +435,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
     LnBwdParams l{};
     l.dxn = gn; l.ld_dxn = D; l.x = w.feat0; l.ldx = E; l.gamma = h->pt.fptr(h->pe_g);
     l.dres = w.dc1; l.ld_dres = E; l.out = w.dfeat; l.ld_out = E;
-    l.dgamma = G + h->flat_off[h->pe_g]; l.dbeta = G + h->flat_off[h->pe_b];
+    l.dgamma = G + h->ts.flat_off[h->pe_g]; l.dbeta = G + h->ts.flat_off[h->pe_b];
     l.rows = T; l.C = E; l.eps = 1e-5f;
     SRAD_TRY(srad_launch_ln_bwd(l, wq, s));
   }

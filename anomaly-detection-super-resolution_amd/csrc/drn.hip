@@ -8,7 +8,7 @@
 // The MeanShift layers are 1x1 convs with TRAINABLE weights in the reference (the requires_grad
 // assignment there is a no-op), so they are applied as full CxC matrices, fused into the bicubic
 // upsampler (sub_mean) and into the NHWC->NCHW output kernel (add_mean).
-#include "engine.h"
+#include "train_common.h"
 #include "../../include/srad.h"
 #include <math.h>
 #include <new>
@@ -20,7 +20,8 @@ __device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * 
 __device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
 
 __global__ void bicubic_submean_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int H, int W,
-                                       int scale, const float* __restrict__ mw, const float* __restrict__ mb) {
+                                       int scale, const float* __restrict__ mw, const float* __restrict__ mb,
+                                       float* __restrict__ raw /* training: the upsampled image before sub_mean */) {
   const int Ho = H * scale, Wo = W * scale;
   const size_t total = (size_t)B * Ho * Wo;
   const float A = -0.75f, rs = 1.0f / (float)scale;
@@ -54,6 +55,7 @@ __global__ void bicubic_submean_kernel(const float* __restrict__ x, float* __res
       o[co] = acc;
     }
     *reinterpret_cast<float4*>(y + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    if (raw) *reinterpret_cast<float4*>(raw + i * 4) = make_float4(v[0], v[1], v[2], 0.f);
   }
 }
 
@@ -137,6 +139,7 @@ struct srad_drn {
   std::vector<ConvW> up_conv, up_1x1;           // per phase
   std::vector<ConvW> tail;                      // phase + 1
   GraphCache gc;
+  TrainState ts;                                // training (second half of this file)
 };
 
 namespace {
@@ -236,7 +239,7 @@ int forward_body(srad_drn* h, const float* x, int B, int H, int W, float* const*
     const size_t tot = (size_t)B * H0 * W0;
     SradProfScope prof(s, SRAD_K_MISC, 40.0 * tot * C, 4.0 * tot * (4 + C));
     hipLaunchKernelGGL(bicubic_submean_kernel, dim3(grid1d(tot)), dim3(256), 0, s, x, w.up0, B, C, H, W, sc,
-                       h->pt.fptr(h->sub_w), h->pt.fptr(h->sub_b));
+                       h->pt.fptr(h->sub_w), h->pt.fptr(h->sub_b), (float*)nullptr);
     SRAD_CHECK_HIP(hipGetLastError());
   }
   // head -> copies[0], stored in cat[0][:, F:2F]               (drn.py:247, 252)
@@ -516,6 +519,614 @@ int srad_dual_forward(const float* w0, const float* w1, int C, int n_feats, floa
   b.Y = outn; b.ldy = SRAD_IMG_CPAD;
   SRAD_TRY(srad_launch_gemm(precision, b, s));
   return srad_launch_nhwc_to_nchw(outn, SRAD_IMG_CPAD, y, B, C, H2, W2, zero3, 1.0f, s);
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+// Training: DRN forward with saved activations + backward (reference src/trainer.py:161-205 on src/drn.py),
+// and the backward of the dual regression model (src/model.py:8-44).  Same plumbing as the DRCT training engine:
+// flat fp32 parameter / gradient buffers, data gradients = the forward GEMM on transposed packs, weight gradients
+// through the split-K queue.  The stride-2 convolutions' data gradient is the stride-1 transposed convolution of
+// the gradient with zeros inserted between its pixels.
+// =====================================================================================================
+namespace {
+
+// Z[b][2 oy][2 ox][c] = dY[b][oy][ox][c], all other pixels 0                  (stride-2 conv backward)
+__global__ void zero_upsample_kernel(const float* __restrict__ dy, float* __restrict__ z, int B, int Ho, int Wo, int C) {
+  const int c4n = C / 4;
+  const size_t total = (size_t)B * 2 * Ho * 2 * Wo * c4n;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    size_t pix = i / c4n;
+    const int x = (int)(pix % (2 * Wo)); pix /= 2 * Wo;
+    const int y = (int)(pix % (2 * Ho));
+    const int b = (int)(pix / (2 * Ho));
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!(x & 1) && !(y & 1)) v = *reinterpret_cast<const f32x4*>(dy + (((size_t)b * Ho + (y >> 1)) * Wo + (x >> 1)) * C + c4 * 4);
+    *reinterpret_cast<f32x4*>(z + i * 4) = v;
+  }
+}
+
+// partial[b][chunk][c] = sum over the chunk's pixels of g[pix][c] * r[pix][c]     (channel-attention gate gradient)
+__global__ __launch_bounds__(256) void pool_dot_kernel(const float* __restrict__ g, const float* __restrict__ r, float* __restrict__ part,
+                                                       int hw, int C, int nchunk) {
+  __shared__ float red[256 * 4];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int c4n = C / 4, nph = 256 / c4n;
+  const int c4 = threadIdx.x % c4n, ph = threadIdx.x / c4n;
+  const int per = (hw + nchunk - 1) / nchunk;
+  const int p0 = chunk * per, p1 = min(hw, p0 + per);
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (ph < nph)
+    for (int px = p0 + ph; px < p1; px += nph) {
+      const size_t o = ((size_t)b * hw + px) * C + c4 * 4;
+      acc += *reinterpret_cast<const f32x4*>(g + o) * *reinterpret_cast<const f32x4*>(r + o);
+    }
+  *reinterpret_cast<f32x4*>(red + threadIdx.x * 4) = acc;
+  __syncthreads();
+  if (threadIdx.x < c4n) {
+    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < nph; ++q) t += *reinterpret_cast<const f32x4*>(red + (q * c4n + threadIdx.x) * 4);
+    *reinterpret_cast<f32x4*>(part + ((size_t)b * nchunk + chunk) * C + threadIdx.x * 4) = t;
+  }
+}
+
+// CALayer backward (src/drn.py:123-139) for all images of the batch in ONE workgroup (the work is C * C/16 MACs per
+// image): dgate = sum of the pool_dot partials; through the sigmoid, the two 1x1 convs and the ReLU back to the mean;
+// dpool[b][c] = dmean[c] / HW.  Weight / bias gradients are summed over the images in LDS and added to the flat
+// gradient buffer without atomics.
+__global__ __launch_bounds__(256) void ca_bwd_kernel(const float* __restrict__ part, int nchunk, const float* __restrict__ pool,
+                                                     const float* __restrict__ gate, float inv_hw, int B, int C, int Cr,
+                                                     const float* __restrict__ w1, const float* __restrict__ b1,
+                                                     const float* __restrict__ w2, float* __restrict__ dw1,
+                                                     float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
+                                                     float* __restrict__ dpool) {
+  __shared__ float mean[512], s[512], hid[64], dhid[64];
+  __shared__ float a_w1[512 * 8], a_w2[512 * 8];     // C * Cr <= 4096 entries each
+  __shared__ float a_b1[64], a_b2[512];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < C * Cr; i += 256) { a_w1[i] = 0.f; a_w2[i] = 0.f; }
+  for (int i = tid; i < C; i += 256) a_b2[i] = 0.f;
+  if (tid < Cr) a_b1[tid] = 0.f;
+  __syncthreads();
+  for (int b = 0; b < B; ++b) {
+    for (int c = tid; c < C; c += 256) {
+      float dg = 0.f;
+      for (int k = 0; k < nchunk; ++k) dg += part[((size_t)b * nchunk + k) * C + c];
+      const float gt = gate[(size_t)b * C + c];
+      s[c] = dg * gt * (1.f - gt);                       // through the sigmoid
+      mean[c] = pool[(size_t)b * C + c] * inv_hw;
+    }
+    __syncthreads();
+    if (tid < Cr) {
+      float acc = b1[tid];
+      for (int c = 0; c < C; ++c) acc += w1[tid * C + c] * mean[c];
+      hid[tid] = fmaxf(acc, 0.f);
+      float dh = 0.f;
+      for (int c = 0; c < C; ++c) dh += s[c] * w2[c * Cr + tid];
+      dhid[tid] = acc > 0.f ? dh : 0.f;
+      a_b1[tid] += dhid[tid];
+    }
+    __syncthreads();
+    for (int i = tid; i < C * Cr; i += 256) {
+      const int c = i / Cr, j = i - c * Cr;              // w2 [C][Cr]
+      a_w2[i] += s[c] * hid[j];
+      const int j1 = i / C, c1 = i - j1 * C;             // w1 [Cr][C]
+      a_w1[i] += dhid[j1] * mean[c1];
+    }
+    for (int c = tid; c < C; c += 256) {
+      a_b2[c] += s[c];
+      float dm = 0.f;
+      for (int j = 0; j < Cr; ++j) dm += dhid[j] * w1[j * C + c];
+      dpool[(size_t)b * C + c] = dm * inv_hw;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < C * Cr; i += 256) { dw1[i] += a_w1[i]; dw2[i] += a_w2[i]; }
+  for (int c = tid; c < C; c += 256) db2[c] += a_b2[c];
+  if (tid < Cr) db1[tid] += a_b1[tid];
+}
+
+// dr = g * gate[b] + dpool[b]                                                   (RCAB: r * gate + x, drn.py:139,156)
+__global__ void ca_apply_bwd_kernel(const float* __restrict__ g, const float* __restrict__ gate, const float* __restrict__ dpool,
+                                    float* __restrict__ dr, size_t T, int C, int hw) {
+  const int c4n = C / 4;
+  const size_t total = T * c4n;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = i / c4n;
+    const int c = (int)(i - pix * c4n) * 4;
+    const int b = (int)(pix / hw);
+    *reinterpret_cast<f32x4*>(dr + pix * C + c) = *reinterpret_cast<const f32x4*>(g + pix * C + c) *
+                                                      *reinterpret_cast<const f32x4*>(gate + (size_t)b * C + c) +
+                                                  *reinterpret_cast<const f32x4*>(dpool + (size_t)b * C + c);
+  }
+}
+
+// dst[m][0..C) += src[m][0..C)
+__global__ void add_cols_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst, size_t rows, int C) {
+  const int c4n = C / 4;
+  const size_t total = rows * c4n;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t m = i / c4n;
+    const int c = (int)(i - m * c4n) * 4;
+    f32x4* d = reinterpret_cast<f32x4*>(dst + m * ld_dst + c);
+    *d = *d + *reinterpret_cast<const f32x4*>(src + m * ld_src + c);
+  }
+}
+
+// MeanShift backward (1x1 conv CxC + bias, trainable in the reference): dt = W^T dy (optional), dW += dy (x) t, db += dy.
+// dy comes either as NCHW (add_mean, the network outputs) or as NHWC[4] rows (sub_mean); t is NHWC[ldt].
+__global__ __launch_bounds__(256) void affine_bwd_kernel(const float* __restrict__ dy_nchw, const float* __restrict__ dy_rows,
+                                                         const float* __restrict__ t, int ldt, float* __restrict__ dt, int B,
+                                                         int C, int HW, const float* __restrict__ w, float* __restrict__ dw,
+                                                         float* __restrict__ db) {
+  __shared__ float red[12 * 256];
+  float a[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) a[k] = 0.f;
+  const size_t total = (size_t)B * HW;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / HW);
+    const int hw = (int)(i - (size_t)b * HW);
+    float d[3] = {0.f, 0.f, 0.f}, tv[3] = {0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) {
+      d[c] = dy_nchw ? dy_nchw[((size_t)b * C + c) * HW + hw] : dy_rows[i * 4 + c];
+      tv[c] = t[i * ldt + c];
+    }
+    for (int c = 0; c < C; ++c) {
+      for (int c2 = 0; c2 < C; ++c2) a[c * 3 + c2] += d[c] * tv[c2];
+      a[9 + c] += d[c];
+    }
+    if (dt) {
+      float o[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int c2 = 0; c2 < C; ++c2)
+        for (int c = 0; c < C; ++c) o[c2] += w[c * C + c2] * d[c];
+      *reinterpret_cast<float4*>(dt + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 12; ++k) red[k * 256 + threadIdx.x] = a[k];
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    float sum = 0.f;
+    for (int q = 0; q < 256; ++q) sum += red[threadIdx.x * 256 + q];
+    const int k = threadIdx.x;
+    if (k < 9) { if (k / 3 < C && k % 3 < C) atomicAdd(dw + (k / 3) * C + (k % 3), sum); }
+    else if (k - 9 < C) atomicAdd(db + (k - 9), sum);
+  }
+}
+
+struct RcabSave { float *t, *r, *xo, *gate, *pool; };
+
+struct DrnTrainWs {
+  float *uraw, *up0, *deep;
+  std::vector<float*> cat, dtmp, ups, timg;
+  std::vector<std::vector<RcabSave>> rc;
+  // backward
+  float *gdeep, *ga, *gb, *dr, *dt, *dups, *dus, *ddtmp, *zup, *dtimg, *dup0, *ppart, *dpool;
+  std::vector<float*> gcat;
+  size_t bytes;
+};
+
+constexpr int DRN_POOL_CHUNKS = 32;
+
+DrnTrainWs plan_train_ws(const srad_drn* h, int B, int H, int W, void* base, size_t cap) {
+  const srad_drn_config& c = h->cfg;
+  const int P = h->phase, F = c.n_feats, s = c.scale, top = F << P;
+  const size_t T0 = (size_t)B * H * s * W * s;
+  Bump bp(base, cap);
+  DrnTrainWs w;
+  w.uraw = bp.take(T0 * SRAD_IMG_CPAD);
+  w.up0 = bp.take(T0 * SRAD_IMG_CPAD);
+  for (int L = 0; L < P; ++L) w.cat.push_back(bp.take((T0 >> (2 * L)) * 2 * (F << L)));
+  const size_t TP = T0 >> (2 * P);
+  w.deep = bp.take(TP * top);
+  for (int L = 0; L < P; ++L) w.dtmp.push_back(bp.take((T0 >> (2 * (L + 1))) * (F << L)));
+  size_t rmax = 0, umax = 0;
+  w.rc.resize(P);
+  for (int idx = 0; idx < P; ++idx) {
+    const int lvl = P - idx;
+    const int ch = h->rcab[idx][0].ch;
+    const size_t T = T0 >> (2 * lvl);
+    for (int b = 0; b < c.n_blocks; ++b) {
+      RcabSave r;
+      r.t = bp.take(T * ch); r.r = bp.take(T * ch); r.xo = bp.take(T * ch);
+      r.gate = bp.take((size_t)B * ch); r.pool = bp.take((size_t)B * ch);
+      w.rc[idx].push_back(r);
+    }
+    w.ups.push_back(bp.take(4 * T * ch));
+    if (T * ch > rmax) rmax = T * ch;
+    if (4 * T * ch > umax) umax = 4 * T * ch;
+  }
+  for (int j = 0; j <= P; ++j) w.timg.push_back(bp.take((T0 >> (2 * (P - j))) * SRAD_IMG_CPAD));
+  // backward
+  for (int L = 0; L < P; ++L) w.gcat.push_back(bp.take((T0 >> (2 * L)) * 2 * (F << L)));
+  w.gdeep = bp.take(TP * top);
+  w.ga = bp.take(rmax); w.gb = bp.take(rmax); w.dr = bp.take(rmax); w.dt = bp.take(rmax);
+  w.dups = bp.take(umax); w.dus = bp.take(umax);
+  w.ddtmp = bp.take((T0 >> 2) * F);
+  w.zup = bp.take(T0 * F);
+  w.dtimg = bp.take(T0 * SRAD_IMG_CPAD);
+  w.dup0 = bp.take(T0 * SRAD_IMG_CPAD);
+  w.ppart = bp.take((size_t)B * DRN_POOL_CHUNKS * top);
+  w.dpool = bp.take((size_t)B * top);
+  w.bytes = bp.used;
+  return w;
+}
+
+int drn_train_check(const srad_drn* h, int B, int H, int W) {
+  SRAD_REQUIRE(h->ts.ready, "drn training: call srad_drn_train_bind() and srad_drn_sync_params() first");
+  SRAD_REQUIRE(h->cfg.n_feats % 4 == 0, "drn training: n_feats must be a multiple of 4 (got %d)", h->cfg.n_feats);
+  const int top = h->cfg.n_feats << h->phase;
+  SRAD_REQUIRE(top * (top / 16) <= 4096 && top <= 512, "drn training: channel attention too wide for the backward kernel");
+  return drn_check_shape(h, B, H, W);
+}
+
+GemmParams drn_dgrad(const srad_drn* h, const ConvW& c, const float* dY, int ldy, int B, int Hh, int Ww, float* dX, int ldx, int xoff) {
+  GemmParams p{};
+  const int npad = srad_round_up(c.n, 4), cpad = srad_round_up(c.cin, 4);
+  p.Hi = p.Ho = Hh; p.Wi = p.Wo = Ww; p.stride = 1;
+  p.X = dY; p.ldx = ldy; p.M = B * Hh * Ww; p.Cin = npad; p.Cp = srad_cp(npad); p.ntaps = c.ntaps; p.ln_eps = 1e-5f;
+  p.Wp = h->ts.tarena + h->ts.t_off[c.w]; p.N = cpad; p.alpha = 1.f;
+  p.Y = dX; p.ldy = ldx; p.yoff = xoff;
+  return p;
+}
+void accumulate_into(GemmParams& p) { p.R = p.Y + p.yoff; p.ldr = p.ldy; p.rmode = SRAD_RMODE_ADD; }
+
+WgradParams drn_wgrad(const srad_drn* h, const ConvW& c, float* G, const float* dY, int ldy, int ycol0, const float* X, int ldx,
+                      int B, int Hi, int Wi, int stride) {
+  WgradParams p{};
+  const int pad = c.ntaps == 9 ? 1 : 0, k = c.ntaps == 9 ? 3 : 1;
+  p.Hi = Hi; p.Wi = Wi; p.Ho = (Hi + 2 * pad - k) / stride + 1; p.Wo = (Wi + 2 * pad - k) / stride + 1; p.stride = stride;
+  p.dY = dY; p.ldy = ldy; p.ycol0 = ycol0; p.X = X; p.ldx = ldx; p.M = B * p.Ho * p.Wo;
+  p.N = srad_round_up(c.n, 4); p.Cin = srad_round_up(c.cin, 4); p.ntaps = c.ntaps;
+  p.n_real = c.n; p.cin_real = c.cin; p.alpha = 1.f;
+  p.dW = G + h->ts.flat_off[c.w];
+  p.db = c.b >= 0 ? G + h->ts.flat_off[c.b] : nullptr;
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int srad_drn_train_param_floats(srad_drn_t* h, int64_t* total) {
+  SRAD_REQUIRE(h && total, "train_param_floats: null argument");
+  return train_param_floats(h->pt, h->ts, total);
+}
+int srad_drn_train_param_offset(srad_drn_t* h, int idx, int64_t* off_floats) {
+  int64_t tot = 0;
+  SRAD_REQUIRE(h, "train_param_offset: null argument");
+  SRAD_TRY(train_param_floats(h->pt, h->ts, &tot));
+  SRAD_REQUIRE(off_floats && idx >= 0 && idx < (int)h->pt.entries.size(), "train_param_offset: index %d out of range", idx);
+  *off_floats = h->ts.flat_off[idx];
+  return SRAD_OK;
+}
+int srad_drn_train_arena_bytes(srad_drn_t* h, size_t* bytes) {
+  SRAD_REQUIRE(h && bytes, "train_arena_bytes: null argument");
+  return train_arena_bytes(h->pt, h->ts, bytes);
+}
+int srad_drn_train_bind(srad_drn_t* h, void* train_arena, size_t bytes) {
+  SRAD_REQUIRE(h, "train_bind: null argument");
+  return train_bind(h->pt, h->ts, train_arena, bytes);
+}
+int srad_drn_sync_params(srad_drn_t* h, const float* flat_params, void* stream) {
+  SRAD_REQUIRE(h, "sync_params: null argument");
+  SRAD_TRY(train_sync_params(h->pt, h->ts, flat_params, reinterpret_cast<hipStream_t>(stream)));
+  h->gc.reset();
+  return SRAD_OK;
+}
+int srad_drn_train_workspace_bytes(const srad_drn_t* h, int B, int H, int W, size_t* bytes) {
+  SRAD_REQUIRE(h && bytes && B > 0 && H > 0 && W > 0, "train_workspace_bytes: bad argument");
+  *bytes = plan_train_ws(h, B, H, W, nullptr, 0).bytes;
+  return SRAD_OK;
+}
+
+// Training-mode DRN.forward (src/drn.py:241-270): as srad_drn_forward, every tensor the backward needs stays in `workspace`.
+int srad_drn_forward_train(srad_drn_t* h, const float* x, int B, int H, int W, float* const* ys, int n_out, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  SRAD_REQUIRE(h && x && ys && workspace, "drn_forward_train: null argument");
+  SRAD_REQUIRE(n_out == h->phase + 1, "drn_forward_train: %d outputs given, the model returns %d", n_out, h->phase + 1);
+  SRAD_TRY(drn_train_check(h, B, H, W));
+  SRAD_REQUIRE(((uintptr_t)workspace & 255) == 0, "drn_forward_train: workspace must be 256-byte aligned");
+  const DrnTrainWs w = plan_train_ws(h, B, H, W, workspace, workspace_bytes);
+  SRAD_REQUIRE(w.bytes <= workspace_bytes, "drn_forward_train: workspace %zu bytes, %zu needed", workspace_bytes, w.bytes);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const srad_drn_config& c = h->cfg;
+  const int prec = c.precision, P = h->phase, F = c.n_feats, sc = c.scale, C = c.n_colors;
+  const int H0 = H * sc, W0 = W * sc, top = F << P;
+  {
+    const size_t tot = (size_t)B * H0 * W0;
+    hipLaunchKernelGGL(bicubic_submean_kernel, dim3(grid1d(tot)), dim3(256), 0, s, x, w.up0, B, C, H, W, sc,
+                       h->pt.fptr(h->sub_w), h->pt.fptr(h->sub_b), w.uraw);
+    SRAD_CHECK_HIP(hipGetLastError());
+  }
+  {
+    GemmParams p = conv_params(h, h->head, w.up0, SRAD_IMG_CPAD, B, H0, W0, 1, w.cat[0], 2 * F, F);
+    p.Cin = SRAD_IMG_CPAD;
+    SRAD_TRY(srad_launch_gemm(prec, p, s));
+  }
+  for (int L = 0; L < P; ++L) {
+    const int f = F << L, Hl = H0 >> L, Wl = W0 >> L;
+    GemmParams p = conv_params(h, h->down_s2[L], w.cat[L] + f, 2 * f, B, Hl, Wl, 2, w.dtmp[L], f, 0);
+    p.act = SRAD_ACT_LRELU; p.slope = c.negval;
+    SRAD_TRY(srad_launch_gemm(prec, p, s));
+    float* dst = L + 1 < P ? w.cat[L + 1] : w.deep;
+    const int f1 = F << (L + 1);
+    GemmParams q = conv_params(h, h->down_s1[L], w.dtmp[L], f, B, Hl / 2, Wl / 2, 1, dst, L + 1 < P ? 2 * f1 : f1, L + 1 < P ? f1 : 0);
+    SRAD_TRY(srad_launch_gemm(prec, q, s));
+  }
+  auto tail_out = [&](int j, const float* X, int ldx, int Hh, int Ww) -> int {
+    GemmParams p = conv_params(h, h->tail[j], X, ldx, B, Hh, Ww, 1, w.timg[j], SRAD_IMG_CPAD, 0);
+    SRAD_TRY(srad_launch_gemm(prec, p, s));
+    const size_t tot = (size_t)B * Hh * Ww;
+    hipLaunchKernelGGL(affine_to_nchw_kernel, dim3(grid1d(tot)), dim3(256), 0, s, w.timg[j], SRAD_IMG_CPAD, ys[j], B, C, Hh * Ww,
+                       h->pt.fptr(h->add_w), h->pt.fptr(h->add_b));
+    SRAD_CHECK_HIP(hipGetLastError());
+    return SRAD_OK;
+  };
+  SRAD_TRY(tail_out(0, w.deep, top, H0 >> P, W0 >> P));
+  const float* xin = w.deep;
+  int ldin = top;
+  for (int idx = 0; idx < P; ++idx) {
+    const int lvl = P - idx, Hl = H0 >> lvl, Wl = W0 >> lvl;
+    const int ch = h->rcab[idx][0].ch;
+    const size_t T = (size_t)B * Hl * Wl;
+    for (int b = 0; b < c.n_blocks; ++b) {
+      const RcabW& r = h->rcab[idx][b];
+      const RcabSave& sv = w.rc[idx][b];
+      SRAD_CHECK_HIP(hipMemsetAsync(sv.pool, 0, (size_t)B * ch * sizeof(float), s));
+      {
+        GemmParams p = conv_params(h, r.c0, xin, ldin, B, Hl, Wl, 1, sv.t, ch, 0);
+        p.act = SRAD_ACT_RELU;
+        SRAD_TRY(srad_launch_gemm(prec, p, s));
+      }
+      {
+        GemmParams p = conv_params(h, r.c1, sv.t, ch, B, Hl, Wl, 1, sv.r, ch, 0);
+        p.pool = sv.pool;
+        SRAD_TRY(srad_launch_gemm(prec, p, s));
+      }
+      hipLaunchKernelGGL(ca_gate_kernel, dim3(B), dim3(128), 0, s, sv.pool, 1.0f / (float)(Hl * Wl), ch, ch / 16,
+                         h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2), sv.gate);
+      hipLaunchKernelGGL(scale_add_kernel, dim3(grid1d(T * ch / 4)), dim3(256), 0, s, sv.r, sv.gate, xin, ldin, sv.xo, T, ch, Hl * Wl);
+      SRAD_CHECK_HIP(hipGetLastError());
+      xin = sv.xo; ldin = ch;
+    }
+    const int cout = F << (lvl - 1);
+    {
+      GemmParams p = conv_params(h, h->up_conv[idx], xin, ldin, B, Hl, Wl, 1, w.ups[idx], ch, 0);
+      p.ps = 2;
+      SRAD_TRY(srad_launch_gemm(prec, p, s));
+    }
+    {
+      GemmParams p = conv_params(h, h->up_1x1[idx], w.ups[idx], ch, B, 2 * Hl, 2 * Wl, 1, w.cat[lvl - 1], 2 * cout, 0);
+      SRAD_TRY(srad_launch_gemm(prec, p, s));
+    }
+    xin = w.cat[lvl - 1];
+    ldin = 2 * cout;
+    SRAD_TRY(tail_out(idx + 1, xin, ldin, 2 * Hl, 2 * Wl));
+  }
+  return SRAD_OK;
+}
+
+// Backward of srad_drn_forward_train: dys[j] = dLoss/d(output j) (NCHW, null = this output does not enter the loss);
+// parameter gradients are ACCUMULATED into flat_grad (offsets as the flat parameter buffer).
+int srad_drn_backward(srad_drn_t* h, const float* const* dys, int n_out, int B, int H, int W, float* flat_grad,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+  SRAD_REQUIRE(h && dys && flat_grad && workspace, "drn_backward: null argument");
+  SRAD_REQUIRE(n_out == h->phase + 1, "drn_backward: %d gradients given, the model returns %d outputs", n_out, h->phase + 1);
+  SRAD_TRY(drn_train_check(h, B, H, W));
+  const DrnTrainWs w = plan_train_ws(h, B, H, W, workspace, workspace_bytes);
+  SRAD_REQUIRE(w.bytes <= workspace_bytes, "drn_backward: workspace %zu bytes, %zu needed", workspace_bytes, w.bytes);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const srad_drn_config& c = h->cfg;
+  const int prec = c.precision, P = h->phase, F = c.n_feats, sc = c.scale, C = c.n_colors;
+  const int H0 = H * sc, W0 = W * sc, top = F << P;
+  const size_t T0 = (size_t)B * H0 * W0;
+  float* G = flat_grad;
+  WgradQueue wq = train_wgrad_queue(h->ts);
+
+  for (int L = 0; L < P; ++L) SRAD_CHECK_HIP(hipMemsetAsync(w.gcat[L], 0, (T0 >> (2 * L)) * 2 * (F << L) * sizeof(float), s));
+  SRAD_CHECK_HIP(hipMemsetAsync(w.gdeep, 0, (T0 >> (2 * P)) * top * sizeof(float), s));
+
+  // ---- tails + add_mean (drn.py:256-258, 265-267): every output's gradient lands in the buffer its tail conv read ----
+  for (int j = 0; j <= P; ++j) {
+    if (!dys[j]) continue;
+    const int lvl_in = j == 0 ? P : P - j;                 // level of the pixels the tail conv runs on
+    const int Hh = H0 >> lvl_in, Ww = W0 >> lvl_in;
+    const float* X = j == 0 ? w.deep : w.cat[lvl_in];
+    float* GX = j == 0 ? w.gdeep : w.gcat[lvl_in];
+    const int ld = j == 0 ? top : 2 * (F << lvl_in);
+    const size_t tot = (size_t)B * Hh * Ww;
+    hipLaunchKernelGGL(affine_bwd_kernel, dim3(grid1d(tot) > 256 ? 256 : grid1d(tot)), dim3(256), 0, s, dys[j], (const float*)nullptr,
+                       w.timg[j], SRAD_IMG_CPAD, w.dtimg, B, C, Hh * Ww, h->pt.fptr(h->add_w), G + h->ts.flat_off[h->add_w],
+                       G + h->ts.flat_off[h->add_b]);
+    SRAD_CHECK_HIP(hipGetLastError());
+    WgradParams g = drn_wgrad(h, h->tail[j], G, w.dtimg, SRAD_IMG_CPAD, 0, X, ld, B, Hh, Ww, 1);
+    SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
+    GemmParams p = drn_dgrad(h, h->tail[j], w.dtimg, SRAD_IMG_CPAD, B, Hh, Ww, GX, ld, 0);
+    accumulate_into(p);
+    SRAD_TRY(srad_launch_gemm(prec, p, s));
+    SRAD_TRY(srad_wgrad_flush(wq, s));                       // dtimg is reused by the next output
+  }
+
+  // ---- up phases, finest first (drn.py:260-268) ----
+  for (int idx = P - 1; idx >= 0; --idx) {
+    const int lvl = P - idx, Hl = H0 >> lvl, Wl = W0 >> lvl;
+    const int ch = h->rcab[idx][0].ch;
+    const size_t T = (size_t)B * Hl * Wl;
+    const int cout = F << (lvl - 1);
+    const float* drive = w.gcat[lvl - 1];                    // columns [0, cout): gradient of the 1x1 conv's output
+    {
+      WgradParams g = drn_wgrad(h, h->up_1x1[idx], G, drive, 2 * cout, 0, w.ups[idx], ch, B, 2 * Hl, 2 * Wl, 1);
+      SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
+      GemmParams p = drn_dgrad(h, h->up_1x1[idx], drive, 2 * cout, B, 2 * Hl, 2 * Wl, w.dups, ch, 0);
+      SRAD_TRY(srad_launch_gemm(prec, p, s));
+    }
+    SRAD_TRY(srad_launch_unshuffle(w.dups, w.dus, B, Hl, Wl, ch, s));
+    const float* chain_out = w.rc[idx][c.n_blocks - 1].xo;
+    {
+      WgradParams g = drn_wgrad(h, h->up_conv[idx], G, w.dus, 4 * ch, 0, chain_out, ch, B, Hl, Wl, 1);
+      SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
+      GemmParams p = drn_dgrad(h, h->up_conv[idx], w.dus, 4 * ch, B, Hl, Wl, w.ga, ch, 0);
+      SRAD_TRY(srad_launch_gemm(prec, p, s));
+    }
+    float* ga = w.ga;
+    float* gb = w.gb;
+    const float* x0 = idx == 0 ? w.deep : w.cat[lvl];       // input of the first RCAB
+    const int ld0 = idx == 0 ? top : ch;
+    for (int b = c.n_blocks - 1; b >= 0; --b) {              // RCAB (drn.py:143-158)
+      const RcabW& r = h->rcab[idx][b];
+      const RcabSave& sv = w.rc[idx][b];
+      const float* xin = b == 0 ? x0 : w.rc[idx][b - 1].xo;
+      const int ldin = b == 0 ? ld0 : ch;
+      hipLaunchKernelGGL(pool_dot_kernel, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, ga, sv.r, w.ppart, Hl * Wl, ch, DRN_POOL_CHUNKS);
+      hipLaunchKernelGGL(ca_bwd_kernel, dim3(1), dim3(256), 0, s, w.ppart, DRN_POOL_CHUNKS, sv.pool, sv.gate, 1.0f / (float)(Hl * Wl), B,
+                         ch, ch / 16, h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), G + h->ts.flat_off[r.w1],
+                         G + h->ts.flat_off[r.b1], G + h->ts.flat_off[r.w2], G + h->ts.flat_off[r.b2], w.dpool);
+      hipLaunchKernelGGL(ca_apply_bwd_kernel, dim3(grid1d(T * ch / 4)), dim3(256), 0, s, ga, sv.gate, w.dpool, w.dr, T, ch, Hl * Wl);
+      SRAD_CHECK_HIP(hipGetLastError());
+      {
+        WgradParams g = drn_wgrad(h, r.c1, G, w.dr, ch, 0, sv.t, ch, B, Hl, Wl, 1);
+        SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
+        GemmParams p = drn_dgrad(h, r.c1, w.dr, ch, B, Hl, Wl, w.dt, ch, 0);
+        p.R = sv.t; p.ldr = ch; p.rmode = SRAD_RMODE_DLRELU; p.slope = 0.f;           // through the ReLU
+        SRAD_TRY(srad_launch_gemm(prec, p, s));
+      }
+      {
+        WgradParams g = drn_wgrad(h, r.c0, G, w.dt, ch, 0, xin, ldin, B, Hl, Wl, 1);
+        SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
+        GemmParams p = drn_dgrad(h, r.c0, w.dt, ch, B, Hl, Wl, gb, ch, 0);
+        p.R = ga; p.ldr = ch;                                                        // + the skip path
+        SRAD_TRY(srad_launch_gemm(prec, p, s));
+      }
+      SRAD_TRY(srad_wgrad_flush(wq, s));
+      float* t = ga; ga = gb; gb = t;
+    }
+    // gradient of the chain's input: deep (idx 0) or the concat buffer of this level
+    float* GX = idx == 0 ? w.gdeep : w.gcat[lvl];
+    hipLaunchKernelGGL(add_cols_kernel, dim3(grid1d(T * ch / 4)), dim3(256), 0, s, ga, ch, GX, ch, T, ch);
+    SRAD_CHECK_HIP(hipGetLastError());
+  }
+
+  // ---- down path (drn.py:250-253, DownBlock 83-119) ----
+  for (int L = P - 1; L >= 0; --L) {
+    const int f = F << L, f1 = F << (L + 1), Hl = H0 >> L, Wl = W0 >> L;
+    const float* gout = L + 1 < P ? w.gcat[L + 1] + f1 : w.gdeep;
+    const int ldg = L + 1 < P ? 2 * f1 : f1;
+    {
+      WgradParams g = drn_wgrad(h, h->down_s1[L], G, gout, ldg, 0, w.dtmp[L], f, B, Hl / 2, Wl / 2, 1);
+      SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
+      GemmParams p = drn_dgrad(h, h->down_s1[L], gout, ldg, B, Hl / 2, Wl / 2, w.ddtmp, f, 0);
+      p.R = w.dtmp[L]; p.ldr = f; p.rmode = SRAD_RMODE_DLRELU; p.slope = c.negval;     // through the LeakyReLU
+      SRAD_TRY(srad_launch_gemm(prec, p, s));
+    }
+    {
+      WgradParams g = drn_wgrad(h, h->down_s2[L], G, w.ddtmp, f, 0, w.cat[L] + f, 2 * f, B, Hl, Wl, 2);
+      SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
+      const size_t tot = (size_t)B * Hl * Wl * f / 4;
+      hipLaunchKernelGGL(zero_upsample_kernel, dim3(grid1d(tot)), dim3(256), 0, s, w.ddtmp, w.zup, B, Hl / 2, Wl / 2, f);
+      SRAD_CHECK_HIP(hipGetLastError());
+      GemmParams p = drn_dgrad(h, h->down_s2[L], w.zup, f, B, Hl, Wl, w.gcat[L], 2 * f, f);
+      accumulate_into(p);
+      SRAD_TRY(srad_launch_gemm(prec, p, s));
+    }
+    SRAD_TRY(srad_wgrad_flush(wq, s));
+  }
+  // ---- head + sub_mean (drn.py:243-247) ----
+  {
+    WgradParams g = drn_wgrad(h, h->head, G, w.gcat[0] + F, 2 * F, 0, w.up0, SRAD_IMG_CPAD, B, H0, W0, 1);
+    SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
+    GemmParams p = drn_dgrad(h, h->head, w.gcat[0] + F, 2 * F, B, H0, W0, w.dup0, SRAD_IMG_CPAD, 0);
+    SRAD_TRY(srad_launch_gemm(prec, p, s));
+    const size_t tot = (size_t)B * H0 * W0;
+    hipLaunchKernelGGL(affine_bwd_kernel, dim3(grid1d(tot) > 256 ? 256 : grid1d(tot)), dim3(256), 0, s, (const float*)nullptr, w.dup0,
+                       w.uraw, SRAD_IMG_CPAD, (float*)nullptr, B, C, H0 * W0, h->pt.fptr(h->sub_w), G + h->ts.flat_off[h->sub_w],
+                       G + h->ts.flat_off[h->sub_b]);
+    SRAD_CHECK_HIP(hipGetLastError());
+  }
+  return srad_wgrad_flush(wq, s);
+}
+
+// Backward of the dual regression model (srad_dual_forward): dy [B,C,H/2,W/2] -> dw0 / dw1 accumulated (PyTorch layouts),
+// dx [B,C,H,W] optional.  The hidden activation is recomputed.  n_feats % 4 == 0.
+int srad_dual_backward_workspace_bytes(int B, int C, int H, int W, int n_feats, size_t* bytes) {
+  SRAD_REQUIRE(bytes && B > 0 && C > 0 && H > 0 && W > 0 && n_feats > 0, "dual_backward_workspace_bytes: bad argument");
+  const size_t T = (size_t)B * H * W, T2 = (size_t)B * (H / 2) * (W / 2);
+  const int fm = srad_round_up(n_feats, 4);
+  const size_t pk = srad_align_up(srad_packed_bytes(SRAD_PREC_F32, fm, fm, 9), 256);   // covers [F][4], [4][F] and their transposes
+  *bytes = 2 * srad_align_up(T * SRAD_IMG_CPAD * 4, 256) + 2 * srad_align_up(T2 * n_feats * 4, 256) + srad_align_up(T2 * SRAD_IMG_CPAD * 4, 256) +
+           srad_align_up(T * n_feats * 4, 256) + 4 * pk + srad_align_up(SRAD_WGRAD_WS_BYTES, 256);
+  return SRAD_OK;
+}
+
+int srad_dual_backward(const float* w0, const float* w1, int C, int n_feats, float negval, const float* x, int B, int H,
+                       int W, const float* dy, float* dx, float* dw0, float* dw1, void* workspace, size_t workspace_bytes,
+                       int precision, void* stream) {
+  SRAD_REQUIRE(w0 && w1 && x && dy && dw0 && dw1 && workspace, "dual_backward: null argument");
+  SRAD_REQUIRE((C == 1 || C == 3) && n_feats % 4 == 0 && H % 2 == 0 && W % 2 == 0, "dual_backward: needs 1 or 3 channels, n_feats %% 4 == 0, even H and W");
+  size_t need = 0;
+  SRAD_TRY(srad_dual_backward_workspace_bytes(B, C, H, W, n_feats, &need));
+  SRAD_REQUIRE(workspace_bytes >= need && ((uintptr_t)workspace & 255) == 0, "dual_backward: workspace %zu bytes, %zu needed (256-byte aligned)", workspace_bytes, need);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Bump bp(workspace, workspace_bytes);
+  const int H2 = H / 2, W2 = W / 2, Fh = n_feats;
+  const size_t T = (size_t)B * H * W, T2 = (size_t)B * H2 * W2;
+  float* xin = bp.take(T * SRAD_IMG_CPAD);
+  float* dxin = bp.take(T * SRAD_IMG_CPAD);
+  float* mid = bp.take(T2 * Fh);
+  float* dmid = bp.take(T2 * Fh);
+  float* dyn = bp.take(T2 * SRAD_IMG_CPAD);
+  float* zup = bp.take(T * Fh);
+  const size_t pk = srad_packed_bytes(SRAD_PREC_F32, Fh, Fh, 9) / 4;
+  void* p0 = bp.take(pk);     // w0 forward   [F][C]
+  void* p1t = bp.take(pk);    // w1 transposed (rows F, K = C)
+  void* p0t = bp.take(pk);    // w0 transposed (rows C, K = F)
+  WgradQueue wq;
+  wq.ws = bp.take(SRAD_WGRAD_WS_BYTES / 4);
+  wq.ws_floats = SRAD_WGRAD_WS_BYTES / sizeof(float);
+  const float zero3[3] = {0.f, 0.f, 0.f};
+  SRAD_TRY(srad_launch_nchw_to_nhwc(x, xin, B, C, SRAD_IMG_CPAD, H, W, zero3, 1.0f, s));
+  SRAD_TRY(srad_launch_nchw_to_nhwc(dy, dyn, B, C, SRAD_IMG_CPAD, H2, W2, zero3, 1.0f, s));
+  SRAD_TRY(srad_launch_pack_weight(precision, w0, p0, Fh, C, 9, s));
+  SRAD_TRY(srad_launch_pack_weight_transposed(precision, w1, p1t, C, Fh, 9, SRAD_IMG_CPAD, Fh, s));
+  SRAD_TRY(srad_launch_pack_weight_transposed(precision, w0, p0t, Fh, C, 9, Fh, SRAD_IMG_CPAD, s));
+  {  // recompute mid = lrelu(conv_s2(x))
+    GemmParams a{};
+    a.X = xin; a.ldx = SRAD_IMG_CPAD; a.Cin = SRAD_IMG_CPAD; a.Cp = srad_cp(SRAD_IMG_CPAD); a.ntaps = 9;
+    a.Hi = H; a.Wi = W; a.Ho = H2; a.Wo = W2; a.stride = 2; a.M = (int)T2; a.ln_eps = 1e-5f;
+    a.Wp = p0; a.N = Fh; a.act = SRAD_ACT_LRELU; a.slope = negval; a.alpha = 1.f; a.Y = mid; a.ldy = Fh;
+    SRAD_TRY(srad_launch_gemm(precision, a, s));
+  }
+  {  // second conv: dw1, dmid = (dy . w1) * lrelu'(mid)
+    WgradParams g{};
+    g.dY = dyn; g.ldy = SRAD_IMG_CPAD; g.X = mid; g.ldx = Fh; g.M = (int)T2; g.N = SRAD_IMG_CPAD; g.Cin = Fh; g.ntaps = 9;
+    g.n_real = C; g.cin_real = Fh; g.Hi = g.Ho = H2; g.Wi = g.Wo = W2; g.stride = 1; g.alpha = 1.f; g.dW = dw1;
+    SRAD_TRY(srad_launch_wgrad(precision, g, wq, s));
+    GemmParams p{};
+    p.Hi = p.Ho = H2; p.Wi = p.Wo = W2; p.stride = 1; p.X = dyn; p.ldx = SRAD_IMG_CPAD; p.M = (int)T2; p.Cin = SRAD_IMG_CPAD;
+    p.Cp = srad_cp(SRAD_IMG_CPAD); p.ntaps = 9; p.ln_eps = 1e-5f; p.Wp = p1t; p.N = Fh; p.alpha = 1.f;
+    p.R = mid; p.ldr = Fh; p.rmode = SRAD_RMODE_DLRELU; p.slope = negval; p.Y = dmid; p.ldy = Fh;
+    SRAD_TRY(srad_launch_gemm(precision, p, s));
+  }
+  {  // first conv (stride 2): dw0, dx
+    WgradParams g{};
+    g.dY = dmid; g.ldy = Fh; g.X = xin; g.ldx = SRAD_IMG_CPAD; g.M = (int)T2; g.N = Fh; g.Cin = SRAD_IMG_CPAD; g.ntaps = 9;
+    g.n_real = Fh; g.cin_real = C; g.Hi = H; g.Wi = W; g.Ho = H2; g.Wo = W2; g.stride = 2; g.alpha = 1.f; g.dW = dw0;
+    SRAD_TRY(srad_launch_wgrad(precision, g, wq, s));
+    if (dx) {
+      const size_t tot = T * Fh / 4;
+      hipLaunchKernelGGL(zero_upsample_kernel, dim3(grid1d(tot)), dim3(256), 0, s, dmid, zup, B, H2, W2, Fh);
+      SRAD_CHECK_HIP(hipGetLastError());
+      GemmParams p{};
+      p.Hi = p.Ho = H; p.Wi = p.Wo = W; p.stride = 1; p.X = zup; p.ldx = Fh; p.M = (int)T; p.Cin = Fh; p.Cp = srad_cp(Fh);
+      p.ntaps = 9; p.ln_eps = 1e-5f; p.Wp = p0t; p.N = SRAD_IMG_CPAD; p.alpha = 1.f; p.Y = dxin; p.ldy = SRAD_IMG_CPAD;
+      SRAD_TRY(srad_launch_gemm(precision, p, s));
+      SRAD_TRY(srad_launch_nhwc_to_nchw(dxin, SRAD_IMG_CPAD, dx, B, C, H, W, zero3, 1.0f, s));
+    }
+  }
+  return srad_wgrad_flush(wq, s);
 }
 
 }  // extern "C"

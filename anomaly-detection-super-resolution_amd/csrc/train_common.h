@@ -1,0 +1,170 @@
+// train_common.h - training plumbing shared by the DRCT and DRN engines: the flat fp32 parameter / gradient layout,
+// the training arena (transposed weight packs, descriptor table, split-K workspace) and the one-launch re-pack of
+// every parameter after an optimizer step.
+#pragma once
+#include "engine.h"
+#include <type_traits>
+
+struct TrainState {
+  std::vector<int64_t> flat_off;  // per table entry: offset (floats) in the flat fp32 parameter / gradient buffers
+  int64_t flat_total = 0;
+  std::vector<size_t> t_off;      // per table entry: byte offset of the transposed pack in the training arena
+  size_t t_desc_off = 0;          // byte offset of the device descriptor table inside the training arena
+  size_t t_wgrad_off = 0;         // byte offset of the split-K workspace
+  size_t t_bytes = 0;
+  int n_sync_blocks = 0;
+  char* tarena = nullptr;
+  bool ready = false;
+};
+
+struct SyncDesc {
+  long long src_off;    // floats into the flat parameter buffer
+  long long dst_off;    // bytes into the forward arena
+  long long tdst_off;   // bytes into the training arena (-1: no transposed pack)
+  int packed, n, cin, ntaps, Np, Cp, tRp, tKp;
+  long long numel;
+  unsigned blk0, nblk;
+};
+
+namespace {
+
+constexpr int SYNC_EPB = 2048;   // elements per block of the sync kernel
+
+template <int PREC>
+__global__ __launch_bounds__(256) void sync_params_kernel(const SyncDesc* __restrict__ descs, int ndesc,
+                                                          const float* __restrict__ flat, char* __restrict__ arena,
+                                                          char* __restrict__ tarena) {
+  using T = typename std::conditional<PREC == SRAD_PREC_BF16, __bf16, float>::type;
+  // binary search: last descriptor with blk0 <= blockIdx.x
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].blk0 <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const SyncDesc d = descs[lo];
+  const long long base = (long long)(blockIdx.x - d.blk0) * SYNC_EPB;
+  const float* src = flat + d.src_off;
+  if (!d.packed) {
+    float* dst = reinterpret_cast<float*>(arena + d.dst_off);
+    for (long long i = base + threadIdx.x; i < base + SYNC_EPB && i < d.numel; i += 256) dst[i] = src[i];
+    return;
+  }
+  const long long ftotal = (long long)d.Np * d.ntaps * d.Cp;
+  T* dst = reinterpret_cast<T*>(arena + d.dst_off);
+  for (long long i = base + threadIdx.x; i < base + SYNC_EPB && i < ftotal; i += 256) {
+    const int c = (int)(i % d.Cp);
+    const int tap = (int)((i / d.Cp) % d.ntaps);
+    const int n = (int)(i / ((long long)d.Cp * d.ntaps));
+    float v = 0.f;
+    if (n < d.n && c < d.cin) v = src[((long long)n * d.cin + c) * d.ntaps + tap];
+    dst[i] = (T)v;
+  }
+  if (d.tdst_off >= 0) {
+    const long long ttotal = (long long)d.tRp * d.ntaps * d.tKp;
+    T* tdst = reinterpret_cast<T*>(tarena + d.tdst_off);
+    for (long long i = base + threadIdx.x; i < base + SYNC_EPB && i < ttotal; i += 256) {
+      const int n = (int)(i % d.tKp);
+      const int tap = (int)((i / d.tKp) % d.ntaps);
+      const int c = (int)(i / ((long long)d.tKp * d.ntaps));
+      float v = 0.f;
+      if (n < d.n && c < d.cin) v = src[((long long)n * d.cin + c) * d.ntaps + (d.ntaps - 1 - tap)];
+      tdst[i] = (T)v;
+    }
+  }
+}
+
+inline int train_param_floats(const ParamTable& pt, TrainState& ts, int64_t* total) {
+  if (ts.flat_off.empty()) {
+    int64_t off = 0;
+    for (const ParamEntry& e : pt.entries) {
+      ts.flat_off.push_back(off);
+      off += (e.numel + 63) / 64 * 64;
+    }
+    ts.flat_total = off;
+  }
+  *total = ts.flat_total;
+  return SRAD_OK;
+}
+
+inline int train_arena_bytes(const ParamTable& pt, TrainState& ts, size_t* bytes) {
+  int64_t tot = 0;
+  SRAD_TRY(train_param_floats(pt, ts, &tot));
+  if (ts.t_off.empty()) {
+    size_t off = 0;
+    for (const ParamEntry& e : pt.entries) {
+      ts.t_off.push_back(off);
+      if (e.packed) off += srad_align_up(srad_packed_bytes(pt.prec, srad_round_up(e.cin, 4), srad_round_up(e.n, 4), e.ntaps), 256);
+    }
+    ts.t_desc_off = off;
+    off += srad_align_up(pt.entries.size() * sizeof(SyncDesc), 256);
+    ts.t_wgrad_off = off;                       // split-K workspace of the weight-gradient kernel
+    off += srad_align_up(SRAD_WGRAD_WS_BYTES, 256);
+    ts.t_bytes = off;
+  }
+  *bytes = ts.t_bytes;
+  return SRAD_OK;
+}
+
+// Binds the caller-owned training arena.  Synchronous (one small host-to-device copy).
+inline int train_bind(const ParamTable& pt, TrainState& ts, void* train_arena, size_t bytes) {
+  SRAD_REQUIRE(train_arena, "train_bind: null argument");
+  size_t need = 0;
+  SRAD_TRY(train_arena_bytes(pt, ts, &need));
+  SRAD_REQUIRE(bytes >= need, "train_bind: %zu bytes given, %zu needed", bytes, need);
+  SRAD_REQUIRE(((uintptr_t)train_arena & 255) == 0, "train_bind: arena must be 256-byte aligned");
+  if (!pt.arena) return srad_set_error(SRAD_ERR_STATE, "train_bind: bind the forward arena first");
+  std::vector<SyncDesc> descs;
+  unsigned blk = 0;
+  for (size_t i = 0; i < pt.entries.size(); ++i) {
+    const ParamEntry& e = pt.entries[i];
+    SyncDesc d{};
+    d.src_off = ts.flat_off[i]; d.dst_off = (long long)e.off; d.tdst_off = -1;
+    d.packed = e.packed; d.numel = e.numel;
+    long long work = e.numel;
+    if (e.packed) {
+      SRAD_REQUIRE(e.grp_pad == 0 && (e.n_pad == 0 || e.n_pad == e.n),
+                   "train_bind: zero-padded layers (DRN x8, n_feats = 10) are not trainable");
+      d.n = e.n; d.cin = e.cin; d.ntaps = e.ntaps; d.Np = srad_np(e.n); d.Cp = srad_cp(e.cin);
+      d.tRp = srad_np(srad_round_up(e.cin, 4)); d.tKp = srad_cp(srad_round_up(e.n, 4));
+      d.tdst_off = (long long)ts.t_off[i];
+      const long long f = (long long)d.Np * d.ntaps * d.Cp, t = (long long)d.tRp * d.ntaps * d.tKp;
+      work = f > t ? f : t;
+    }
+    d.blk0 = blk;
+    d.nblk = (unsigned)((work + SYNC_EPB - 1) / SYNC_EPB);
+    if (d.nblk == 0) d.nblk = 1;
+    blk += d.nblk;
+    descs.push_back(d);
+  }
+  ts.n_sync_blocks = (int)blk;
+  ts.tarena = reinterpret_cast<char*>(train_arena);
+  SRAD_CHECK_HIP(hipMemcpy(ts.tarena + ts.t_desc_off, descs.data(), descs.size() * sizeof(SyncDesc), hipMemcpyHostToDevice));
+  ts.ready = false;
+  return SRAD_OK;
+}
+
+// Refreshes every packed weight (forward and transposed) and raw parameter from the flat fp32 master buffer: one launch.
+inline int train_sync_params(const ParamTable& pt, TrainState& ts, const float* flat_params, hipStream_t s) {
+  SRAD_REQUIRE(flat_params, "sync_params: null argument");
+  if (!ts.tarena) return srad_set_error(SRAD_ERR_STATE, "sync_params: no training arena bound");
+  const SyncDesc* descs = reinterpret_cast<const SyncDesc*>(ts.tarena + ts.t_desc_off);
+  SradProfScope prof(s, SRAD_K_PACK, 0.0, 4.0 * ts.flat_total + 2.0 * (pt.bytes + ts.t_bytes));
+  if (pt.prec == SRAD_PREC_BF16)
+    hipLaunchKernelGGL((sync_params_kernel<SRAD_PREC_BF16>), dim3(ts.n_sync_blocks), dim3(256), 0, s, descs,
+                       (int)pt.entries.size(), flat_params, pt.arena, ts.tarena);
+  else
+    hipLaunchKernelGGL((sync_params_kernel<SRAD_PREC_F32>), dim3(ts.n_sync_blocks), dim3(256), 0, s, descs,
+                       (int)pt.entries.size(), flat_params, pt.arena, ts.tarena);
+  SRAD_CHECK_HIP(hipGetLastError());
+  ts.ready = true;
+  return SRAD_OK;
+}
+
+inline WgradQueue train_wgrad_queue(const TrainState& ts) {
+  WgradQueue q;
+  q.ws = reinterpret_cast<float*>(ts.tarena + ts.t_wgrad_off);
+  q.ws_floats = SRAD_WGRAD_WS_BYTES / sizeof(float);
+  return q;
+}
+
+}  // namespace

@@ -203,6 +203,74 @@ class _EngineModule(nn.Module):
     def _can_train(self) -> bool:
         return False
 
+    # -- training plumbing shared by DRCT and DRN (C ABI <prefix>_train_*, <prefix>_sync_params) -----------
+    def enable_training(self):
+        """Re-home every parameter into ONE flat fp32 device buffer (``p.data`` become views, state-dict and
+        optimizers keep working) with a twin flat gradient buffer (``p.grad`` views), and bind the engine's
+        training arena.  Call after the module is on its GPU; moving it afterwards needs another call."""
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("srad_amd trains on the GPU only (HIP engine); move the model with .cuda() first")
+        self._ensure_handle(dev)
+        h = self._handle
+        total = C.c_int64()
+        L.check(self._fn("train_param_floats")(h, C.byref(total)), "train_param_floats")
+        flat = torch.zeros(total.value, dtype=torch.float32, device=dev)
+        grad = torch.zeros(total.value, dtype=torch.float32, device=dev)
+        views = []
+        off = C.c_int64()
+        with torch.no_grad():
+            for i, (name, numel) in enumerate(self._engine_params):
+                L.check(self._fn("train_param_offset")(h, i, C.byref(off)), "train_param_offset")
+                p = self.get_parameter(name)
+                v = flat[off.value:off.value + numel].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                g = grad[off.value:off.value + numel].view(p.shape)
+                p.grad = g
+                views.append((p, g))
+        nbytes = C.c_size_t()
+        L.check(self._fn("train_arena_bytes")(h, C.byref(nbytes)), "train_arena_bytes")
+        self._tarena = torch.zeros(nbytes.value + 256, dtype=torch.uint8, device=dev)
+        tp, tb = self._aligned(self._tarena)
+        L.check(self._fn("train_bind")(h, tp, tb), "train_bind")
+        self.flat_params, self.flat_grads, self._grad_views = flat, grad, views
+        self._synced_version = None
+        self._train_ws = {}
+        self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+        self._param_cache = None
+        return self
+
+    def mark_params_dirty(self) -> None:
+        """Tell the engine the flat parameters were changed by something that does not bump tensor versions
+        (the fused Adam kernel)."""
+        self._synced_version = None
+
+    def _sync_flat(self) -> None:
+        if getattr(self, "flat_params", None) is None:
+            raise RuntimeError(f"{type(self).__name__}: call enable_training() before a training-mode forward")
+        ver = self.flat_params._version
+        if self._synced_version != ver:
+            L.check(self._fn("sync_params")(self._handle, L.dptr(self.flat_params), L.current_stream_ptr()), "sync_params")
+            self._synced_version = ver
+            self._tags = None               # the eval path re-checks its own tags
+
+    def _train_workspace(self, B, H, W, dev):
+        key = (B, H, W)
+        if key not in self._train_ws:
+            nbytes = C.c_size_t()
+            L.check(self._fn("train_workspace_bytes")(self._handle, B, H, W, C.byref(nbytes)), "train_workspace_bytes")
+            self._train_ws = {key: torch.empty(nbytes.value + 256, dtype=torch.uint8, device=dev)}
+        return self._aligned(self._train_ws[key])
+
+    def zero_grad(self, set_to_none: bool = False) -> None:   # noqa: D401 - nn.Module signature
+        if getattr(self, "flat_grads", None) is not None:
+            self.flat_grads.zero_()
+            for p, g in self._grad_views:
+                p.grad = g
+        else:
+            super().zero_grad(set_to_none)
+
     def flops(self, B: int, H: int, W: int) -> float:
         dev = next(self.parameters()).device
         self._ensure_handle(dev)
@@ -226,6 +294,51 @@ class _DrctTrainFn(torch.autograd.Function):
     def backward(ctx, dy):
         dx = ctx.module._backward(dy.to(torch.float32).contiguous(), ctx.need_dx)
         return dx, None, None
+
+
+class _DrnTrainFn(torch.autograd.Function):
+    """autograd seam of the DRN training step: the outputs are the phase + 1 images; backward hands the engine one
+    gradient per output (None for outputs the loss does not use).  The LR input gets no gradient (the reference
+    never asks for one)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, module):
+        ctx.module = module
+        outs = module._forward_train(x.detach().to(torch.float32).contiguous())
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        ctx.module._backward(list(dys))
+        return None, None, None
+
+
+class _DualFn(torch.autograd.Function):
+    """Dual regression model with gradients: y = conv(lrelu(conv_s2(x, w0)), w1) (src/model.py:8-44)."""
+
+    @staticmethod
+    def forward(ctx, x, w0, w1, module):
+        ctx.module = module
+        x = x.detach().to(torch.float32).contiguous()
+        ctx.save_for_backward(x, w0.detach(), w1.detach())
+        return module._run_forward(x, w0.detach().contiguous(), w1.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w0, w1 = ctx.saved_tensors
+        m = ctx.module
+        B, Cc, H, W = x.shape
+        dy = dy.to(torch.float32).contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw0, dw1 = torch.zeros_like(w0), torch.zeros_like(w1)
+        nbytes = C.c_size_t()
+        L.check(L.lib().srad_dual_backward_workspace_bytes(B, Cc, H, W, m.n_feats, C.byref(nbytes)), "dual_backward_workspace_bytes")
+        ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=x.device)
+        wp, wb = _EngineModule._aligned(ws)
+        L.check(L.lib().srad_dual_backward(L.dptr(w0.contiguous()), L.dptr(w1.contiguous()), Cc, m.n_feats, m.negval, L.dptr(x), B, H, W,
+                                           L.dptr(dy), L.dptr(dx), L.dptr(dw0), L.dptr(dw1), wp, wb, L.PRECISIONS[m.precision],
+                                           L.current_stream_ptr()), "dual_backward")
+        return dx, dw0, dw1, None
 
 
 # ------------------------------------------------------------------ DRCT
@@ -271,40 +384,8 @@ class DRCT(_EngineModule):
         return True
 
     def enable_training(self) -> "DRCT":
-        """Re-home every parameter into ONE flat fp32 device buffer (``p.data`` become views, state-dict and
-        optimizers keep working) with a twin flat gradient buffer (``p.grad`` views), and bind the engine's
-        training arena.  Call after the module is on its GPU; moving it afterwards needs another call."""
-        dev = next(self.parameters()).device
-        if dev.type != "cuda":
-            raise RuntimeError("srad_amd trains on the GPU only (HIP engine); move the model with .cuda() first")
-        self._ensure_handle(dev)
+        super().enable_training()
         h = self._handle
-        total = C.c_int64()
-        L.check(L.lib().srad_drct_train_param_floats(h, C.byref(total)), "train_param_floats")
-        flat = torch.zeros(total.value, dtype=torch.float32, device=dev)
-        grad = torch.zeros(total.value, dtype=torch.float32, device=dev)
-        views = []
-        off = C.c_int64()
-        with torch.no_grad():
-            for i, (name, numel) in enumerate(self._engine_params):
-                L.check(L.lib().srad_drct_train_param_offset(h, i, C.byref(off)), "train_param_offset")
-                p = self.get_parameter(name)
-                v = flat[off.value:off.value + numel].view(p.shape)
-                v.copy_(p.data)
-                p.data = v
-                g = grad[off.value:off.value + numel].view(p.shape)
-                p.grad = g
-                views.append((p, g))
-        nbytes = C.c_size_t()
-        L.check(L.lib().srad_drct_train_arena_bytes(h, C.byref(nbytes)), "train_arena_bytes")
-        self._tarena = torch.zeros(nbytes.value + 256, dtype=torch.uint8, device=dev)
-        tp, tb = self._aligned(self._tarena)
-        L.check(L.lib().srad_drct_train_bind(h, tp, tb), "train_bind")
-        self.flat_params, self.flat_grads, self._grad_views = flat, grad, views
-        self._synced_version = None
-        self._train_ws = {}
-        self._anchor = torch.zeros(1, device=dev, requires_grad=True)
-        self._param_cache = None
         self.keep_scale_override = None     # tests: explicit DropPath factors [2 * n_blocks, B]
         self.on_bucket = None               # data-parallel hook: callable(bucket index), see GradReducer
         nb = L.lib().srad_drct_num_buckets(h)
@@ -314,28 +395,6 @@ class DRCT(_EngineModule):
             L.check(L.lib().srad_drct_bucket_range(h, i, C.byref(a), C.byref(b)), "bucket_range")
             self.grad_buckets.append((a.value, b.value))
         return self
-
-    def mark_params_dirty(self) -> None:
-        """Tell the engine the flat parameters were changed by something that does not bump tensor versions
-        (the fused Adam kernel)."""
-        self._synced_version = None
-
-    def _sync_flat(self) -> None:
-        if getattr(self, "flat_params", None) is None:
-            raise RuntimeError("DRCT: call enable_training() before a training-mode forward")
-        ver = self.flat_params._version
-        if self._synced_version != ver:
-            L.check(L.lib().srad_drct_sync_params(self._handle, L.dptr(self.flat_params), L.current_stream_ptr()), "sync_params")
-            self._synced_version = ver
-            self._tags = None               # the eval path re-checks its own tags
-
-    def zero_grad(self, set_to_none: bool = False) -> None:   # noqa: D401 - nn.Module signature
-        if getattr(self, "flat_grads", None) is not None:
-            self.flat_grads.zero_()
-            for p, g in self._grad_views:
-                p.grad = g
-        else:
-            super().zero_grad(set_to_none)
 
     def drop_path_keep_probs(self) -> torch.Tensor:
         """keep_prob of every Swin block: all five blocks of RDG i use dpr[i * depth] of
@@ -350,11 +409,7 @@ class DRCT(_EngineModule):
         B, _, H, W = x.shape
         self._sync_flat()
         key = (B, H, W)
-        if key not in self._train_ws:
-            nbytes = C.c_size_t()
-            L.check(L.lib().srad_drct_train_workspace_bytes(self._handle, B, H, W, C.byref(nbytes)), "train_workspace_bytes")
-            self._train_ws = {key: torch.empty(nbytes.value + 256, dtype=torch.uint8, device=dev)}
-        wp, wb = self._aligned(self._train_ws[key])
+        wp, wb = self._train_workspace(B, H, W, dev)
         keep = self.keep_scale_override
         if keep is None and self.drop_path_rate > 0:
             kp = self.drop_path_keep_probs().to(dev).repeat_interleave(2)[:, None]        # [2 * blocks, 1]
@@ -444,7 +499,42 @@ class DRN(_EngineModule):
         L.check(L.lib().srad_drn_create(C.byref(cc), C.byref(h)), "drn_create")
         return h
 
+    # -- training (C ABI srad_drn_forward_train / srad_drn_backward) -----------------------------
+    def _can_train(self) -> bool:
+        return self.cfg.n_feats % 4 == 0        # the x8 preset (n_feats 10, zero-padded layers) is inference-only
+
+    def _forward_train(self, x: torch.Tensor) -> List[torch.Tensor]:
+        dev = x.device
+        B, Cc, H, W = x.shape
+        self._sync_flat()
+        wp, wb = self._train_workspace(B, H, W, dev)
+        outs = [torch.empty(B, Cc, H * 2 ** i, W * 2 ** i, dtype=torch.float32, device=dev) for i in range(self.phase + 1)]
+        ptrs = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+        L.check(L.lib().srad_drn_forward_train(self._handle, L.dptr(x), B, H, W, ptrs, len(outs), wp, wb,
+                                               L.current_stream_ptr()), "drn_forward_train")
+        self._train_shape = (B, H, W)
+        return outs
+
+    def _backward(self, dys) -> None:
+        """dys: one gradient (or None) per output of the last training forward."""
+        B, H, W = self._train_shape
+        if self._grad_views[0][0].grad is None:
+            self.zero_grad()
+        wp, wb = self._train_workspace(B, H, W, self.flat_grads.device)
+        keep = [None if g is None else g.to(torch.float32).contiguous() for g in dys]
+        ptrs = (C.c_void_p * len(keep))(*[0 if g is None else g.data_ptr() for g in keep])
+        L.check(L.lib().srad_drn_backward(self._handle, ptrs, len(keep), B, H, W, L.dptr(self.flat_grads), wp, wb,
+                                          L.current_stream_ptr()), "drn_backward")
+
     def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
+        if self.training and torch.is_grad_enabled() and self._can_train():
+            if not x.is_cuda:
+                raise RuntimeError("srad_amd runs on the GPU only (HIP engine); got a CPU tensor - there is no CPU fallback")
+            if x.dim() != 4 or x.shape[1] != self.cfg.n_colors:
+                raise ValueError(f"expected a [B, {self.cfg.n_colors}, H, W] tensor")
+            if getattr(self, "flat_params", None) is None:
+                self.enable_training()
+            return list(_DrnTrainFn.apply(x, self._anchor, self))
         x = self._check_input(x, self.cfg.n_colors)
         dev = x.device
         B, Cc, H, W = x.shape
@@ -493,15 +583,21 @@ class DownBlock(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not x.is_cuda:
             raise RuntimeError("srad_amd runs on the GPU only (HIP engine)")
-        x = x.detach().to(torch.float32).contiguous()
+        w0 = self.get_parameter("dual_module.0.0.weight")
+        w1 = self.get_parameter("dual_module.1.weight")
+        if torch.is_grad_enabled() and (x.requires_grad or w0.requires_grad or w1.requires_grad):
+            if self.n_feats % 4 or x.shape[2] % 2 or x.shape[3] % 2:
+                raise NotImplementedError("DownBlock backward needs n_feats % 4 == 0 and even image sizes")
+            return _DualFn.apply(x, w0, w1, self)
+        return self._run_forward(x.detach().to(torch.float32).contiguous(), w0.detach().contiguous(), w1.detach().contiguous())
+
+    def _run_forward(self, x: torch.Tensor, w0: torch.Tensor, w1: torch.Tensor) -> torch.Tensor:
         B, Cc, H, W = x.shape
         y = torch.empty(B, Cc, (H + 1) // 2, (W + 1) // 2, dtype=torch.float32, device=x.device)
         nbytes = C.c_size_t()
         L.check(L.lib().srad_dual_workspace_bytes(B, Cc, H, W, self.n_feats, C.byref(nbytes)), "dual_workspace_bytes")
         ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=x.device)
         wp, wb = _EngineModule._aligned(ws)
-        w0 = self.get_parameter("dual_module.0.0.weight").detach().contiguous()
-        w1 = self.get_parameter("dual_module.1.weight").detach().contiguous()
         L.check(L.lib().srad_dual_forward(L.dptr(w0), L.dptr(w1), Cc, self.n_feats, self.negval, L.dptr(x), B, H, W,
                                           L.dptr(y), wp, wb, L.PRECISIONS[self.precision], L.current_stream_ptr()),
                 "dual_forward")

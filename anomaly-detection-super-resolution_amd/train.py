@@ -132,3 +132,41 @@ def train_step(model, lr_img: torch.Tensor, hr_img: torch.Tensor, optimizer: Fus
         reducer.finish()
     optimizer.step(grad_scale=reducer.grad_scale if reducer is not None else 1.0)
     return loss
+
+
+def drn_loss(sr, lr_list, hr, sr2lr, dual_weight: float = 0.1) -> torch.Tensor:
+    """DRN training loss (src/trainer.py:168-185): L1(sr[-1], hr) + sum_j L1(sr[j], lr[j]) over the coarser outputs
+    + dual_weight * sum_i L1(dual_i(sr[i - n]), lr[i]).  ``lr_list`` = [LR_x(max), ..., LR_x2] coarse -> fine, as the
+    reference loader yields it."""
+    l1 = torch.nn.functional.l1_loss
+    loss_primary = l1(sr[-1], hr)
+    for i in range(1, len(sr)):
+        loss_primary = loss_primary + l1(sr[i - 1 - len(sr)], lr_list[i - len(sr)])
+    loss_dual = l1(sr2lr[0], lr_list[0])
+    for i in range(1, len(sr2lr)):
+        loss_dual = loss_dual + l1(sr2lr[i], lr_list[i])
+    return loss_primary + dual_weight * loss_dual
+
+
+def drn_train_step(model, dual_models, lr_list, hr, optimizer, dual_optimizers, dual_weight: float = 0.1,
+                   reducer: Optional["GradReducer"] = None) -> torch.Tensor:
+    """One iteration of Trainer.train for DRN-L with its dual regression models (src/trainer.py:161-205): forward of
+    the SR net and of every dual model on the matching SR output, the composite loss, backward through the dual models
+    into the SR outputs and through the DRN engine, one Adam step for the SR net and one per dual model."""
+    optimizer.zero_grad()
+    for o in dual_optimizers:
+        o.zero_grad()
+    sr = model(lr_list[0])
+    sr2lr = [dual_models[i](sr[i - len(dual_models)]) for i in range(len(dual_models))]
+    loss = drn_loss(sr, lr_list, hr, sr2lr, dual_weight)
+    loss.backward()
+    if reducer is not None:
+        reducer.reduce_all(model.flat_grads, [(0, model.flat_grads.numel())])
+        for dm in dual_models:
+            for p in dm.parameters():
+                reducer.dist.all_reduce(p.grad, group=reducer.group)
+                p.grad.mul_(reducer.grad_scale)
+    optimizer.step(grad_scale=reducer.grad_scale if reducer is not None else 1.0)
+    for o in dual_optimizers:
+        o.step()
+    return loss.detach()

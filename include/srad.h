@@ -135,6 +135,30 @@ int srad_dual_workspace_bytes(int B, int C, int H, int W, int n_feats, size_t* b
 int srad_dual_forward(const float* w0, const float* w1, int C, int n_feats, float negval, const float* x, int B,
                       int H, int W, float* y, void* workspace, size_t workspace_bytes, int precision, void* stream);
 
+/* ------------------------------------------------------------------ DRN training step (src/trainer.py:161-205)
+ * Same scheme as the DRCT training entry points: flat fp32 parameter / gradient buffers with the offsets of
+ * srad_drn_train_param_offset, a second caller-owned arena, srad_drn_sync_params after every optimizer step.
+ * n_feats must be a multiple of 4 (the x2 / x4 presets). */
+int srad_drn_train_param_floats(srad_drn_t* h, int64_t* total);
+int srad_drn_train_param_offset(srad_drn_t* h, int idx, int64_t* off_floats);
+int srad_drn_train_arena_bytes(srad_drn_t* h, size_t* bytes);
+int srad_drn_train_bind(srad_drn_t* h, void* train_arena, size_t bytes);
+int srad_drn_sync_params(srad_drn_t* h, const float* dev_flat_params, void* stream);
+int srad_drn_train_workspace_bytes(const srad_drn_t* h, int B, int H, int W, size_t* bytes);
+/* model.train() forward of DRN (src/drn.py:241-270); saved activations stay in `workspace` for srad_drn_backward */
+int srad_drn_forward_train(srad_drn_t* h, const float* x, int B, int H, int W, float* const* ys, int n_out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+/* dys[j] = dLoss/d(output j) (NCHW device pointers, NULL when output j is not in the loss); parameter gradients are
+ * ACCUMULATED into dev_flat_grad (incl. the trainable MeanShift layers, hazard H4) */
+int srad_drn_backward(srad_drn_t* h, const float* const* dys, int n_out, int B, int H, int W, float* dev_flat_grad,
+                      void* workspace, size_t workspace_bytes, void* stream);
+/* Backward of the dual regression model (srad_dual_forward; src/trainer.py:168-185 back-propagates through it into the
+ * SR outputs): dw0 [n_feats,C,3,3] / dw1 [C,n_feats,3,3] accumulated, dx [B,C,H,W] optional; n_feats % 4 == 0 */
+int srad_dual_backward_workspace_bytes(int B, int C, int H, int W, int n_feats, size_t* bytes);
+int srad_dual_backward(const float* w0, const float* w1, int C, int n_feats, float negval, const float* x, int B, int H,
+                       int W, const float* dy, float* dx, float* dw0, float* dw1, void* workspace, size_t workspace_bytes,
+                       int precision, void* stream);
+
 /* ------------------------------------------------------------------ scorer (src/evaluate.py:204-265) */
 /* `mul(255/range).clamp(0,255).byte()` TRUNCATING u8 conversion + NCHW->HWC (evaluate.py:214-215). */
 int srad_to_u8_hwc(const float* x, int B, int C, int H, int W, float rgb_range, uint8_t* out, void* stream);

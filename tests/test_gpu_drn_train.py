@@ -1,0 +1,94 @@
+"""GPU: DRN-L training step through the C ABI (DRN branch; B1-B6 backward): gradients of every
+parameter (incl. the trainable MeanShift layers, H4) and of the dual regression models under the reference's
+composite loss against torch autograd of the oracle; fused Adam steps reduce the loss.
+fp32 mode, bar 1e-3 relative per tensor (max error over the tensor's max)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import DRN_GAIN, rel_err
+from tests.test_gpu_drn import Opt
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(scale, n_colors, n_blocks, n_feats, B, H, W, seed=31):
+    from srad_amd import spec as S
+    from srad_amd.nets import DRN, DownBlock
+    cfg = S.DRNConfig(n_colors=n_colors, scale=scale, n_blocks=n_blocks, n_feats=n_feats)
+    sd = S.synth_state(S.drn_spec(cfg), seed=seed, gain=DRN_GAIN, cfg=cfg)
+    duals = [S.synth_state(S.dual_spec(cfg), seed=seed + 100 + i, gain=DRN_GAIN, cfg=cfg) for i in range(cfg.phase)]
+    x = S.synth_image("drn_tr", (B, n_colors, H, W), seed=5)
+    lrs = [x] + [S.synth_image(f"drn_tr/lr{i}", (B, n_colors, H * 2 ** i, W * 2 ** i), seed=6 + i) for i in range(1, cfg.phase)]
+    hr = S.synth_image("drn_tr/hr", (B, n_colors, H * scale, W * scale), seed=9)
+    m = DRN(Opt(cfg, "fp32")).cuda()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m.train()
+    m.enable_training()
+    dms = []
+    for d in duals:
+        dm = DownBlock(Opt(cfg, "fp32")).cuda()
+        dm.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in d.items()})
+        dms.append(dm)
+    return cfg, sd, duals, lrs, hr, m, dms
+
+
+@pytest.mark.parametrize("scale,n_colors,n_feats,B,H,W", [(4, 1, 20, 2, 8, 12), (2, 3, 8, 1, 16, 16), (4, 3, 20, 1, 8, 8)])
+def test_drn_gradients_match_oracle_autograd(scale, n_colors, n_feats, B, H, W):
+    from oracle import sr_ref as R
+    from srad_amd.train import drn_loss
+    cfg, sd, duals, lrs, hr, m, dms = _setup(scale, n_colors, 2, n_feats, B, H, W)
+    # oracle: torch CPU autograd over the same state
+    sdt = {k: torch.from_numpy(np.asarray(v)).clone().requires_grad_(True) for k, v in sd.items()}
+    dts = [{k: torch.from_numpy(np.asarray(v)).clone().requires_grad_(True) for k, v in d.items()} for d in duals]
+    sr_ref = R.drn_forward(sdt, torch.from_numpy(lrs[0]), cfg)
+    sr2lr_ref = [R.dual_forward(dts[i], sr_ref[i - len(dts)], cfg) for i in range(len(dts))]
+    loss_ref = R.drn_total_loss(sr_ref, [torch.from_numpy(a) for a in lrs], torch.from_numpy(hr), sr2lr_ref)
+    loss_ref.backward()
+    # engine
+    lr_t = [torch.from_numpy(a).cuda() for a in lrs]
+    sr = m(lr_t[0])
+    assert len(sr) == cfg.phase + 1
+    for a, b in zip(sr, sr_ref):
+        assert rel_err(a.detach().cpu().numpy(), b.detach().numpy()) < 2e-4
+    sr2lr = [dms[i](sr[i - len(dms)]) for i in range(len(dms))]
+    loss = drn_loss(sr, lr_t, torch.from_numpy(hr).cuda(), sr2lr)
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-5 * abs(float(loss_ref))
+    loss.backward()
+    worst = ("", 0.0)
+    for n, p in m.named_parameters():
+        e = rel_err(p.grad.cpu().numpy(), sdt[n].grad.numpy())
+        worst = max(worst, (n, e), key=lambda t: t[1])
+        assert e < 1e-3, (n, e)
+    for dm, dt in zip(dms, dts):
+        for n, p in dm.named_parameters():
+            e = rel_err(p.grad.cpu().numpy(), dt[n].grad.numpy())
+            assert e < 1e-3, ("dual " + n, e)
+    print("worst DRN parameter-gradient error:", worst)
+
+
+def test_drn_train_steps_reduce_the_loss_and_eval_uses_new_weights():
+    from srad_amd.train import FusedAdam, drn_train_step
+    cfg, sd, duals, lrs, hr, m, dms = _setup(4, 1, 2, 20, 2, 8, 8)
+    opt = FusedAdam(m, lr=1e-4, weight_decay=1e-8)                      # src/main.py:61-66 (DRN: weight decay 1e-8)
+    dopts = [torch.optim.Adam(dm.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-8) for dm in dms]
+    lr_t = [torch.from_numpy(a).cuda() for a in lrs]
+    hr_t = torch.from_numpy(hr).cuda()
+    before = m.flat_params.clone()
+    losses = [float(drn_train_step(m, dms, lr_t, hr_t, opt, dopts)) for _ in range(5)]
+    print("DRN losses", losses)
+    assert losses[-1] < losses[0]
+    assert float((m.flat_params - before).abs().max()) > 0
+    m.eval()
+    with torch.no_grad():
+        y = m(lr_t[0])
+    assert len(y) == 3 and bool(torch.isfinite(y[-1]).all())
+
+
+def test_drn_x8_preset_training_is_refused():
+    from srad_amd import spec as S
+    from srad_amd.nets import DRN
+    cfg = S.DRNConfig.for_scale(8, 1)
+    m = DRN(Opt(cfg, "fp32")).cuda().train()
+    with pytest.raises(NotImplementedError, match="backward"):
+        m(torch.zeros(1, 1, 4, 4, device="cuda"))
