@@ -1,7 +1,7 @@
 """CLI entry with the reference's flags (src/main.py:390-474).  ``--model-type drct`` trains on the HIP engine
 (forward + L1 + backward + fused Adam; under ``python -m torch.distributed.run`` the minibatch is sharded over the
-ranks and gradients are all-reduced over RCCL while the backward runs).  ``--test-only`` evaluates an existing run.
-DRN training needs the DRN backward, which is not built yet, and says so."""
+ranks and gradients are all-reduced over RCCL while the backward runs); ``--model-type drn-l`` trains DRN-L with its
+dual regression models (x2 / x4; the x8 preset is inference-only).  ``--test-only`` evaluates an existing run."""
 from __future__ import annotations
 
 import os
@@ -19,9 +19,6 @@ def main(argv=None):
     if args.test_only:
         from . import evaluate
         return evaluate.main([a for a in (argv if argv is not None else sys.argv[1:]) if a != '--test-only'])
-    if args.model_type != 'drct':
-        raise SystemExit("training --model-type drn-l on the HIP engine is not built yet (DRN backward + dual-regression "
-                         "loss are the next rows, see DESIGN.md); --model-type drct trains, --test-only evaluates")
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -35,8 +32,8 @@ def main(argv=None):
     opt = build_opt(args.model_type, args.classe, args.resolution, args.scale, batch_size=args.batch_size,
                     dtype=getattr(args, "dtype", "bf16"), data_root=data_root, save=save, epochs=args.epochs,
                     no_augment=getattr(args, "no_augment", True))
-    from .trainer import train_drct
-    out = train_drct(opt)
+    from .trainer import train_drct, train_drn
+    out = train_drn(opt) if args.model_type == 'drn-l' else train_drct(opt)
     if world > 1:
         dist.destroy_process_group()
     return out

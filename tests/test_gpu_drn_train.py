@@ -53,7 +53,7 @@ def test_drn_gradients_match_oracle_autograd(scale, n_colors, n_feats, B, H, W):
         assert rel_err(a.detach().cpu().numpy(), b.detach().numpy()) < 2e-4
     sr2lr = [dms[i](sr[i - len(dms)]) for i in range(len(dms))]
     loss = drn_loss(sr, lr_t, torch.from_numpy(hr).cuda(), sr2lr)
-    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-5 * abs(float(loss_ref))
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-5 * abs(float(loss_ref.detach()))
     loss.backward()
     worst = ("", 0.0)
     for n, p in m.named_parameters():
@@ -92,3 +92,38 @@ def test_drn_x8_preset_training_is_refused():
     m = DRN(Opt(cfg, "fp32")).cuda().train()
     with pytest.raises(NotImplementedError, match="backward"):
         m(torch.zeros(1, 1, 4, 4, device="cuda"))
+
+
+def test_drn_trainer_mirror_runs_an_epoch_on_png_folders(tmp_path):
+    """src/trainer.py's DRN loop on the folder layout src/data.py reads (HR + LR_2 + LR_4): dual models, their Adam
+    optimizers and cosine schedules, checkpoints incl. dual_model_latest.pt."""
+    from PIL import Image
+    from srad_amd import options as Opt
+    from srad_amd.model import Model
+    from srad_amd.trainer import FolderPairs, Trainer
+    rng = np.random.default_rng(0)
+    d = tmp_path / "grid" / "train" / "good"
+    for sub in ("HR", "LR_2", "LR_4"):
+        (d / sub).mkdir(parents=True)
+    yy, xx = np.mgrid[0:64, 0:64]
+    for i in range(4):
+        hr = (127 + 90 * np.sin(xx / (3.0 + i)) * np.cos(yy / 4.0) + rng.normal(0, 4, (64, 64))).clip(0, 255).astype(np.uint8)
+        Image.fromarray(hr).save(d / "HR" / f"{i}.png")
+        Image.fromarray(hr.reshape(32, 2, 32, 2).mean((1, 3)).round().astype(np.uint8)).save(d / "LR_2" / f"{i}.png")
+        Image.fromarray(hr.reshape(16, 4, 16, 4).mean((1, 3)).round().astype(np.uint8)).save(d / "LR_4" / f"{i}.png")
+    opt = Opt.build_opt('drn-l', 'grid', 64, 4, batch_size=2, dtype='fp32', data_root=str(tmp_path), save=str(tmp_path / "run"), epochs=2)
+    opt.n_blocks, opt.print_every = 2, 1
+    assert opt.scale == [2, 4] and opt.weight_decay == 1e-8
+    torch.manual_seed(1)
+    model = Model(opt, None, dual_model=True)
+    ds = FolderPairs(opt.data_dir, list(opt.scale), 1)
+    assert ds.multi and [a.shape for a in ds.items[0][1]] == [(16, 16, 1), (32, 32, 1)]
+    t = Trainer(opt, ds, model, dual_model=True, val_set=ds)
+    while not t.terminate():
+        t.train()
+        model.save(opt.save, is_best=True)
+    assert len(t.loss_log) == 2 and t.loss_log[1] < t.loss_log[0]
+    duals = torch.load(tmp_path / "run" / "model" / "dual_model_latest.pt", weights_only=True)
+    assert isinstance(duals, list) and len(duals) == 2 and set(duals[0]) == {"dual_module.0.0.weight", "dual_module.1.weight"}
+    psnr, ssim = t.test()
+    assert np.isfinite(psnr)
