@@ -76,15 +76,50 @@ __global__ void affine_to_nchw_kernel(const float* __restrict__ x, int ldx, floa
   }
 }
 
-// channel-attention gate: sigmoid(W2 relu(W1 mean + b1) + b2), one workgroup per image (drn.py:128-139)
-__global__ __launch_bounds__(128) void ca_gate_kernel(const float* __restrict__ pool, float inv_hw, int C, int Cr,
+// partial[b][chunk][c] = sum over the chunk's pixels of r[pix][c] (* g[pix][c] when g is given): the global average
+// pool of the channel attention (drn.py:127,136) and, with g, its gate gradient.  Partial rows instead of atomics:
+// float atomicAdd of every conv output element onto B * C addresses made the pooled convolutions 5x slower.
+__global__ __launch_bounds__(256) void pool_dot_kernel(const float* __restrict__ g, const float* __restrict__ r, float* __restrict__ part,
+                                                       int hw, int C, int nchunk) {
+  __shared__ float red[256 * 4];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int c4n = C / 4, nph = 256 / c4n;
+  const int c4 = threadIdx.x % c4n, ph = threadIdx.x / c4n;
+  const int per = (hw + nchunk - 1) / nchunk;
+  const int p0 = chunk * per, p1 = min(hw, p0 + per);
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (ph < nph)
+    for (int px = p0 + ph; px < p1; px += nph) {
+      const size_t o = ((size_t)b * hw + px) * C + c4 * 4;
+      const f32x4 rv = *reinterpret_cast<const f32x4*>(r + o);
+      acc += g ? *reinterpret_cast<const f32x4*>(g + o) * rv : rv;
+    }
+  *reinterpret_cast<f32x4*>(red + threadIdx.x * 4) = acc;
+  __syncthreads();
+  if (threadIdx.x < c4n) {
+    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < nph; ++q) t += *reinterpret_cast<const f32x4*>(red + (q * c4n + threadIdx.x) * 4);
+    *reinterpret_cast<f32x4*>(part + ((size_t)b * nchunk + chunk) * C + threadIdx.x * 4) = t;
+  }
+}
+
+constexpr int DRN_POOL_CHUNKS = 32;
+
+// channel-attention gate: sigmoid(W2 relu(W1 mean + b1) + b2), one workgroup per image (drn.py:128-139); sums the
+// pool_dot partial rows first and (training) keeps the pooled sums
+__global__ __launch_bounds__(128) void ca_gate_kernel(const float* __restrict__ part, int nchunk, float inv_hw, int C, int Cr,
                                                       const float* __restrict__ w1, const float* __restrict__ b1,
                                                       const float* __restrict__ w2, const float* __restrict__ b2,
-                                                      float* __restrict__ gate) {
+                                                      float* __restrict__ gate, float* __restrict__ pool_out) {
   __shared__ float mean[512];
   __shared__ float hid[64];
   const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) mean[c] = pool[(size_t)b * C + c] * inv_hw;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float sum = 0.f;
+    for (int k = 0; k < nchunk; ++k) sum += part[((size_t)b * nchunk + k) * C + c];
+    if (pool_out) pool_out[(size_t)b * C + c] = sum;
+    mean[c] = sum * inv_hw;
+  }
   __syncthreads();
   for (int j = threadIdx.x; j < Cr; j += blockDim.x) {
     float acc = b1[j];
@@ -170,9 +205,8 @@ struct DrnWs {
   float *ra, *rb, *rt, *rr;         // RCAB ping/pong, relu(conv), conv result
   float* ups;                       // conv + pixel-shuffle output
   float* timg;                      // tail conv output [T][C]
-  float* pool;                      // [n_rcab_total][B][chmax]
+  float* pool;                      // [B][DRN_POOL_CHUNKS][chmax] partial sums of the global average pool
   float* gate;                      // [B][chmax]
-  size_t pool_bytes;
   size_t bytes;
 };
 
@@ -206,9 +240,7 @@ DrnWs plan_ws(const srad_drn* h, int B, int H, int W, void* base, size_t cap) {
   }
   w.ups = bp.take(umax);
   w.timg = bp.take(T0 * SRAD_IMG_CPAD);
-  const size_t nr = (size_t)P * c.n_blocks;
-  w.pool_bytes = nr * B * top * sizeof(float);
-  w.pool = bp.take(nr * B * top);
+  w.pool = bp.take((size_t)B * 32 * top);
   w.gate = bp.take((size_t)B * top);
   w.bytes = bp.used;
   return w;
@@ -233,7 +265,6 @@ int forward_body(srad_drn* h, const float* x, int B, int H, int W, float* const*
   const int H0 = H * sc, W0 = W * sc;
   const int top = F << P;
   const int F0 = srad_round_up(F, 4);   // stored width of the level-0 feature groups; pad columns are exact zeros
-  SRAD_CHECK_HIP(hipMemsetAsync(w.pool, 0, w.pool_bytes, s));
   // bicubic upsample to the target size + sub_mean            (drn.py:243-246)
   {
     const size_t tot = (size_t)B * H0 * W0;
@@ -274,21 +305,21 @@ int forward_body(srad_drn* h, const float* x, int B, int H, int W, float* const*
     float* nxt = w.rb;
     for (int b = 0; b < c.n_blocks; ++b) {
       const RcabW& r = h->rcab[idx][b];
-      float* pool = w.pool + ((size_t)idx * c.n_blocks + b) * B * top;
       {  // conv + ReLU                                         (drn.py:147-150)
         GemmParams p = conv_params(h, r.c0, xin, ldin, B, Hl, Wl, 1, w.rt, ch, 0);
         p.act = SRAD_ACT_RELU;
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
-      {  // conv, with the global-average-pool sums taken in the epilogue (drn.py:127,136)
+      {  // conv                                                 (drn.py:147-150)
         GemmParams p = conv_params(h, r.c1, w.rt, ch, B, Hl, Wl, 1, w.rr, ch, 0);
-        p.pool = pool;
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
-      {
-        SradProfScope prof(s, SRAD_K_MISC, 4.0 * B * ch * (ch / 16), 8.0 * B * ch);
-        hipLaunchKernelGGL(ca_gate_kernel, dim3(B), dim3(128), 0, s, pool, 1.0f / (float)(Hl * Wl), ch, ch / 16,
-                           h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2), w.gate);
+      {  // global average pool (partial rows) + the gate       (drn.py:127-138)
+        SradProfScope prof(s, SRAD_K_MISC, 1.0 * T * ch + 4.0 * B * ch * (ch / 16), 4.0 * T * ch);
+        hipLaunchKernelGGL(pool_dot_kernel, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, (const float*)nullptr, w.rr, w.pool, Hl * Wl, ch,
+                           DRN_POOL_CHUNKS);
+        hipLaunchKernelGGL(ca_gate_kernel, dim3(B), dim3(128), 0, s, w.pool, DRN_POOL_CHUNKS, 1.0f / (float)(Hl * Wl), ch, ch / 16,
+                           h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2), w.gate, (float*)nullptr);
       }
       {  // res = body(x) * gate + x                             (drn.py:139, 156-157)
         SradProfScope prof(s, SRAD_K_MISC, 2.0 * T * ch, 12.0 * T * ch);
@@ -548,30 +579,6 @@ __global__ void zero_upsample_kernel(const float* __restrict__ dy, float* __rest
   }
 }
 
-// partial[b][chunk][c] = sum over the chunk's pixels of g[pix][c] * r[pix][c]     (channel-attention gate gradient)
-__global__ __launch_bounds__(256) void pool_dot_kernel(const float* __restrict__ g, const float* __restrict__ r, float* __restrict__ part,
-                                                       int hw, int C, int nchunk) {
-  __shared__ float red[256 * 4];
-  const int b = blockIdx.y, chunk = blockIdx.x;
-  const int c4n = C / 4, nph = 256 / c4n;
-  const int c4 = threadIdx.x % c4n, ph = threadIdx.x / c4n;
-  const int per = (hw + nchunk - 1) / nchunk;
-  const int p0 = chunk * per, p1 = min(hw, p0 + per);
-  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (ph < nph)
-    for (int px = p0 + ph; px < p1; px += nph) {
-      const size_t o = ((size_t)b * hw + px) * C + c4 * 4;
-      acc += *reinterpret_cast<const f32x4*>(g + o) * *reinterpret_cast<const f32x4*>(r + o);
-    }
-  *reinterpret_cast<f32x4*>(red + threadIdx.x * 4) = acc;
-  __syncthreads();
-  if (threadIdx.x < c4n) {
-    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int q = 0; q < nph; ++q) t += *reinterpret_cast<const f32x4*>(red + (q * c4n + threadIdx.x) * 4);
-    *reinterpret_cast<f32x4*>(part + ((size_t)b * nchunk + chunk) * C + threadIdx.x * 4) = t;
-  }
-}
-
 // CALayer backward (src/drn.py:123-139) for all images of the batch in ONE workgroup (the work is C * C/16 MACs per
 // image): dgate = sum of the pool_dot partials; through the sigmoid, the two 1x1 convs and the ReLU back to the mean;
 // dpool[b][c] = dmean[c] / HW.  Weight / bias gradients are summed over the images in LDS and added to the flat
@@ -708,8 +715,6 @@ struct DrnTrainWs {
   std::vector<float*> gcat;
   size_t bytes;
 };
-
-constexpr int DRN_POOL_CHUNKS = 32;
 
 DrnTrainWs plan_train_ws(const srad_drn* h, int B, int H, int W, void* base, size_t cap) {
   const srad_drn_config& c = h->cfg;
@@ -876,7 +881,6 @@ int srad_drn_forward_train(srad_drn_t* h, const float* x, int B, int H, int W, f
     for (int b = 0; b < c.n_blocks; ++b) {
       const RcabW& r = h->rcab[idx][b];
       const RcabSave& sv = w.rc[idx][b];
-      SRAD_CHECK_HIP(hipMemsetAsync(sv.pool, 0, (size_t)B * ch * sizeof(float), s));
       {
         GemmParams p = conv_params(h, r.c0, xin, ldin, B, Hl, Wl, 1, sv.t, ch, 0);
         p.act = SRAD_ACT_RELU;
@@ -884,11 +888,12 @@ int srad_drn_forward_train(srad_drn_t* h, const float* x, int B, int H, int W, f
       }
       {
         GemmParams p = conv_params(h, r.c1, sv.t, ch, B, Hl, Wl, 1, sv.r, ch, 0);
-        p.pool = sv.pool;
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
-      hipLaunchKernelGGL(ca_gate_kernel, dim3(B), dim3(128), 0, s, sv.pool, 1.0f / (float)(Hl * Wl), ch, ch / 16,
-                         h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2), sv.gate);
+      hipLaunchKernelGGL(pool_dot_kernel, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, (const float*)nullptr, sv.r, w.ppart, Hl * Wl, ch,
+                         DRN_POOL_CHUNKS);
+      hipLaunchKernelGGL(ca_gate_kernel, dim3(B), dim3(128), 0, s, w.ppart, DRN_POOL_CHUNKS, 1.0f / (float)(Hl * Wl), ch, ch / 16,
+                         h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2), sv.gate, sv.pool);
       hipLaunchKernelGGL(scale_add_kernel, dim3(grid1d(T * ch / 4)), dim3(256), 0, s, sv.r, sv.gate, xin, ldin, sv.xo, T, ch, Hl * Wl);
       SRAD_CHECK_HIP(hipGetLastError());
       xin = sv.xo; ldin = ch;

@@ -473,7 +473,7 @@ int launch_one(const GemmParams& p, hipStream_t s) {
     configured = true;
   }
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
-  const int cls = BN == 64 ? SRAD_K_GEMM_BN64 : (BN == 32 ? SRAD_K_GEMM_BN32 : SRAD_K_GEMM_BN16);
+  const int cls = BN >= 64 ? SRAD_K_GEMM_BN64 : (BN == 32 ? SRAD_K_GEMM_BN32 : SRAD_K_GEMM_BN16);
   // algorithmic work: 2*M*N*K flops; bytes = A rows once + packed W once + Y once (+ residual)
   const double K = (double)p.ntaps * p.Cin;
   const double wbytes = (double)p.N * K * (PREC == SRAD_PREC_BF16 ? 2 : 4);
@@ -513,6 +513,8 @@ int launch_prec(const GemmParams& p, hipStream_t s) {
     if (p.N <= 32 && tiles(128, 32) >= 384) return launch_cfg<PREC, 128, 32, 4, 1>(p, s);
   }
   if (p.N <= 32) return launch_cfg<PREC, 32, 32, 2, 2>(p, s);
+  // N = 65..80 (DRN's 80-channel RCAB convolutions): one 80-wide tile instead of a full and a mostly empty 64-wide one
+  if (!p.ln_g && p.N > 64 && p.N <= 80 && tiles(64, 80) >= 384) return launch_cfg<PREC, 64, 80, 4, 1>(p, s);
   if (tiles(64, 64) >= 384) return launch_cfg<PREC, 64, 64, 2, 2>(p, s);
   if (tiles(32, 64) >= 384) return launch_cfg<PREC, 32, 64, 2, 2>(p, s);
   return launch_cfg<PREC, 32, 32, 2, 2>(p, s);

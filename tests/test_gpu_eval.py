@@ -84,9 +84,9 @@ def test_model_checkpoint_surface(tmp_path):
     assert make_model(opt) is None
 
 
-def test_training_mode_drct_trains_drn_is_refused():
-    """DRCT has the HIP backward (tests/test_gpu_train.py); DRN's is not built: a training-mode forward with grad
-    enabled must say so instead of silently returning a graph-less tensor."""
+def test_training_mode_through_the_model_wrapper():
+    """Model(opt) in train() mode: DRCT and DRN-L x4 return tensors with a graph and fill the flat gradient buffer;
+    the DRN x8 preset (n_feats = 10, zero-padded layers) has no backward and must say so."""
     from srad_amd import options as Opt
     from srad_amd.model import Model
     opt = Opt.build_opt('drct', 'grid', 64, 4)
@@ -99,7 +99,16 @@ def test_training_mode_drct_trains_drn_is_refused():
     y.mean().backward()
     assert float(m.model.flat_grads.abs().sum()) > 0
     opt = Opt.build_opt('drn-l', 'grid', 64, 4)
+    opt.n_blocks = 2
+    m = Model(opt, None)
+    m.train()
+    ys = m(torch.rand(1, 1, 16, 16, device='cuda') * 255)
+    assert len(ys) == 3 and ys[-1].requires_grad
+    (ys[-1].mean() + ys[0].mean()).backward()
+    assert float(m.model.flat_grads.abs().sum()) > 0
+    opt = Opt.build_opt('drn-l', 'grid', 64, 8)
+    opt.n_blocks = 2
     m = Model(opt, None)
     m.train()
     with pytest.raises(NotImplementedError, match="backward"):
-        m(torch.zeros(1, 1, 16, 16, device='cuda'))
+        m(torch.zeros(1, 1, 8, 8, device='cuda'))
