@@ -219,6 +219,35 @@ def c5_leg(args, torch, dev):
     return out
 
 
+def c3_leg(args, torch, dev):
+    """BASELINE config C3: DRN-L x4 forward, carpet-shaped RGB input, 256 px HR, batch 8 (LR [8,3,64,64])."""
+    from srad_amd.nets import DRN
+
+    class DrnOpt:
+        n_colors, n_blocks, n_feats, negval, rgb_range, scale = 3, 40, 20, 0.2, 255.0, [2, 4]
+        precision, use_graph = args.dtype, True
+    torch.manual_seed(1)
+    m = DRN(DrnOpt()).to(dev).eval()
+    x = torch.rand(8, 3, 64, 64, device=dev) * 255.0
+    steps = 20
+    with torch.no_grad():
+        for _ in range(3):
+            m(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m(x)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    fl = m.flops(8, 64, 64)
+    out = {"workload": "C3: DRN-L x4 forward, RGB, 256 px HR, batch 8 (LR [8,3,64,64])", "ms_per_batch": round(dt * 1e3, 3),
+           "hr_mpixels_per_s": round(8 * 256 * 256 / dt / 1e6, 2), "algorithmic_gflop": round(fl / 1e9, 1),
+           "model_tflops": round(fl / dt / 1e12, 1)}
+    del m
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -386,6 +415,7 @@ def main():
         if n_gpus == 1 and not args.no_eval:
             result["anomaly_eval"] = anomaly_eval_leg(model, args, torch)
             result["eval_1024px_tile"] = c5_leg(args, torch, dev)
+            result["drn_forward"] = c3_leg(args, torch, dev)
         print(json.dumps(result))
     if world > 1:
         dist.barrier()
