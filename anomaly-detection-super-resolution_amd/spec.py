@@ -312,3 +312,28 @@ def synth_image(name: str, shape, seed: int = 1, rgb_range: float = 255.0) -> np
     """LR tile in [0, rgb_range] (value range of the reference loader, data.py:11-17)."""
     n = int(np.prod(shape))
     return (det_uniform(name, n, seed).reshape(shape) * rgb_range).astype(np.float32)
+
+
+# -------------------------------------------------------------------------------------- synthetic scorer inputs
+def synth_pairs(n_good: int, n_bad: int, size: int, channels: int = 1, seed: int = 0
+                ) -> Tuple[List[int], List[np.ndarray], List[np.ndarray]]:
+    """Grid-textured u8 HR images; SR = HR + noise, with planted blobs in the 'bad' half."""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32)
+    y_true, sr, hr = [], [], []
+    for i in range(n_good + n_bad):
+        period = 6 + (i % 5)
+        tex = 120 + 60 * np.sin(2 * np.pi * xx / period) * np.sin(2 * np.pi * yy / period)
+        tex = tex[..., None] + rng.normal(0, 4, (size, size, channels))
+        h = np.clip(tex, 0, 255).astype(np.uint8)
+        s = h.astype(np.float32) + rng.normal(0, 3, h.shape)
+        bad = i >= n_good
+        if bad:
+            cy, cx = rng.randint(size // 4, 3 * size // 4, 2)
+            r = max(2, size // 12)
+            blob = ((yy - cy) ** 2 + (xx - cx) ** 2) < r * r
+            s[blob] += rng.uniform(15, 50)
+        y_true.append(int(bad))
+        sr.append(np.clip(s, 0, 255).astype(np.uint8))
+        hr.append(h)
+    return y_true, sr, hr

@@ -50,12 +50,12 @@ def anomaly_eval_leg(model, args, torch):
     (SR forward + truncating u8 + SSIM window sweep + MSE + PSNR + the three AUCs) on an MVTec-grid sized
     synthetic test split (21 good + 57 bad pairs, 128 px HR), and the AUCs against the CPU oracle."""
     import numpy as np
-    from oracle import scorer_ref as O
     from srad_amd import evaluate as E
+    from srad_amd.spec import synth_pairs
 
     class EvalOpt:
         rgb_range = 255.0
-    y, sr_u8, hr_u8 = O.synth_pairs(21, 57, 128, 1, seed=0)
+    y, sr_u8, hr_u8 = synth_pairs(21, 57, 128, 1, seed=0)
     pairs = []
     for s_img, h_img in zip(sr_u8, hr_u8):           # LR = 4x4 box average of the (defective) image
         lr = s_img.reshape(32, 4, 32, 4, 1).astype(np.float32).mean((1, 3))
@@ -79,6 +79,7 @@ def anomaly_eval_leg(model, args, torch):
            "auc": {k: round(got[k], 4) for k in ("auc_ssim", "auc_mse", "auc_psnr")}, "best_ws": got["best_ws"]}
     # CPU baseline of the scorer: the reference's per-pixel-loop ssim_numpy semantics (oracle, literal
     # loop) on a bounded sample: 1 pair x all window sizes, single core
+    from oracle import scorer_ref as O          # cpu_baseline leg only: the checker, never the thing measured
     t0 = time.perf_counter()
     sizes = O.sweep_window_sizes(128)
     for ws in sizes:
