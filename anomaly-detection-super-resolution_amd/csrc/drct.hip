@@ -268,6 +268,8 @@ int srad_drct_create(const srad_drct_config* cfg, srad_drct_t** out) {
 void srad_drct_destroy(srad_drct_t* h) {
   if (!h) return;
   h->gc.reset();
+  for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
+  if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
 }
 

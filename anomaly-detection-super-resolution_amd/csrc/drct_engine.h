@@ -23,4 +23,6 @@ struct srad_drct {
   bool fuse_mlp = true;           // bf16: second half of each Swin block as one launch (kernels_fused.hip)
   GraphCache gc;
   TrainState ts;                  // training (drct_train.hip)
+  hipStream_t side = nullptr;     // weight gradients run here, next to the data-gradient chain on the caller's stream
+  std::vector<hipEvent_t> events; // reused across backward calls
 };

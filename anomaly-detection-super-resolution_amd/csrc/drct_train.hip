@@ -27,7 +27,8 @@ struct TrainWs {
   float *body, *c1, *c2, *outn;
   std::vector<float*> upb;
   // backward temporaries
-  float *dimg, *dus, *dc2, *dc1, *dbody, *g0, *g1, *dx2, *dxn, *dx1, *dO, *dA, *dh, *dqkv, *dfeat, *dxin;
+  float *dimg, *dus, *dc2, *dc1, *dbody, *g0, *g1, *dxn, *dO, *dfeat, *dxin;
+  float *dx2[2], *dx1[2], *dA[2], *dh[2], *dqkv[2];   // read by the side stream's weight gradients: two sets, alternating per block
   std::vector<float*> dup;            // gradient of upb[j]
   size_t bytes;
 };
@@ -59,8 +60,11 @@ TrainWs plan_train_ws(const srad_drct* h, int B, int H, int W, void* base, size_
   w.dus = bp.take((h->up.empty() ? T : Tout / 4) * 4 * F);
   w.dc2 = bp.take(T * F); w.dc1 = bp.take(T * E); w.dbody = bp.take(T * E);
   w.g0 = bp.take(T * D); w.g1 = bp.take(T * D);
-  w.dx2 = bp.take(T * h->dmax); w.dxn = bp.take(T * h->dmax); w.dx1 = bp.take(T * h->dmax); w.dO = bp.take(T * h->dmax);
-  w.dA = bp.take(T * E); w.dh = bp.take(T * h->hmax); w.dqkv = bp.take(T * 3 * h->dmax);
+  w.dxn = bp.take(T * h->dmax); w.dO = bp.take(T * h->dmax);
+  for (int k = 0; k < 2; ++k) {
+    w.dx2[k] = bp.take(T * h->dmax); w.dx1[k] = bp.take(T * h->dmax); w.dA[k] = bp.take(T * E);
+    w.dh[k] = bp.take(T * h->hmax); w.dqkv[k] = bp.take(T * 3 * h->dmax);
+  }
   w.dfeat = bp.take(T * E); w.dxin = bp.take(T * SRAD_IMG_CPAD);
   w.bytes = bp.used;
   return w;
@@ -293,6 +297,46 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
   int hh = H << stages, ww = W << stages;
   float* G = flat_grad;
   WgradQueue wq = train_wgrad_queue(h->ts);   // split-K partials of the weight gradients, reduced once per Swin block
+  // Two streams: the data-gradient chain (each kernel needs the previous one's output) stays on the caller's stream;
+  // the weight gradients, which nothing in the backward waits for, run on a side stream and fill the idle CUs.
+  // Set SRAD_BWD_ONE_STREAM=1 to keep everything on the caller's stream.
+  static const bool one_stream = getenv("SRAD_BWD_ONE_STREAM") != nullptr;
+  if (!one_stream && !h->side) {
+    int lo = 0, hi = 0;                          // lowest priority: the chain on the caller's stream gets the CUs first
+    SRAD_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    SRAD_CHECK_HIP(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo));
+  }
+  hipStream_t side = one_stream ? s : h->side;
+  size_t ev_next = 0;
+  auto next_event = [&](hipEvent_t* out) -> int {
+    if (ev_next == h->events.size()) {
+      hipEvent_t ev = nullptr;
+      SRAD_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      h->events.push_back(ev);
+    }
+    *out = h->events[ev_next++];
+    return SRAD_OK;
+  };
+  auto side_waits_main = [&]() -> int {          // everything enqueued on the caller's stream so far is visible to the side stream
+    if (side == s) return SRAD_OK;
+    hipEvent_t ev;
+    SRAD_TRY(next_event(&ev));
+    SRAD_CHECK_HIP(hipEventRecord(ev, s));
+    SRAD_CHECK_HIP(hipStreamWaitEvent(side, ev, 0));
+    return SRAD_OK;
+  };
+  auto main_waits_side = [&]() -> int {
+    if (side == s) return SRAD_OK;
+    hipEvent_t ev;
+    SRAD_TRY(next_event(&ev));
+    SRAD_CHECK_HIP(hipEventRecord(ev, side));
+    SRAD_CHECK_HIP(hipStreamWaitEvent(s, ev, 0));
+    return SRAD_OK;
+  };
+  const size_t wq_half = wq.ws_floats / 2;
+  float* const wq_base = wq.ws;
+  hipEvent_t side_done[2] = {nullptr, nullptr};    // side stream finished block n - 2 / n - 1 (their temporaries are free)
+  int blk_count = 0;
 
   // dLoss/d(outn) = dy / img_range, NCHW -> NHWC (pad channels zero)           (drct.py:897)
   SRAD_TRY(srad_launch_nchw_to_nhwc(dy, w.dimg, B, c.in_chans, SRAD_IMG_CPAD, hh, ww, zero3, 1.0f / c.img_range, s));
@@ -358,79 +402,97 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       const int d = sw.d, hdp = hdp_of(d, sw.heads);
       const float* ks1 = keep_scale ? keep_scale + (size_t)(2 * bi) * B : nullptr;
       const float* ks2 = keep_scale ? keep_scale + (size_t)(2 * bi + 1) * B : nullptr;
+      const int set = blk_count & 1;                       // temporaries + partial workspace of this block
+      if (side != s && side_done[set]) SRAD_CHECK_HIP(hipStreamWaitEvent(s, side_done[set], 0));   // block n - 2 fully consumed
+      wq.ws = wq_base + (size_t)set * wq_half; wq.ws_floats = wq_half;
+      float *dx2 = w.dx2[set], *dx1 = w.dx1[set], *dh = w.dh[set], *dqkv = w.dqkv[set];
       // ---- adjust_k: 1x1 conv (+ LeakyReLU 0.2 | * 0.2)                        (drct.py:389-393)
-      const float* dA; int ldA, no; float aalpha = 1.f;
+      const float* dA; int ldA; float aalpha = 1.f;
       if (k < 4) {
-        SRAD_TRY(srad_launch_dact(gc + d, D, cur + d, D, w.dA, c.gc, T, c.gc, 0.2f, s));
-        dA = w.dA; ldA = c.gc; no = c.gc;
+        SRAD_TRY(srad_launch_dact(gc + d, D, cur + d, D, w.dA[set], c.gc, T, c.gc, 0.2f, s));
+        dA = w.dA[set]; ldA = c.gc;
       } else {
-        dA = gn; ldA = D; no = E; aalpha = 0.2f;
+        dA = gn; ldA = D; aalpha = 0.2f;
       }
+      SRAD_TRY(side_waits_main());
       {
         WgradParams g = wgrad_of(h, sw.adjust, G, dA, ldA, 0, sv.x2, d, T);
         g.alpha = aalpha;
-        SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
-        GemmParams p = dgrad_gemm(h, sw.adjust, dA, ldA, T, w.dx2, d);
+        SRAD_TRY(srad_launch_wgrad(prec, g, wq, side));
+        GemmParams p = dgrad_gemm(h, sw.adjust, dA, ldA, T, dx2, d);
         p.alpha = aalpha;
         SRAD_TRY(srad_launch_gemm(prec, p, s));
-        (void)no;
       }
       // ---- MLP branch: x2 = x1 + rs2 * fc2(gelu(fc1(LN2(x1))))                 (drct.py:510, 184-190)
+      SRAD_TRY(side_waits_main());
       {
-        WgradParams g = wgrad_of(h, sw.fc2, G, w.dx2, d, 0, sv.hact, sw.hidden, T);
+        WgradParams g = wgrad_of(h, sw.fc2, G, dx2, d, 0, sv.hact, sw.hidden, T);
         g.row_scale = ks2; g.rps = HW;
-        SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
-        GemmParams p = dgrad_gemm(h, sw.fc2, w.dx2, d, T, w.dh, sw.hidden);
+        SRAD_TRY(srad_launch_wgrad(prec, g, wq, side));
+        GemmParams p = dgrad_gemm(h, sw.fc2, dx2, d, T, dh, sw.hidden);
         p.row_scale = ks2; p.rps = HW; p.R = sv.hpre; p.ldr = sw.hidden; p.rmode = SRAD_RMODE_DGELU;
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
+      SRAD_TRY(side_waits_main());
       {
-        WgradParams g = wgrad_of(h, sw.fc1, G, w.dh, sw.hidden, 0, sv.xn2, d, T);
-        SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
-        GemmParams p = dgrad_gemm(h, sw.fc1, w.dh, sw.hidden, T, w.dxn, d);
+        WgradParams g = wgrad_of(h, sw.fc1, G, dh, sw.hidden, 0, sv.xn2, d, T);
+        SRAD_TRY(srad_launch_wgrad(prec, g, wq, side));
+        GemmParams p = dgrad_gemm(h, sw.fc1, dh, sw.hidden, T, w.dxn, d);
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
       {  // dx1 = dx2 + dLN2(dxn)
         LnBwdParams l{};
         l.dxn = w.dxn; l.ld_dxn = d; l.x = sv.x1; l.ldx = d; l.gamma = h->pt.fptr(sw.n2g);
-        l.dres = w.dx2; l.ld_dres = d; l.out = w.dx1; l.ld_out = d;
+        l.dres = dx2; l.ld_dres = d; l.out = dx1; l.ld_out = d;
         l.dgamma = G + h->ts.flat_off[sw.n2g]; l.dbeta = G + h->ts.flat_off[sw.n2b];
         l.rows = T; l.C = d; l.eps = 1e-5f;
         SRAD_TRY(srad_launch_ln_bwd(l, wq, s));
       }
       // ---- attention branch: x1 = x + rs1 * proj(attn(LN1(x)))                  (drct.py:477-509)
+      SRAD_TRY(side_waits_main());
       {
-        WgradParams g = wgrad_of(h, sw.proj, G, w.dx1, d, 0, sv.attn, d, T);
+        WgradParams g = wgrad_of(h, sw.proj, G, dx1, d, 0, sv.attn, d, T);
         g.row_scale = ks1; g.rps = HW;
-        SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
-        GemmParams p = dgrad_gemm(h, sw.proj, w.dx1, d, T, w.dO, d);
+        SRAD_TRY(srad_launch_wgrad(prec, g, wq, side));
+        GemmParams p = dgrad_gemm(h, sw.proj, dx1, d, T, w.dO, d);
         p.row_scale = ks1; p.rps = HW;
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
       {
-        AttnBwdParams a{sv.qkv, w.dO, w.dqkv, h->pt.fptr(sw.table), G + h->ts.flat_off[sw.table], B, H, W, c.window_size,
+        AttnBwdParams a{sv.qkv, w.dO, dqkv, h->pt.fptr(sw.table), G + h->ts.flat_off[sw.table], B, H, W, c.window_size,
                         sw.shift, d, sw.heads, hdp};
         SRAD_TRY(srad_launch_window_attn_bwd(a, wq, s));
       }
+      SRAD_TRY(side_waits_main());
       {
-        WgradParams g = wgrad_of(h, sw.qkv, G, w.dqkv, 3 * d, 0, sv.xn1, d, T);
-        SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
-        GemmParams p = dgrad_gemm(h, sw.qkv, w.dqkv, 3 * d, T, w.dxn, d);
+        WgradParams g = wgrad_of(h, sw.qkv, G, dqkv, 3 * d, 0, sv.xn1, d, T);
+        SRAD_TRY(srad_launch_wgrad(prec, g, wq, side));
+        GemmParams p = dgrad_gemm(h, sw.qkv, dqkv, 3 * d, T, w.dxn, d);
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
       {  // gc[:, :d] += dx1 + dLN1(dxn)
         LnBwdParams l{};
         l.dxn = w.dxn; l.ld_dxn = d; l.x = cur; l.ldx = D; l.gamma = h->pt.fptr(sw.n1g);
-        l.dres = w.dx1; l.ld_dres = d; l.out = gc; l.ld_out = D; l.accumulate = 1;
+        l.dres = dx1; l.ld_dres = d; l.out = gc; l.ld_out = D; l.accumulate = 1;
         l.dgamma = G + h->ts.flat_off[sw.n1g]; l.dbeta = G + h->ts.flat_off[sw.n1b];
         l.rows = T; l.C = d; l.eps = 1e-5f;
         SRAD_TRY(srad_launch_ln_bwd(l, wq, s));
       }
-      SRAD_TRY(srad_wgrad_flush(wq, s));              // this block's five weight gradients, one launch
+      // this block's five weight gradients + LayerNorm / bias-table column sums, one launch on the side stream
+      // (after the caller's stream has written its partial rows)
+      SRAD_TRY(side_waits_main());
+      SRAD_TRY(srad_wgrad_flush(wq, side));
+      if (side != s) {
+        SRAD_TRY(next_event(&side_done[set]));
+        SRAD_CHECK_HIP(hipEventRecord(side_done[set], side));
+      }
+      ++blk_count;
     }
+    SRAD_TRY(main_waits_side());                         // the RDG's gradients are final on the caller's stream
     float* t = gn; gn = gc; gc = t;
     if (on_bucket) on_bucket(user, c.n_rdg - i);
   }
+  wq.ws = wq_base; wq.ws_floats = 2 * wq_half;           // the remaining layers run on the caller's stream only
   {  // patch_embed.norm, joined by the long skip of conv_after_body(...) + x      (drct.py:873, 893)
     LnBwdParams l{};
     l.dxn = gn; l.ld_dxn = D; l.x = w.feat0; l.ldx = E; l.gamma = h->pt.fptr(h->pe_g);

@@ -38,6 +38,9 @@ static inline int grid_for(size_t total) {
 // release/acquire fences it needs write back / invalidate a whole XCD L2 because the eight L2s are not
 // coherent with each other: 60-90 us per layer).  A kernel boundary is the cheap cross-XCD barrier.
 // ------------------------------------------------------------------------------------------
+#ifndef SRAD_WGRAD_PREFETCH
+#define SRAD_WGRAD_PREFETCH 1   /* two register sets: measured best together with the two-stream backward */
+#endif
 constexpr int WG_TS = 64 * 64 + 64;          // floats per partial: the tile and its 64 bias sums
 constexpr int LNB_RPW = 32;                  // LayerNorm backward: rows per workgroup
 constexpr int LNB_J4 = 2;                    // float4 chunks per lane: 2 * 256 = 512 channels at most
@@ -78,9 +81,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const i
 
   // every load is unconditional on a clamped address; masking happens on the registers afterwards.
   // The next step's loads are issued before this step's MFMAs (two register sets).
-  f32x4 av[2][RL], bv[2][RL];
+  f32x4 av[1 + SRAD_WGRAD_PREFETCH][RL], bv[1 + SRAD_WGRAD_PREFETCH][RL];
   unsigned okm[2];                    // bit t: a row valid, bit 8 + t: b row valid
-  float rs[2][RL];
+  float rs[1 + SRAD_WGRAD_PREFETCH][RL];
   auto load_step = [&](int m0, auto set_c) {
     constexpr int set = decltype(set_c)::value;
     unsigned ok = 0u;
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const i
     using S1 = std::integral_constant<int, 1>;
     constexpr int ST = 4 * KR;
     int m0 = mb + wave * KR;
+#if SRAD_WGRAD_PREFETCH
     if (m0 < me) load_step(m0, S0{});
     while (m0 < me) {
       if (m0 + ST < me) load_step(m0 + ST, S1{});
@@ -159,6 +163,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const i
       compute_step(S1{});
       m0 += ST;
     }
+#else
+    (void)sizeof(S1);
+    for (; m0 < me; m0 += ST) { load_step(m0, S0{}); compute_step(S0{}); }
+#endif
   }
 
   // ---- the four waves' partial tiles through LDS (plain 16-byte stores): lane (fq, fr) element e of
