@@ -119,12 +119,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   f32x4 a_reg[RPT][CPA];
   unsigned a_ok = 0u;                                          // bit (i*CPA + j): block holds real data
   constexpr int W_SEGS = 32 * (int)sizeof(T) / 16;           // 16-byte segments per chunk per W row
-  static_assert(CPS * W_SEGS == 32, "W stage rows are 32 x 16 bytes");
+  constexpr int SEGS = CPS * W_SEGS;                         // 16-byte segments per W stage row
+  constexpr int WRP = 256 / SEGS;                            // W rows per pass of the 256 threads
+  static_assert(SEGS == 32 || SEGS == 16, "W stage rows are 32 or 16 x 16 bytes");
   static_assert(RPT * CPA <= 32, "a_ok bitmask too small");
-  constexpr int W_PT = BN / 8;                                // rows tid/32 + 8*j, segment tid%32
+  constexpr int W_PT = BN / WRP;                              // rows tid/SEGS + WRP*j, segment tid%SEGS
+  static_assert(W_PT * WRP == BN, "W rows must divide over the threads");
   u32x4 w_reg[W_PT];
-  const int w_seg = tid & 31;
-  const unsigned w_off0 = (unsigned)((tid >> 5) * Kp) * (unsigned)sizeof(T);
+  const int w_seg = tid % SEGS;
+  const unsigned w_off0 = (unsigned)((tid / SEGS) * Kp) * (unsigned)sizeof(T);
   const char* const Wb = reinterpret_cast<const char*>(p.Wp) + (size_t)n0 * Kp * sizeof(T);
   [[maybe_unused]] int ld_tap = 0, ld_c0 = 0;                  // conv: running (tap, channel) of the next chunk
 
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     const char* wb = Wb + (size_t)ch0 * 32 * sizeof(T);
 #pragma unroll
     for (int j = 0; j < W_PT; ++j)
-      w_reg[j] = *reinterpret_cast<const u32x4*>(wb + (size_t)j * 8 * Kp * sizeof(T) + woff);
+      w_reg[j] = *reinterpret_cast<const u32x4*>(wb + (size_t)j * WRP * Kp * sizeof(T) + woff);
   };
   [[maybe_unused]] float ln_mu[RPT], ln_rs[RPT];
   auto store_a = [&]() {
@@ -205,9 +208,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     }
   };
   auto store_w = [&]() {
-    char* wdst = reinterpret_cast<char*>(Ws) + ((tid >> 5) * STW) * (int)sizeof(T) + w_seg * 16;
+    char* wdst = reinterpret_cast<char*>(Ws) + ((tid / SEGS) * STW) * (int)sizeof(T) + w_seg * 16;
 #pragma unroll
-    for (int j = 0; j < W_PT; ++j) *reinterpret_cast<u32x4*>(wdst + j * 8 * STW * (int)sizeof(T)) = w_reg[j];
+    for (int j = 0; j < W_PT; ++j) *reinterpret_cast<u32x4*>(wdst + j * WRP * STW * (int)sizeof(T)) = w_reg[j];
   };
 
   // ---- issue every independent load now: first A/W stage, LN gamma/beta, bias, residual ----
@@ -459,9 +462,9 @@ __global__ void pack_weight_t_kernel(const float* __restrict__ src, void* __rest
   }
 }
 
-template <int PREC, int BM, int BN, int WMV, int WNV, bool LN, bool CONV, bool SPECIAL>
+template <int PREC, int BM, int BN, int WMV, int WNV, bool LN, bool CONV, bool SPECIAL, int CPS_ = 0>
 int launch_one(const GemmParams& p, hipStream_t s) {
-  constexpr int CPS = PREC == SRAD_PREC_BF16 ? 8 : 4;
+  constexpr int CPS = CPS_ ? CPS_ : (PREC == SRAD_PREC_BF16 ? 8 : 4);
   constexpr int CPA = LN ? CPS + (PREC == SRAD_PREC_BF16 ? 2 : 6) : CPS;
   using T = typename PrecT<PREC>::type;
   constexpr size_t lds = ((size_t)BM * (CPA * 32 + PrecT<PREC>::PAD) + (size_t)BN * (CPS * 32 + PrecT<PREC>::PAD)) * sizeof(T) +
@@ -498,6 +501,11 @@ int launch_cfg(const GemmParams& p, hipStream_t s) {
     } else {
       return srad_set_error(SRAD_ERR_ARG, "gemm: LayerNorm fusion needs N > 32");
     }
+  }
+  if constexpr (PREC == SRAD_PREC_BF16 && BM == 64 && BN == 64) {
+    // 128-wide K stages (half the LDS, four workgroups per CU, deeper load / MFMA overlap): 4 % on the training step
+    return special ? launch_one<PREC, BM, BN, WMV, WNV, false, false, true, 4>(p, s)
+                   : launch_one<PREC, BM, BN, WMV, WNV, false, false, false, 4>(p, s);
   }
   return special ? launch_one<PREC, BM, BN, WMV, WNV, false, false, true>(p, s)
                  : launch_one<PREC, BM, BN, WMV, WNV, false, false, false>(p, s);
