@@ -7,10 +7,11 @@
 // arithmetic, never copies), streams the window's keys in chunks of 64 with an online softmax
 // (so N = ws^2 of 4 ... 4096 tokens all take the same path), adds the relative-position bias
 // and the 0/-100 shift mask computed on the fly, and scatters P.V back to raster order.
-//   S = (q*scale) k^T : MFMA, A = Q tile in LDS, B = K chunk in LDS (both head-dim contiguous)
-//   softmax           : C-layout registers, 16-lane xor-shuffle row reductions
-//   O += P V          : P through LDS (per-wave 16-row slab); V stays row-major in LDS and is read
-//                       as the MFMA B operand with ds_read_b64_tr_b16 (hardware transpose read)
+//   S^T = k (q*scale)^T : MFMA with swapped operands (A = K chunk, B = Q slab, both head-dim contiguous in LDS):
+//                         a lane then holds 16 scores of ONE query
+//   softmax             : per-lane scalars + two cross-row shuffles per reduction
+//   O^T += V^T P^T      : P^T is already the B operand in registers (never through LDS); V stays row-major in LDS
+//                         and is read as the A operand with ds_read_b64_tr_b16 (hardware transpose read)
 //
 // Input layout ("head-padded"): row t = [q | k | v], each [heads][hdp] floats, hdp = head_dim
 // rounded up to a multiple of 4 so every (token, head) slice is float4-addressable.  The QKV GEMM
@@ -38,13 +39,13 @@ __device__ __forceinline__ void store4(typename AT<PREC>::type* dst, f32x4 v) {
 // sixteen look-ups per lane and chunk became branchy flat loads, each waited for before the next.
 // NW = waves per workgroup = 16-query slabs per workgroup: 4 for windows of up to 64 tokens, 8 above (the K / V
 // chunk and the bias table in LDS are then shared by 128 queries and two waves per SIMD hide each other's latency).
-template <int PREC, int NT_O, bool TBL_LDS, int NW>
+// FULL: the window's token count is a multiple of 64, no key of a chunk needs masking out.
+template <int PREC, int NT_O, bool TBL_LDS, int NW, bool FULL>
 __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p) {
   using T = typename AT<PREC>::type;
   constexpr int PAD = AT<PREC>::PAD;
   constexpr int HDP = NT_O * 16;
   constexpr int HS = HDP + PAD;      // Q/K/V row stride (elements)
-  constexpr int KS = 64 + PAD;       // P row stride
   constexpr int V4R = HDP / 4;       // float4 per staged row
   constexpr int NT = NW * 64;        // threads
   constexpr int BQ = NW * 16;        // query rows per workgroup
@@ -55,8 +56,7 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
   T* Qs = reinterpret_cast<T*>(smem);
   T* Ks = Qs + BQ * HS;
   T* Vs = Ks + 64 * HS;
-  T* Ps = Vs + 64 * HS;
-  int* tokq = reinterpret_cast<int*>(Ps + BQ * KS);
+  int* tokq = reinterpret_cast<int*>(Vs + 64 * HS);
   int* infq = tokq + BQ;             // packed (region << 24) | (py * (2 ws - 1) + px)
   int* tokk = infq + BQ;             // [3][64]: key chunks kc, kc + 1 (loads in flight), kc + 2 (being computed)
   int* infk = tokk + 3 * 64;         // [3][64]
@@ -135,10 +135,14 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
   f32x4 o[NT_O];
 #pragma unroll
   for (int j = 0; j < NT_O; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float mrow[4], lrow[4];
-  int qinf[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { mrow[e] = -1e30f; lrow[e] = 0.f; qinf[e] = infq[wave * 16 + fq * 4 + e]; }
+  // S^T formulation: the MFMA operands are swapped (A = K chunk, B = Q slab), so lane (fq, fr) holds, for ONE query
+  // (row wave * 16 + fr), the scores of the 16 keys 16 j + 4 fq + e.  The softmax statistics of a query are then
+  // per-lane scalars (two cross-row shuffles per reduction instead of a 16-lane butterfly per score row), and P^T is
+  // already laid out as the B operand of O^T += V^T P^T: P never goes through LDS.
+  float mrow = -1e30f, lrow = 0.f;
+  const int qinf = infq[wave * 16 + fr];
+  // bias index (qy - ky + ws - 1) * tw + (qx - kx + ws - 1) = lin_q - lin_k + (ws - 1) * (tw + 1)
+  const int aq = (qinf & 0xffffff) + (ws - 1) * (tw + 1), qr = qinf >> 24;
 
   // Key chunks are software-pipelined: while chunk kc is being multiplied, the K / V rows of chunk kc + 1 are in
   // flight in registers and the token list of chunk kc + 2 is being written (three-slot ring in LDS).
@@ -161,112 +165,105 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
       tokk[((kc + 2) % 3) * 64 + tid] = tok; infk[((kc + 2) % 3) * 64 + tid] = inf;
     }
 
-    // ---- S = Q K^T for this wave's 16 query rows x 64 keys ----
+    // ---- S^T = K (Q * scale)^T: s[j][e] = score(key 16 j + 4 fq + e, query wave * 16 + fr) ----
     f32x4 s[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (PREC == SRAD_PREC_BF16) {
 #pragma unroll
       for (int kk = 0; kk < HDP; kk += 32) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Qs + (wave * 16 + fr) * HS + kk + 8 * fq);
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + (wave * 16 + fr) * HS + kk + 8 * fq);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const bf16x8 bb = *reinterpret_cast<const bf16x8*>(Ks + (j * 16 + fr) * HS + kk + 8 * fq);
-          s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, s[j], 0, 0, 0);
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (j * 16 + fr) * HS + kk + 8 * fq);
+          s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, s[j], 0, 0, 0);
         }
       }
     } else {
 #pragma unroll
       for (int kk = 0; kk < HDP; kk += 16) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(Qs + (wave * 16 + fr) * HS + kk + 4 * fq);
+        const f32x4 qf = *reinterpret_cast<const f32x4*>(Qs + (wave * 16 + fr) * HS + kk + 4 * fq);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(Ks + (j * 16 + fr) * HS + kk + 4 * fq);
+          const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (j * 16 + fr) * HS + kk + 4 * fq);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bb[e], s[j], 0, 0, 0);
+          for (int e = 0; e < 4; ++e) s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[e], s[j], 0, 0, 0);
         }
       }
     }
 
-    // ---- bias + mask + online softmax (row = fq*4+e, key = j*16+fr) ----
-    int kinf[4];
-    bool kval[4];
+    // ---- bias + mask + online softmax of this lane's query over its 16 keys, then across the four lane groups ----
+    float mx = -1e30f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { kinf[j] = infk_c[j * 16 + fr]; kval[j] = (k0 + j * 16 + fr) < N; }
-    float pmax[4];
+    for (int j = 0; j < 4; ++j) {
+      const int4 ki = *reinterpret_cast<const int4*>(infk_c + j * 16 + 4 * fq);
+      const int kinf[4] = {ki.x, ki.y, ki.z, ki.w};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      // bias index (qy - ky + ws - 1) * tw + (qx - kx + ws - 1) = lin_q - lin_k + (ws - 1) * (tw + 1)
-      const int aq = (qinf[e] & 0xffffff) + (ws - 1) * (tw + 1), qr = qinf[e] >> 24;
-      float mx = -1e30f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int kr = kinf[j] >> 24;
-        const int bi = aq - (kinf[j] & 0xffffff);
+      for (int e = 0; e < 4; ++e) {
+        const int bi = aq - (kinf[e] & 0xffffff);
         float bias;
         if constexpr (TBL_LDS) bias = tbl[bi]; else bias = p.table[(size_t)bi * heads + h];
         float v = s[j][e] + bias;
-        if (p.shift > 0 && qr != kr) v += -100.0f;
-        if (!kval[j]) v = -1e30f;
+        if (p.shift > 0 && qr != (kinf[e] >> 24)) v += -100.0f;
+        if constexpr (!FULL) { if (k0 + j * 16 + 4 * fq + e >= N) v = -1e30f; }
         s[j][e] = v;
         mx = fmaxf(mx, v);
       }
-      pmax[e] = mx;
     }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mnew = fmaxf(mrow, mx);
+    const float alpha = fexp(mrow - mnew);
+    float rs = 0.f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      pmax[e] = srad_row16_max(pmax[e]);          // DPP lane swizzles, no LDS round trips
-      const float mnew = fmaxf(mrow[e], pmax[e]);
-      const float alpha = fexp(mrow[e] - mnew);
-      float rs = 0.f;
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float pv = kval[j] ? fexp(s[j][e] - mnew) : 0.f;
+      for (int e = 0; e < 4; ++e) {
+        const float pv = (FULL || k0 + j * 16 + 4 * fq + e < N) ? fexp(s[j][e] - mnew) : 0.f;
         s[j][e] = pv;
         rs += pv;
       }
-      rs = srad_row16_sum(rs);
-      lrow[e] = lrow[e] * alpha + rs;
-      mrow[e] = mnew;
+    rs += __shfl_xor(rs, 16);
+    rs += __shfl_xor(rs, 32);
+    lrow = lrow * alpha + rs;
+    mrow = mnew;
 #pragma unroll
-      for (int j = 0; j < NT_O; ++j) o[j][e] *= alpha;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) Ps[(wave * 16 + fq * 4 + e) * KS + j * 16 + fr] = (T)s[j][e];
-    }
-    // a wave reads back only the 16 rows of P it has just written: LDS operations of one wave complete in
-    // order, so no workgroup barrier is needed here
+    for (int j = 0; j < NT_O; ++j) o[j] *= alpha;
 
-    // ---- O += P V ----
+    // ---- O^T += V^T P^T: o[ct][e] = out(channel 16 ct + 4 fq + e, query wave * 16 + fr) ----
     if constexpr (PREC == SRAD_PREC_BF16) {
-      // B operand (V[key][col], key = 8*fq + 0..7 contiguous per lane) comes from the row-major V tile
-      // through two transposing reads: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3
-      // of a 4x16 block and receives column (lane&15) of its 4 rows.
+      // k slot (fq, t) of a 32-key step stands for key 32 ks + 4 fq + t (t < 4) or 32 ks + 16 + 4 fq + t - 4: exactly the
+      // keys whose probabilities this lane holds in s[2 ks] and s[2 ks + 1].  V^T comes from the row-major V tile through
+      // two transposing reads: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4x16 block and
+      // receives column (lane & 15) of its 4 rows.
       const int tq = fr >> 2, tp = fr & 3;
 #pragma unroll
-      for (int kk = 0; kk < 64; kk += 32) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ps + (wave * 16 + fr) * KS + kk + 8 * fq);
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 pb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pb[e] = (__bf16)s[2 * ks][e]; pb[4 + e] = (__bf16)s[2 * ks + 1][e]; }
 #pragma unroll
         for (int j = 0; j < NT_O; ++j) {
           typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-          const T* r0 = Vs + (kk + 8 * fq + tq) * HS + j * 16 + 4 * tp;
+          const T* r0 = Vs + (32 * ks + 4 * fq + tq) * HS + j * 16 + 4 * tp;
           const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0));
-          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0 + 4 * HS));
-          bf16x8 bb;
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0 + 16 * HS));
+          bf16x8 vf;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { bb[e] = lo[e]; bb[4 + e] = hi[e]; }
-          o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, o[j], 0, 0, 0);
+          for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+          o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb, o[j], 0, 0, 0);
         }
       }
     } else {
+      // fp32: the MFMA step (jt, e) sums the four keys 16 jt + 4 fq + e, fq = 0..3
 #pragma unroll
-      for (int kk = 0; kk < 64; kk += 16) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(Ps + (wave * 16 + fr) * KS + kk + 4 * fq);
+      for (int jt = 0; jt < 4; ++jt) {
 #pragma unroll
         for (int j = 0; j < NT_O; ++j) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float bv = Vs[(kk + 4 * fq + e) * HS + j * 16 + fr];
-            o[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bv, o[j], 0, 0, 0);
+            const float vt = Vs[(jt * 16 + 4 * fq + e) * HS + j * 16 + fr];
+            o[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vt, s[jt][e], o[j], 0, 0, 0);
           }
         }
       }
@@ -274,16 +271,18 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
   }
 
   // ---- normalise and scatter back to raster order ([T][d], plain head-major columns) ----
+  {
+    const int row = wave * 16 + fr;
+    if (q0 + row < N) {
+      const float inv = 1.0f / lrow;
+      float* dst = p.out + (size_t)tokq[row] * d + h * hd;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int row = wave * 16 + fq * 4 + e;
-    if (q0 + row >= N) continue;
-    const float inv = 1.0f / lrow[e];
-    float* dst = p.out + (size_t)tokq[row] * d + h * hd;
+      for (int j = 0; j < NT_O; ++j)
 #pragma unroll
-    for (int j = 0; j < NT_O; ++j) {
-      const int c = j * 16 + fr;
-      if (c < hd) dst[c] = o[j][e] * inv;
+        for (int e = 0; e < 4; ++e) {
+          const int c = j * 16 + 4 * fq + e;
+          if (c < hd) dst[c] = o[j][e] * inv;
+        }
     }
   }
 }
@@ -292,18 +291,20 @@ template <int PREC, int NT_O, int NW>
 int launch_attn(const AttnParams& p, hipStream_t stream) {
   using T = typename AT<PREC>::type;
   constexpr int PAD = AT<PREC>::PAD;
-  constexpr int HDP = NT_O * 16, HS = HDP + PAD, KS = 64 + PAD, BQ = NW * 16;
+  constexpr int HDP = NT_O * 16, HS = HDP + PAD, BQ = NW * 16;
   const int N = p.ws * p.ws;
   const int tw = 2 * p.ws - 1;
-  size_t base = (size_t)((BQ + 128) * HS + BQ * KS) * sizeof(T) + (2 * BQ + 6 * 64) * sizeof(int);
+  size_t base = (size_t)((BQ + 128) * HS) * sizeof(T) + (2 * BQ + 6 * 64) * sizeof(int);
   base = srad_align_up(base, 16);
   const int tbl_in_lds = (base + (size_t)tw * tw * 4) <= 150 * 1024 ? 1 : 0;
   const size_t lds = base + (tbl_in_lds ? (size_t)tw * tw * 4 : 0);
-  auto kern = tbl_in_lds ? window_attn_kernel<PREC, NT_O, true, NW> : window_attn_kernel<PREC, NT_O, false, NW>;
-  static size_t configured[2] = {0, 0};
-  if (lds > configured[tbl_in_lds]) {
+  const int full = N % 64 == 0 ? 1 : 0;
+  auto kern = tbl_in_lds ? (full ? window_attn_kernel<PREC, NT_O, true, NW, true> : window_attn_kernel<PREC, NT_O, true, NW, false>)
+                         : (full ? window_attn_kernel<PREC, NT_O, false, NW, true> : window_attn_kernel<PREC, NT_O, false, NW, false>);
+  static size_t configured[4] = {0, 0, 0, 0};
+  if (lds > configured[tbl_in_lds * 2 + full]) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured[tbl_in_lds] = lds;
+    configured[tbl_in_lds * 2 + full] = lds;
   }
   const int nW = (p.H / p.ws) * (p.W / p.ws);
   dim3 grid((N + BQ - 1) / BQ, p.heads, p.B * nW);
@@ -317,10 +318,10 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
 template <int PREC, int NT_O>
 int launch_attn_nw(const AttnParams& p, hipStream_t stream) {
   using T = typename AT<PREC>::type;
-  constexpr int HS = NT_O * 16 + AT<PREC>::PAD, KS = 64 + AT<PREC>::PAD;
+  constexpr int HS = NT_O * 16 + AT<PREC>::PAD;
   // 128-query workgroups when the window has that many tokens and their tiles + the bias table fit in LDS
   const int tw = 2 * p.ws - 1;
-  const size_t lds8 = (size_t)((128 + 128) * HS + 128 * KS) * sizeof(T) + (2 * 128 + 6 * 64) * sizeof(int) + 16 + (size_t)tw * tw * 4;
+  const size_t lds8 = (size_t)((128 + 128) * HS) * sizeof(T) + (2 * 128 + 6 * 64) * sizeof(int) + 16 + (size_t)tw * tw * 4;
   if (p.ws * p.ws >= 128 && lds8 <= 150 * 1024) return launch_attn<PREC, NT_O, 8>(p, stream);
   return launch_attn<PREC, NT_O, 4>(p, stream);
 }
