@@ -46,7 +46,15 @@ def _reference_init(name: str, kind: str, shape, cfg) -> torch.Tensor:
     trunc-N(0,.02), Linear bias 0, LayerNorm (1,0), bias table trunc-N(.02); convolutions keep
     PyTorch's default (kaiming-uniform(a=sqrt 5) weight, U(+-1/sqrt(fan_in)) bias)."""
     if kind in ("index", "mask", "meanshift_w", "meanshift_b_sub", "meanshift_b_add"):
-        return torch.from_numpy(S.synth_tensor(name, shape, kind, cfg=cfg))
+        a = S.synth_tensor(name, shape, kind, cfg=cfg)
+        if a.flags.writeable or a.nbytes < (1 << 24):
+            return torch.from_numpy(np.array(a))
+        # the large index / mask buffers of wide windows (134 MB / 1 GB each at window 64, identical in every block):
+        # all blocks alias one read-only host array until the module is moved to its GPU
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return torch.from_numpy(a)
     t = torch.empty(shape, dtype=torch.float32)
     if kind == "lin_w":
         _trunc_normal_(t, 0.02)

@@ -14,6 +14,7 @@ oracle and the fixture generator.
 """
 from __future__ import annotations
 
+import functools
 import math
 from collections import OrderedDict
 from dataclasses import dataclass, field
@@ -96,7 +97,20 @@ class DRNConfig:
 # --------------------------------------------------------------------------------------
 # integer / mask buffers (reference drct.py:250-260, 449-470)
 # --------------------------------------------------------------------------------------
+@functools.lru_cache(maxsize=8)
+def _relative_position_index_cached(ws: int) -> np.ndarray:
+    a = _relative_position_index(ws)
+    a.setflags(write=False)
+    return a
+
+
 def relative_position_index(ws: int) -> np.ndarray:
+    """[N, N] int64 index into the (2 ws - 1)^2 bias table (reference drct.py:250-260).  Cached and read-only: at
+    window 64 it is 134 MB and every one of the 60 blocks registers the same buffer."""
+    return _relative_position_index_cached(int(ws))
+
+
+def _relative_position_index(ws: int) -> np.ndarray:
     coords = np.stack(np.meshgrid(np.arange(ws), np.arange(ws), indexing="ij"))  # 2,ws,ws
     flat = coords.reshape(2, -1)
     rel = flat[:, :, None] - flat[:, None, :]
@@ -107,8 +121,20 @@ def relative_position_index(ws: int) -> np.ndarray:
     return rel.sum(-1).astype(np.int64)
 
 
+@functools.lru_cache(maxsize=4)
+def _shifted_window_mask_cached(H: int, W: int, ws: int, shift: int) -> np.ndarray:
+    a = _shifted_window_mask(H, W, ws, shift)
+    a.setflags(write=False)
+    return a
+
+
 def shifted_window_mask(H: int, W: int, ws: int, shift: int) -> np.ndarray:
-    """[nW, N, N] float32 mask with values 0 / -100 (reference drct.py:449-470)."""
+    """[nW, N, N] float32 mask with values 0 / -100 (reference drct.py:449-470).  Cached and read-only (1 GB at
+    window 64 on a 256 x 256 image)."""
+    return _shifted_window_mask_cached(int(H), int(W), int(ws), int(shift))
+
+
+def _shifted_window_mask(H: int, W: int, ws: int, shift: int) -> np.ndarray:
     img = np.zeros((H, W), dtype=np.float32)
     cnt = 0
     for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
@@ -276,10 +302,10 @@ def synth_tensor(name: str, shape, kind: str, seed: int = 0, gain: float = 1.0,
     through the whole network and every term (biases, LN affine, bias table, mask) matters
     numerically - unlike the reference's init (Linear std .02, zero biases) under which a
     wrong attention bias would hide below the tolerance."""
-    if kind == "index":
-        return relative_position_index(cfg.window_size)
-    if kind == "mask":
-        return shifted_window_mask(cfg.img_size, cfg.img_size, cfg.window_size, cfg.shift)
+    if kind in ("index", "mask"):
+        a = (relative_position_index(cfg.window_size) if kind == "index"
+             else shifted_window_mask(cfg.img_size, cfg.img_size, cfg.window_size, cfg.shift))
+        return a.copy() if a.nbytes < (1 << 24) else a      # big ones (window >= 32) stay shared and read-only
     if kind == "meanshift_w":
         return np.eye(shape[0], dtype=np.float32).reshape(shape)
     if kind in ("meanshift_b_sub", "meanshift_b_add"):
