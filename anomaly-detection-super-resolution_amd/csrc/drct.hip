@@ -24,7 +24,7 @@ GemmParams base_gemm(const srad_drct* h, const ConvW& c, const float* X, int ldx
   p.Wp = h->pt.ptr(c.w); p.N = c.n; p.bias = h->pt.fptr(c.b);
   p.act = SRAD_ACT_NONE; p.slope = 0.f; p.alpha = 1.f;
   p.R = nullptr; p.ldr = 0;
-  p.Y = Y; p.ldy = ldy; p.yoff = 0; p.ps = 0; p.pool = nullptr;
+  p.Y = Y; p.ldy = ldy; p.yoff = 0; p.ps = 0;
   return p;
 }
 

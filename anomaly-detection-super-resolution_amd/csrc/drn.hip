@@ -192,7 +192,7 @@ GemmParams conv_params(const srad_drn* h, const ConvW& c, const float* X, int ld
   p.Wp = h->pt.ptr(c.w); p.N = c.n; p.bias = h->pt.fptr(c.b);
   p.act = SRAD_ACT_NONE; p.slope = 0.f; p.alpha = 1.f;
   p.R = nullptr; p.ldr = 0;
-  p.Y = Y; p.ldy = ldy; p.yoff = yoff; p.ps = 0; p.pool = nullptr;
+  p.Y = Y; p.ldy = ldy; p.yoff = yoff; p.ps = 0;
   p.hsplit_hd = 0; p.hsplit_hdp = 0;
   return p;
 }

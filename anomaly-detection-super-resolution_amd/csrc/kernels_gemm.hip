@@ -43,7 +43,7 @@ __device__ __forceinline__ float dgelu_erf(float x) {
 //   * the kernel is VALU-issue bound (one wave per SIMD, ~4 cycles per instruction), so addresses are
 //     uniform 64-bit bases (SALU) plus per-thread 32-bit byte offsets computed once.
 //   * activations always have a channel count / row stride that is a multiple of 4 floats.
-// SPECIAL = pixel-shuffle scatter / head-padded columns / pooled sums in the epilogue.
+// SPECIAL = pixel-shuffle scatter / head-padded columns in the epilogue.
 template <int PREC, int BM, int BN, int WAVES_M, int WAVES_N, int CPS, bool LN, bool CONV, bool SPECIAL>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -388,16 +388,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       const bool m_ok = m < p.M;
       const int mc = m_ok ? m : 0;
       unsigned yrow = (unsigned)(mc * p.ldy + p.yoff);
-      [[maybe_unused]] int pb = 0;
       if constexpr (SPECIAL) {
-        if (p.ps == 2 || p.pool) {
+        if (p.ps == 2) {
           const int hw_o = p.Ho * p.Wo;
-          pb = mc / hw_o;
-          if (p.ps == 2) {
-            const int rem = mc - pb * hw_o;
-            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            yrow = (unsigned)(((pb * (2 * p.Ho) + 2 * oy) * (2 * p.Wo) + 2 * ox) * p.ldy + p.yoff);
-          }
+          const int pb = mc / hw_o;
+          const int rem = mc - pb * hw_o;
+          const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+          yrow = (unsigned)(((pb * (2 * p.Ho) + 2 * oy) * (2 * p.Wo) + 2 * ox) * p.ldy + p.yoff);
         }
       }
       float rs = p.alpha;
@@ -413,9 +410,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         }
         if (m_ok && ncol[j] < p.N) {
           p.Y[yrow + ycol[j]] = v;
-          if constexpr (SPECIAL) {
-            if (p.pool) atomicAdd(p.pool + (size_t)pb * p.N + ncol[j], v);
-          }
         }
       }
     }
@@ -489,7 +483,7 @@ int launch_one(const GemmParams& p, hipStream_t s) {
 template <int PREC, int BM, int BN, int WMV, int WNV>
 int launch_cfg(const GemmParams& p, hipStream_t s) {
   const bool conv = p.ntaps == 9 || p.stride != 1;
-  const bool special = p.ps == 2 || p.hsplit_hd > 0 || p.pool != nullptr;
+  const bool special = p.ps == 2 || p.hsplit_hd > 0;
   if (conv) {
     return special ? launch_one<PREC, BM, BN, WMV, WNV, false, true, true>(p, s)
                    : launch_one<PREC, BM, BN, WMV, WNV, false, true, false>(p, s);
@@ -542,7 +536,7 @@ int srad_launch_gemm(int prec, const GemmParams& p, hipStream_t stream) {
                "gemm: tensors above 4 GB are not addressable with the 32-bit offsets this kernel uses");
   SRAD_REQUIRE((p.Cin & 3) == 0 && (p.ldx & 3) == 0 && ((uintptr_t)p.X & 15) == 0,
                "gemm: activations need a channel count and row stride that are multiples of 4 floats (Cin=%d ldx=%d)", p.Cin, p.ldx);
-  if (p.ntaps == 9 || p.stride != 1 || p.ps || p.pool)
+  if (p.ntaps == 9 || p.stride != 1 || p.ps)
     SRAD_REQUIRE(p.Ho > 0 && p.Wo > 0 && p.M % (p.Ho * p.Wo) == 0, "gemm: M=%d not a multiple of Ho*Wo=%d*%d", p.M, p.Ho, p.Wo);
   int rc = prec == SRAD_PREC_BF16 ? launch_prec<SRAD_PREC_BF16>(p, stream) : launch_prec<SRAD_PREC_F32>(p, stream);
   if (rc) return rc;

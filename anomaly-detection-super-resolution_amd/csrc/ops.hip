@@ -34,7 +34,7 @@ int srad_op_gemm(int precision, const float* x, int ldx, int B, int Hi, int Wi, 
   p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = 1e-5f;
   p.Wp = scratch; p.N = N; p.bias = bias;
   p.act = act; p.slope = slope; p.alpha = alpha;
-  p.R = r; p.ldr = ldr; p.Y = y; p.ldy = ldy; p.yoff = yoff; p.ps = ps; p.pool = nullptr;
+  p.R = r; p.ldr = ldr; p.Y = y; p.ldy = ldy; p.yoff = yoff; p.ps = ps;
   p.hsplit_hd = 0; p.hsplit_hdp = 0;
   return srad_launch_gemm(precision, p, s);
 }
@@ -60,7 +60,7 @@ int srad_bench_gemm(int precision, const float* x, int ldx, int B, int Hi, int W
   p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = 1e-5f;
   p.Wp = scratch; p.N = N; p.bias = bias;
   p.act = act; p.slope = 0.2f; p.alpha = 1.f;
-  p.R = r; p.ldr = ldr; p.Y = y; p.ldy = ldy; p.yoff = 0; p.ps = 0; p.pool = nullptr;
+  p.R = r; p.ldr = ldr; p.Y = y; p.ldy = ldy; p.yoff = 0; p.ps = 0;
   p.hsplit_hd = hsplit_hd; p.hsplit_hdp = hsplit_hdp;
   for (int i = 0; i < 5; ++i) SRAD_TRY(srad_launch_gemm(precision, p, s));
   hipEvent_t a, b;

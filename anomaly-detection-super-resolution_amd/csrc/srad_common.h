@@ -116,7 +116,6 @@ struct GemmParams {
   int ps;          // 0: plain store, 2: PixelShuffle(2) scatter (N = 4 * ldy-channels)
   int hsplit_hd;   // > 0: column n is stored at (n / hsplit_hd) * hsplit_hdp + n % hsplit_hd, i.e. every
   int hsplit_hdp;  //      head's slice is padded to hsplit_hdp floats (the attention kernel's input layout)
-  float* pool;     // optional [B][N] per-image column sums of the stored values (atomicAdd)
   // ---- training extensions (all off when zero) ----
   int rmode;                 // how R enters: 0 v = act(acc)*alpha*rs + R (residual); 1 v = acc*alpha*rs * gelu'(R);
                              //               2 v = acc*alpha*rs * (R > 0 ? 1 : slope)   (backward through an activation)

@@ -78,8 +78,7 @@ def test_model_checkpoint_surface(tmp_path):
         opt2 = Opt.build_opt('drn-l', 'carpet', 64, 2, pre_train=str(tmp_path / 'model' / 'model_best.pt'),
                              pre_train_dual=str(tmp_path / 'model' / 'dual_model_best.pt'))
         m2 = Model(opt2, None, dual_model=True).eval()
-        # not bitwise: the RCAB global-average-pool sums are float atomics (arrival order varies)
-        assert torch.allclose(m2(x)[-1], a, rtol=1e-5, atol=1e-3)
+        assert torch.equal(m2(x)[-1], a)          # bit-reproducible: no atomics anywhere in the forward
     opt.model_name = 'nope'
     assert make_model(opt) is None
 
