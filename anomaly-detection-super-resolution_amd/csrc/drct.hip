@@ -123,7 +123,8 @@ int forward_body(srad_drct* h, const float* x, int B, int H, int W, float* y, co
         MlpBlockParams q{};
         q.attn = w.attn; q.ld_attn = d; q.shortcut = cur; q.ld_short = D;
         q.M = T; q.d = d; q.m = sw.hidden; q.no = no;
-        q.w_proj = h->pt.ptr(sw.proj.w); q.w_fc1 = h->pt.ptr(sw.fc1.w); q.w_fc2 = h->pt.ptr(sw.fc2.w); q.w_adj = h->pt.ptr(sw.adjust.w);
+        q.w_proj = h->pt.frag_ptr(sw.proj.w); q.w_fc1 = h->pt.frag_ptr(sw.fc1.w); q.w_fc2 = h->pt.frag_ptr(sw.fc2.w);
+        q.w_adj = h->pt.frag_ptr(sw.adjust.w);
         q.b_proj = h->pt.fptr(sw.proj.b); q.b_fc1 = h->pt.fptr(sw.fc1.b); q.b_fc2 = h->pt.fptr(sw.fc2.b); q.b_adj = h->pt.fptr(sw.adjust.b);
         q.ln_g = h->pt.fptr(sw.n2g); q.ln_b = h->pt.fptr(sw.n2b); q.dbg = 0;
         if (k < 4) { q.act = SRAD_ACT_LRELU; q.slope = 0.2f; q.alpha = 1.f; q.R = nullptr; q.ldr = 0; q.Y = cur; q.ldy = D; q.yoff = d; }
@@ -241,12 +242,15 @@ int srad_drct_create(const srad_drct_config* cfg, srad_drct_t** out) {
       sw.n1b = h->pt.add_raw(p + "norm1.bias", sw.d);
       sw.table = h->pt.add_raw(p + "attn.relative_position_bias_table", (int64_t)(2 * ws - 1) * (2 * ws - 1) * sw.heads);
       sw.qkv = h->pt.add_layer(p + "attn.qkv", 3 * sw.d, sw.d, 1, true);
-      sw.proj = h->pt.add_layer(p + "attn.proj", sw.d, sw.d, 1, true);
+      const bool frag = cfg->precision == SRAD_PREC_BF16;      // operands of the fused second half (kernels_fused.hip)
+      sw.proj = frag ? h->pt.add_layer_frag(p + "attn.proj", sw.d, sw.d, true) : h->pt.add_layer(p + "attn.proj", sw.d, sw.d, 1, true);
       sw.n2g = h->pt.add_raw(p + "norm2.weight", sw.d);
       sw.n2b = h->pt.add_raw(p + "norm2.bias", sw.d);
-      sw.fc1 = h->pt.add_layer(p + "mlp.fc1", sw.hidden, sw.d, 1, true);
-      sw.fc2 = h->pt.add_layer(p + "mlp.fc2", sw.d, sw.hidden, 1, true);
-      sw.adjust = h->pt.add_layer("layers." + std::to_string(i) + ".adjust" + std::to_string(k + 1), k < 4 ? cfg->gc : E, sw.d, 1, true);
+      const std::string an = "layers." + std::to_string(i) + ".adjust" + std::to_string(k + 1);
+      const int ao = k < 4 ? cfg->gc : E;
+      sw.fc1 = frag ? h->pt.add_layer_frag(p + "mlp.fc1", sw.hidden, sw.d, true) : h->pt.add_layer(p + "mlp.fc1", sw.hidden, sw.d, 1, true);
+      sw.fc2 = frag ? h->pt.add_layer_frag(p + "mlp.fc2", sw.d, sw.hidden, true) : h->pt.add_layer(p + "mlp.fc2", sw.d, sw.hidden, 1, true);
+      sw.adjust = frag ? h->pt.add_layer_frag(an, ao, sw.d, true) : h->pt.add_layer(an, ao, sw.d, 1, true);
       if (sw.d > h->dmax) h->dmax = sw.d;
       if (3 * sw.heads * hdp_of(sw.d, sw.heads) > h->qkvmax) h->qkvmax = 3 * sw.heads * hdp_of(sw.d, sw.heads);
       if (sw.hidden > h->hmax) h->hmax = sw.hidden;

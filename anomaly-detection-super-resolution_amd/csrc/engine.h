@@ -13,6 +13,7 @@ struct ParamEntry {
   int packed;        // 1: GEMM weight packed by srad_launch_pack_weight, 0: raw fp32 copy
   int n, cin, ntaps; // packed geometry (real sizes of the source tensor)
   int n_pad = 0, grp_real = 0, grp_pad = 0;   // optional padding (srad_launch_pack_weight_padded)
+  long long frag_off = -1;                    // >= 0: second copy as bf16 MFMA fragments (srad_launch_pack_weight_frag)
 };
 
 struct ConvW {       // one Linear / conv layer
@@ -72,7 +73,15 @@ struct ParamTable {
       if (entries[i].name == name) return (int)i;
     return -1;
   }
+  // Linear layer that is also kept as a fragment-major bf16 pack (the fused block kernels' operand)
+  ConvW add_layer_frag(const std::string& prefix, int n, int cin, bool bias) {
+    ConvW c = add_layer(prefix, n, cin, 1, bias);
+    entries[c.w].frag_off = (long long)bytes;
+    bytes += srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, n, cin, 1), 256);
+    return c;
+  }
   const void* ptr(int idx) const { return idx < 0 ? nullptr : arena + entries[idx].off; }
+  const void* frag_ptr(int idx) const { return idx < 0 || entries[idx].frag_off < 0 ? nullptr : arena + entries[idx].frag_off; }
   const float* fptr(int idx) const { return reinterpret_cast<const float*>(ptr(idx)); }
 
   int set(const char* name, const float* src, int64_t numel, hipStream_t s) {
@@ -83,8 +92,10 @@ struct ParamTable {
     if (numel != e.numel)
       return srad_set_error(SRAD_ERR_ARG, "set_param(%s): got %lld elements, expected %lld", name, (long long)numel,
                             (long long)e.numel);
-    if (e.packed)
+    if (e.packed) {
+      if (e.frag_off >= 0) SRAD_TRY(srad_launch_pack_weight_frag(src, arena + e.frag_off, e.n, e.cin, s));
       return srad_launch_pack_weight_padded(prec, src, arena + e.off, e.n, e.cin, e.ntaps, e.n_pad > 0 ? e.n_pad : e.n, e.grp_real, e.grp_pad, s);
+    }
     if (e.n_pad > numel) SRAD_CHECK_HIP(hipMemsetAsync(arena + e.off, 0, (size_t)e.n_pad * 4, s));
     SRAD_CHECK_HIP(hipMemcpyAsync(arena + e.off, src, (size_t)numel * 4, hipMemcpyDeviceToDevice, s));
     return SRAD_OK;

@@ -38,7 +38,6 @@ constexpr int FM = 16;             // rows per workgroup
 constexpr int NRT = FM / 16;       // 16-row MFMA tiles per workgroup
 constexpr int F_LDA = 392;         // LDS row stride of the <=384-wide bf16 activation tile
 constexpr int F_LDH = 520;         // LDS row stride of the <=512-wide hidden tile
-constexpr int F_LDW = 264;         // LDS row stride of a weight stage (256 k + pad)
 constexpr int F_SC = 128;          // output columns per weight stage
 constexpr int F_NV = 2560;         // floats of bias / gamma / beta staged in LDS (10 per thread)
 
@@ -59,8 +58,7 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* A1 = reinterpret_cast<__bf16*>(smem);                  // [FM][F_LDA] attn tile -> LN2(x1) -> x2
   __bf16* Hs = A1 + FM * F_LDA;                                  // [FM][F_LDH] GELU(fc1)
-  __bf16* Ws = Hs + FM * F_LDH;                                  // [F_SC][F_LDW] weight stage
-  float* vec = reinterpret_cast<float*>(Ws + F_SC * F_LDW);      // b_proj | b_fc1 | b_fc2 | b_adj | gamma | beta
+  float* vec = reinterpret_cast<float*>(Hs + FM * F_LDH);        // b_proj | b_fc1 | b_fc2 | b_adj | gamma | beta
   float* red = vec + F_NV;                                       // [FM][8 waves][2] LayerNorm partial sums
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -83,34 +81,33 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     else { s -= n_fc2; w = (const char*)p.w_adj; Kp = Kd; kgs = KGD; }
     const int g = s / kgs, kg = s - g * kgs;
     nch = min(8, (Kp >> 5) - kg * 8);
-    return w + ((size_t)(g * F_SC) * Kp + kg * 256) * 2;
+    // fragment-major pack: 1 KB tiles (16 rows x 32 k), tile (n / 16, k / 32); this wave's row tile is g * 8 + wave
+    return w + ((size_t)(g * 8 + wave) * (Kp >> 5) + kg * 8) * 1024;
   };
 
   // 8 waves (two per SIMD): a lone wave issues one VALU instruction per 4 cycles, two interleave at 2, and
   // the epilogue / staging arithmetic of this kernel is VALU-issue bound.
+  // Each wave owns 16 output columns of a 128-column stage, i.e. 16 rows of the packed weight, and NOBODY else
+  // reads them (one 16-row token tile per workgroup): the weights go straight from global memory into MFMA
+  // fragment registers, three stages ahead.  The weights are packed fragment-major for this (1 KB tiles of 16 rows x
+// 32 k, srad_launch_pack_weight_frag), so every wave load is one contiguous kilobyte; with the row-major pack the same
+// loads are 16 separate 64-byte pieces and the kernel got slower than with the LDS stage (28.7 vs 25.4 us).
+  // No LDS stage for weights, no barrier per stage; barriers remain only where the activation tile changes.
   constexpr int NSETS = 3;
   u32x4 w_reg[NSETS][8];
-  const int w_seg = tid & 31, w_row = tid >> 5;                  // rows w_row + 16*j (j < 8), 16-byte segment w_seg
   auto load_w = [&](int s, u32x4 (&reg)[8]) {
     int Kp, nch;
-    const char* base = stage_ptr(s, Kp, nch);
-    base += (size_t)w_row * Kp * 2 + (w_seg < nch * 4 ? w_seg : 0) * 16;
+    const char* base = stage_ptr(s, Kp, nch) + fr * 64 + fq * 16;  // row fr, k 8 fq .. of the tile: the 64 lanes cover its 1 KB
 #pragma unroll
-    for (int j = 0; j < 8; ++j) reg[j] = *reinterpret_cast<const u32x4*>(base + (size_t)j * 16 * Kp * 2);
+    for (int cc = 0; cc < 8; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + (cc < nch ? cc : 0) * 1024);
   };
-  auto store_w = [&](const u32x4 (&reg)[8]) {
-    char* dst = reinterpret_cast<char*>(Ws) + (w_row * F_LDW) * 2 + w_seg * 16;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(dst + j * 16 * F_LDW * 2) = reg[j];
-  };
-  // c[rt] += (A[32 rows][k0 .. k0 + nch*32) . Ws[16 columns of this wave][..]^T)^T
-  auto mma_stage = [&](const __bf16* A, int lda, int k0, int nch, f32x4 (&c)[NRT]) {
+  // c[rt] += (A[16 rows][k0 .. k0 + nch*32) . W[16 columns of this wave][..]^T)^T
+  auto mma_stage = [&](const __bf16* A, int lda, int k0, int nch, const u32x4 (&reg)[8], f32x4 (&c)[NRT]) {
     const __bf16* ar = A + fr * lda + k0 + 8 * fq;
-    const __bf16* wr = Ws + (wave * 16 + fr) * F_LDW + 8 * fq;
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
       if (cc < nch) {
-        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wr + cc * 32);
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, reg[cc]);
         // operands swapped (W as the MFMA "A", activations as "B"): the result tile is transposed, so a lane
         // holds 4 CONSECUTIVE OUTPUT COLUMNS (4*fq + e) of one token row (fr) - exactly the k-contiguous
         // quad the next GEMM's A operand, the bias/residual vectors and the global store want.
@@ -301,15 +298,14 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     u32x4 (&reg)[8] = w_reg[s % NSETS];
     const int Kp = ph == 2 ? Km : Kd;
     const int nch = min(8, (Kp >> 5) - kg * 8);
-    if (!(p.dbg & 8)) store_w(reg);
-    __syncthreads();                                   // stage (and any A tile / vector written before) visible
-    if (!(p.dbg & 1)) load_w(s + NSETS, reg);          // refill this set, NSETS stages ahead
+    if constexpr (ls == 0) __syncthreads();            // first stage of a phase: the activation tile (A1 / Hs) and,
+                                                       // at s == 0, the staged vectors written before are visible
     if constexpr (kg == 0) {
 #pragma unroll
       for (int rt = 0; rt < NRT; ++rt) c[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (!(p.dbg & 2)) mma_stage(ph == 2 ? Hs : A1, ph == 2 ? F_LDH : F_LDA, kg * 256, nch, c);
-    __syncthreads();                                   // stage buffer free again
+    if (!(p.dbg & 2)) mma_stage(ph == 2 ? Hs : A1, ph == 2 ? F_LDH : F_LDA, kg * 256, nch, reg, c);
+    if (!(p.dbg & 1)) load_w(s + NSETS, reg);          // refill this set, NSETS stages ahead
     if (!(p.dbg & 16)) if constexpr (kg == kgs - 1) {
       if constexpr (ph == 0) epi_proj(std::integral_constant<int, g>{}, c);
       else if constexpr (ph == 1) epi_fc1(g, c);
@@ -326,7 +322,7 @@ inline FusedCfg fused_cfg(int d, int m, int no) {
 }
 template <int GD, int KGD, int GM, int KGM, int GN>
 int launch_mlp(const MlpBlockParams& p, hipStream_t stream) {
-  constexpr size_t lds = (size_t)(FM * F_LDA + FM * F_LDH + F_SC * F_LDW) * 2 + (F_NV + FM * 16) * sizeof(float);
+  constexpr size_t lds = (size_t)(FM * F_LDA + FM * F_LDH) * 2 + (F_NV + FM * 16) * sizeof(float);
   auto kern = mlp_block_kernel<GD, KGD, GM, KGM, GN>;
   static bool configured = false;
   if (!configured) {

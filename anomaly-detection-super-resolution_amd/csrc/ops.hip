@@ -110,10 +110,10 @@ int srad_bench_mlp_block(int M, int d, int m, int no, const float* attn, const f
                b3 = srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, d, m, 1), 256), b4 = srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, no, d, 1), 256);
   SRAD_REQUIRE(scratch_bytes >= b1 + b2 + b3 + b4, "bench_mlp_block: scratch too small");
   char* sc = reinterpret_cast<char*>(scratch);
-  SRAD_TRY(srad_launch_pack_weight(SRAD_PREC_BF16, w_fp32, sc, d, d, 1, s));
-  SRAD_TRY(srad_launch_pack_weight(SRAD_PREC_BF16, w_fp32, sc + b1, m, d, 1, s));
-  SRAD_TRY(srad_launch_pack_weight(SRAD_PREC_BF16, w_fp32, sc + b1 + b2, d, m, 1, s));
-  SRAD_TRY(srad_launch_pack_weight(SRAD_PREC_BF16, w_fp32, sc + b1 + b2 + b3, no, d, 1, s));
+  SRAD_TRY(srad_launch_pack_weight_frag(w_fp32, sc, d, d, s));
+  SRAD_TRY(srad_launch_pack_weight_frag(w_fp32, sc + b1, m, d, s));
+  SRAD_TRY(srad_launch_pack_weight_frag(w_fp32, sc + b1 + b2, d, m, s));
+  SRAD_TRY(srad_launch_pack_weight_frag(w_fp32, sc + b1 + b2 + b3, no, d, s));
   MlpBlockParams q{};
   q.attn = attn; q.ld_attn = 320; q.shortcut = shortcut; q.ld_short = 320; q.M = M; q.d = d; q.m = m; q.no = no;
   q.w_proj = sc; q.w_fc1 = sc + b1; q.w_fc2 = sc + b1 + b2; q.w_adj = sc + b1 + b2 + b3;

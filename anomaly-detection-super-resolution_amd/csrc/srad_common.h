@@ -140,6 +140,8 @@ int srad_launch_pack_weight(int prec, const float* src, void* dst, int n, int ci
 // the packed geometry is that of (n_pad, (cin / grp_real) * grp_pad)
 int srad_launch_pack_weight_padded(int prec, const float* src, void* dst, int n, int cin, int ntaps, int n_pad,
                                    int grp_real, int grp_pad, hipStream_t stream);
+// Linear weights once more as bf16 MFMA fragments (16 x 32 tiles of 1 KB, tile-major): same byte size as the bf16 pack
+int srad_launch_pack_weight_frag(const float* src, void* dst, int n, int cin, hipStream_t stream);
 // Data-gradient operand: the same tensor packed as the weight of the transposed convolution,
 // dst[c][8 - tap][n] (taps mirrored for 3x3, identity for 1x1), geometry (rows cin_pad, columns n_pad).
 int srad_launch_pack_weight_transposed(int prec, const float* src, void* dst, int n, int cin, int ntaps, int n_pad,
@@ -160,7 +162,7 @@ int srad_launch_window_attn(int prec, const AttnParams& p, hipStream_t stream);
 // ------------------------------------------------------------------------------------------
 // Fused second half of a Swin block (kernels_fused.hip): proj + shortcut -> LayerNorm2 -> fc1 -> GELU
 // -> fc2 + residual -> adjust 1x1 conv (+ LeakyReLU | * alpha + R), 32 token rows per workgroup.
-// Weights are the ordinary packed bf16 matrices ([ceil64(N)][ceil32(K)]).
+// Weights are the fragment-major bf16 packs (srad_launch_pack_weight_frag).
 // ------------------------------------------------------------------------------------------
 struct MlpBlockParams {
   const float* attn; int ld_attn;        // [M][d] attention output (pre-proj)

@@ -21,6 +21,7 @@ struct SyncDesc {
   long long src_off;    // floats into the flat parameter buffer
   long long dst_off;    // bytes into the forward arena
   long long tdst_off;   // bytes into the training arena (-1: no transposed pack)
+  long long fdst_off;   // bytes into the forward arena of the fragment-major bf16 pack (-1: none)
   int packed, n, cin, ntaps, Np, Cp, tRp, tKp;
   long long numel;
   unsigned blk0, nblk;
@@ -58,6 +59,18 @@ __global__ __launch_bounds__(256) void sync_params_kernel(const SyncDesc* __rest
     float v = 0.f;
     if (n < d.n && c < d.cin) v = src[((long long)n * d.cin + c) * d.ntaps + tap];
     dst[i] = (T)v;
+  }
+  if (d.fdst_off >= 0) {                      // 16 x 32 tiles, tile-major (srad_launch_pack_weight_frag)
+    __bf16* fdst = reinterpret_cast<__bf16*>(arena + d.fdst_off);
+    const long long ptotal = (long long)d.Np * d.Cp;
+    const int ktiles = d.Cp / 32;
+    for (long long i = base + threadIdx.x; i < base + SYNC_EPB && i < ptotal; i += 256) {
+      const int kin = (int)(i & 31), rin = (int)((i >> 5) & 15);
+      const long long tile = i >> 9;
+      const int kt = (int)(tile % ktiles), nt = (int)(tile / ktiles);
+      const int n = nt * 16 + rin, k = kt * 32 + kin;
+      fdst[i] = (__bf16)((n < d.n && k < d.cin) ? src[(long long)n * d.cin + k] : 0.f);
+    }
   }
   if (d.tdst_off >= 0) {
     const long long ttotal = (long long)d.tRp * d.ntaps * d.tKp;
@@ -118,7 +131,7 @@ inline int train_bind(const ParamTable& pt, TrainState& ts, void* train_arena, s
   for (size_t i = 0; i < pt.entries.size(); ++i) {
     const ParamEntry& e = pt.entries[i];
     SyncDesc d{};
-    d.src_off = ts.flat_off[i]; d.dst_off = (long long)e.off; d.tdst_off = -1;
+    d.src_off = ts.flat_off[i]; d.dst_off = (long long)e.off; d.tdst_off = -1; d.fdst_off = e.frag_off;
     d.packed = e.packed; d.numel = e.numel;
     long long work = e.numel;
     if (e.packed) {
