@@ -500,6 +500,11 @@ int launch_cfg(const GemmParams& p, hipStream_t s) {
   const bool conv = p.ntaps == 9 || p.stride != 1;
   const bool special = p.ps == 2 || p.hsplit_hd > 0;
   if (conv) {
+    if constexpr (PREC == SRAD_PREC_BF16 && BM == 64 && (BN == 64 || BN == 80)) {
+      // 128-wide K stages here too: DRN's 80-channel 3x3 convs 185 -> 225 TFLOP/s
+      return special ? launch_one<PREC, BM, BN, WMV, WNV, false, true, true, 4>(p, s)
+                     : launch_one<PREC, BM, BN, WMV, WNV, false, true, false, 4>(p, s);
+    }
     return special ? launch_one<PREC, BM, BN, WMV, WNV, false, true, true>(p, s)
                    : launch_one<PREC, BM, BN, WMV, WNV, false, true, false>(p, s);
   }
