@@ -5,7 +5,7 @@
 //   out = act(adjust(x2) + b_adj) * alpha (+ R)                  (src/drct.py:389-396: 1x1 conv,
 //                                                                  LeakyReLU 0.2 / "*0.2 + x" for adjust5)
 //
-// Everything after the attention is row-wise, so a workgroup owns 32 token rows for the whole chain:
+// Everything after the attention is row-wise, so a workgroup owns 16 (or 64) token rows for the whole chain:
 // the rows' activations never leave the CU (A operands in LDS as bf16, x1/x2 in accumulator registers
 // in fp32), and the four weight matrices are streamed through one LDS stage buffer, 128 output columns
 // x up to 256 k per stage, with later stages' global loads in flight behind the current MFMAs.
@@ -34,8 +34,6 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-constexpr int FM = 16;             // rows per workgroup
-constexpr int NRT = FM / 16;       // 16-row MFMA tiles per workgroup
 constexpr int F_LDA = 392;         // LDS row stride of the <=384-wide bf16 activation tile
 constexpr int F_LDH = 520;         // LDS row stride of the <=512-wide hidden tile
 constexpr int F_SC = 128;          // output columns per weight stage
@@ -53,8 +51,11 @@ __device__ __forceinline__ float gelu_fast(float x) {
 
 // GD/GM/GN = 128-column groups of the block dim / hidden / adjust output, KGD/KGM = 256-wide k groups
 // of the block dim / hidden.
-template <int GD, int KGD, int GM, int KGM, int GN>
+// FM = token rows per workgroup (16, or 64 for large token counts: every workgroup streams all four weight
+// matrices, so at 65536 tokens 16-row tiles move 4096 x 0.5 MB per launch through L2).
+template <int FM, int GD, int KGD, int GM, int KGM, int GN>
 __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) {
+  constexpr int NRT = FM / 16;       // 16-row MFMA tiles per workgroup
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* A1 = reinterpret_cast<__bf16*>(smem);                  // [FM][F_LDA] attn tile -> LN2(x1) -> x2
   __bf16* Hs = A1 + FM * F_LDA;                                  // [FM][F_LDH] GELU(fc1)
@@ -320,10 +321,10 @@ inline FusedCfg fused_cfg(int d, int m, int no) {
   const int Kd = srad_cp(d), Km = srad_cp(m);
   return FusedCfg{(d + F_SC - 1) / F_SC, (Kd + 255) / 256, (m + F_SC - 1) / F_SC, (Km + 255) / 256, (no + F_SC - 1) / F_SC};
 }
-template <int GD, int KGD, int GM, int KGM, int GN>
-int launch_mlp(const MlpBlockParams& p, hipStream_t stream) {
+template <int FM, int GD, int KGD, int GM, int KGM, int GN>
+int launch_mlp_fm(const MlpBlockParams& p, hipStream_t stream) {
   constexpr size_t lds = (size_t)(FM * F_LDA + FM * F_LDH) * 2 + (F_NV + FM * 16) * sizeof(float);
-  auto kern = mlp_block_kernel<GD, KGD, GM, KGM, GN>;
+  auto kern = mlp_block_kernel<FM, GD, KGD, GM, KGM, GN>;
   static bool configured = false;
   if (!configured) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -336,12 +337,18 @@ int launch_mlp(const MlpBlockParams& p, hipStream_t stream) {
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
 }
+template <int GD, int KGD, int GM, int KGM, int GN>
+int launch_mlp(const MlpBlockParams& p, hipStream_t stream) {
+  // 16-row tiles until there are enough tokens to fill the chip several times with 64-row tiles
+  if (p.M >= 32768 && p.M % 64 == 0) return launch_mlp_fm<64, GD, KGD, GM, KGM, GN>(p, stream);
+  return launch_mlp_fm<16, GD, KGD, GM, KGM, GN>(p, stream);
+}
 // stage geometries of DRCT-L's Swin blocks (embed 180 + k*32; mlp ratio 2,2,2,1,1; adjust to 32 / 180 channels)
 #define SRAD_FUSED_CFGS(X) X(2, 1, 3, 2, 1) X(2, 1, 4, 2, 1) X(3, 2, 3, 2, 1) X(3, 2, 3, 2, 2)
 }  // namespace
 
 bool srad_mlp_block_supported(int prec, int M, int d, int m, int no) {
-  if (!(prec == SRAD_PREC_BF16 && M % FM == 0 && d % 4 == 0 && m % 4 == 0 && no % 4 == 0 && d >= 32 && d <= 384 && m >= 32 &&
+  if (!(prec == SRAD_PREC_BF16 && M % 16 == 0 && d % 4 == 0 && m % 4 == 0 && no % 4 == 0 && d >= 32 && d <= 384 && m >= 32 &&
         m <= 512 && no >= 4 && no <= 384))
     return false;
   const FusedCfg c = fused_cfg(d, m, no);
