@@ -164,3 +164,36 @@ def test_cosine_schedule_matches_torch():
         assert abs(cosine_lr(1e-4, epoch, 30.0, 1e-7) - sch.get_last_lr()[0]) < 1e-12
         opt.step()
         sch.step()
+
+
+def test_folder_pairs_and_rank_sharded_batches(tmp_path):
+    """The training data reader (layout of src/data.py:109-147) and the minibatch sharding of the data-parallel trainer:
+    every rank draws the same permutation and takes rank::world of each global batch, so the union over the ranks is
+    the reference's batch and no image is seen twice in an epoch."""
+    from PIL import Image
+    from srad_amd.trainer import FolderPairs, batches
+    d = tmp_path / "good"
+    for sub in ("HR", "LR_2", "LR_4"):
+        (d / sub).mkdir(parents=True)
+    for i in range(10):
+        hr = np.full((16, 16), 10 * i, dtype=np.uint8)
+        Image.fromarray(hr).save(d / "HR" / f"{i:02d}.png")
+        Image.fromarray(hr[::2, ::2]).save(d / "LR_2" / f"{i:02d}.png")
+        Image.fromarray(hr[::4, ::4]).save(d / "LR_4" / f"{i:02d}.png")
+    single = FolderPairs(str(d), 4, 1)
+    assert len(single) == 10 and not single.multi and single.items[3][1].shape == (4, 4, 1)
+    multi = FolderPairs(str(d), [2, 4], 1)
+    assert multi.multi and [a.shape for a in multi.items[0][1]] == [(4, 4, 1), (8, 8, 1)]       # coarsest first
+    seen = []
+    for rank in range(2):
+        for lr, hr, names in batches(single, 4, epoch=3, rank=rank, world=2):
+            assert lr.shape == (2, 1, 4, 4) and hr.shape == (2, 1, 16, 16) and lr.dtype == torch.float32
+            assert torch.equal(lr[:, 0, 0, 0], hr[:, 0, 0, 0])                                   # pairs stay together
+            seen += list(names)
+    assert len(seen) == 8 and len(set(seen)) == 8                  # 2 full global batches of 4; the ragged tail is dropped
+    one = [n for _, _, names in batches(single, 4, epoch=3) for n in names]
+    assert sorted(one) == sorted(seen)                             # same permutation on every rank
+    lr_list, hr, _ = next(iter(batches(multi, 2, epoch=0, shuffle=False, augment=True)))
+    assert isinstance(lr_list, list) and lr_list[0].shape == (2, 1, 4, 4) and lr_list[1].shape == (2, 1, 8, 8)
+    with pytest.raises(FileNotFoundError):
+        FolderPairs(str(d), 8, 1)
