@@ -47,15 +47,20 @@ constexpr int LNB_J4 = 2;                    // float4 chunks per lane: 2 * 256 
 constexpr int LNB_CP = 320;                  // columns of a dgamma | dbeta partial row (channel counts <= 320)
 
 template <int PREC, bool CONV>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const int ksplit, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const int ksplit, const int tn, const int tc,
+                                                    float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float wsm[];     // [4 waves][64][68] + [4][64] bias + flag
   constexpr int TST = 68;
   float* const dbs = wsm + 4 * 64 * TST;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-  const int tap = blockIdx.z / ksplit, ks = blockIdx.z - tap * ksplit;
-  const int tile_id = (tap * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (linear id L runs on XCD L % 8).  With the row
+  // split fastest (ks = L % ksplit, ksplit a multiple of 8) every tile of one row range lands on the same XCD, so the
+  // range's dY / X rows are fetched into ONE L2 and all the tiles' re-reads of them hit there.
+  const int L = blockIdx.x;
+  const int ks = L % ksplit, tile_id = L / ksplit;
+  const int bx = tile_id % tn, by = (tile_id / tn) % tc, tap = tile_id / (tn * tc);
+  const int n0 = bx * 64, c0 = by * 64;
 
   constexpr int KR = PREC == SRAD_PREC_BF16 ? 32 : 4;        // rows per wave step
   constexpr int RL = PREC == SRAD_PREC_BF16 ? 8 : 1;         // rows per lane per step
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const i
     if (fq == 0) *reinterpret_cast<f32x4*>(dbs + wave * 64 + 4 * fr) = bsum;
   }
   __syncthreads();
-  const bool do_bias = p.db != nullptr && blockIdx.y == 0 && tap == 0;
+  const bool do_bias = p.db != nullptr && by == 0 && tap == 0;
   // thread t owns the float4s e4 = t + 256 j of the tile (n = e4 / 16, c = 4 (e4 % 16))
   f32x4 v[4];
 #pragma unroll
@@ -288,13 +293,14 @@ int launch_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s) {
   const int tn = (p.N + 63) / 64, tc = (p.Cin + 63) / 64;
   const long tiles = (long)tn * tc * p.ntaps;
   constexpr int KR = PREC == SRAD_PREC_BF16 ? 32 : 4;
-  // about two workgroups per CU, at least two row steps per wave
-  long ksplit = (512 + tiles - 1) / tiles;
+  // about two workgroups per CU, at least two row steps per wave; a power of two, so that from 8 up it is a multiple
+  // of 8 (one XCD per row range, see the kernel) and the row ranges come out equal for the usual token counts
+  long target = (512 + tiles - 1) / tiles;
   const long kmax = (p.M + 8 * KR - 1) / (8 * KR);
-  if (ksplit > kmax) ksplit = kmax;
-  if (ksplit < 1) ksplit = 1;
+  if (target > kmax) target = kmax;
+  long ksplit = 1;
+  while (ksplit * 2 <= kmax && ksplit * 10 <= target * 7) ksplit *= 2;      // nearest power of two (rounding up from 1.43x)
   if (const char* e = getenv("SRAD_WGRAD_KSPLIT")) ksplit = atoi(e) > 0 ? atoi(e) : ksplit;   // tools/: timing experiments
-  if ((long)p.ntaps * ksplit > 65535) ksplit = 65535 / p.ntaps;
   {  // drop empty splits: rows_per is rounded up to whole steps
     const long rows_per = ((p.M + ksplit - 1) / ksplit + 4 * KR - 1) / (4 * KR) * (4 * KR);
     ksplit = (p.M + rows_per - 1) / rows_per;
@@ -311,7 +317,7 @@ int launch_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s) {
     it.tn = tn; it.tc = tc; it.ksplit = (int)ksplit; it.tile0 = q.tiles; it.alpha = p.alpha;
     q.tiles += (int)tiles;
   }
-  dim3 grid(tn, tc, (unsigned)(p.ntaps * ksplit));
+  dim3 grid((unsigned)(tiles * ksplit));
   constexpr size_t lds = (size_t)(4 * 64 * 68 + 4 * 64) * sizeof(float);
   const double K = (double)p.ntaps * p.cin_real;
   SradProfScope prof(s, SRAD_K_WGRAD, 2.0 * p.M * p.n_real * K, 4.0 * p.M * ((double)p.N + p.Cin) + 8.0 * p.n_real * K);
@@ -321,7 +327,7 @@ int launch_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s) {
       SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       configured = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p, (int)ksplit, part);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p, (int)ksplit, tn, tc, part);
     return SRAD_OK;
   };
   const int rc = conv ? launch(wgrad_kernel<PREC, true>) : launch(wgrad_kernel<PREC, false>);
