@@ -301,11 +301,9 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
   // the weight gradients, which nothing in the backward waits for, run on a side stream and fill the idle CUs.
   // Set SRAD_BWD_ONE_STREAM=1 to keep everything on the caller's stream.
   static const bool one_stream = getenv("SRAD_BWD_ONE_STREAM") != nullptr;
-  if (!one_stream && !h->side) {
-    int lo = 0, hi = 0;                          // lowest priority: the chain on the caller's stream gets the CUs first
-    SRAD_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    SRAD_CHECK_HIP(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo));
-  }
+  // (default priority: a low-priority side stream gained nothing here, and a process that had created one ran later
+  //  hipGraph replays of other models at half speed - measured with bench.py's C3 leg)
+  if (!one_stream && !h->side) SRAD_CHECK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
   hipStream_t side = one_stream ? s : h->side;
   size_t ev_next = 0;
   auto next_event = [&](hipEvent_t* out) -> int {
