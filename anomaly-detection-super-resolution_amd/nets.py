@@ -274,8 +274,9 @@ class _EngineModule(nn.Module):
     def zero_grad(self, set_to_none: bool = False) -> None:   # noqa: D401 - nn.Module signature
         if getattr(self, "flat_grads", None) is not None:
             self.flat_grads.zero_()
-            for p, g in self._grad_views:
-                p.grad = g
+            if self._grad_views[0][0].grad is None or self._grad_views[-1][0].grad is None:
+                for p, g in self._grad_views:       # an optimizer dropped the views (set_to_none): re-attach all 900
+                    p.grad = g
         else:
             super().zero_grad(set_to_none)
 
