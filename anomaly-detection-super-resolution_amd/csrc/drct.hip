@@ -71,9 +71,6 @@ int forward_body(srad_drct* h, const float* x, int B, int H, int W, float* y, co
   const int E = c.embed_dim, D = E + 4 * c.gc;
   const float mean3[3] = {c.in_chans == 3 ? 0.4488f : 0.f, c.in_chans == 3 ? 0.4371f : 0.f, c.in_chans == 3 ? 0.4040f : 0.f};
 
-  // pad columns of the head-padded q|k|v rows are multiplied by 0 in the attention kernel: keep them
-  // finite whatever the caller's workspace held
-  SRAD_CHECK_HIP(hipMemsetAsync(w.qkv, 0, (size_t)T * h->qkvmax * sizeof(float), s));
   // (x - mean) * img_range, NCHW -> NHWC            (drct.py:887-888)
   SRAD_TRY(srad_launch_nchw_to_nhwc(x, w.xin, B, c.in_chans, SRAD_IMG_CPAD, H, W, mean3, c.img_range, s));
   // conv_first                                       (drct.py:892)

@@ -211,7 +211,6 @@ int srad_drct_forward_train(srad_drct_t* h, const float* x, int B, int H, int W,
       const float* ks1 = keep_scale ? keep_scale + (size_t)(2 * bi) * B : nullptr;
       const float* ks2 = keep_scale ? keep_scale + (size_t)(2 * bi + 1) * B : nullptr;
       SRAD_TRY(srad_launch_layernorm(cur, D, sv.xn1, d, T, d, h->pt.fptr(sw.n1g), h->pt.fptr(sw.n1b), 1e-5f, s));
-      SRAD_CHECK_HIP(hipMemsetAsync(sv.qkv, 0, (size_t)T * 3 * sw.heads * hdp * sizeof(float), s));   // finite pad columns
       {
         GemmParams p = fwd_gemm(h, sw.qkv, sv.xn1, d, T, sv.qkv, 3 * sw.heads * hdp);
         p.hsplit_hd = d / sw.heads; p.hsplit_hdp = hdp;

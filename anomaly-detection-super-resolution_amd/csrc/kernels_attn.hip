@@ -15,7 +15,8 @@
 //
 // Input layout ("head-padded"): row t = [q | k | v], each [heads][hdp] floats, hdp = head_dim
 // rounded up to a multiple of 4 so every (token, head) slice is float4-addressable.  The QKV GEMM
-// epilogue writes this layout directly (GemmParams::hsplit_*); pad columns are never used as data.
+// epilogue writes this layout directly (GemmParams::hsplit_*); pad columns are never read as data and need no
+// initialisation.
 #include "srad_common.h"
 
 namespace {
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
     for (int i = tid; i < tw * tw; i += NT) tbl[i] = p.table[(size_t)i * heads + h];
   __syncthreads();
 
-  // All global loads are unconditional on clamped addresses and masked by a multiply afterwards:
+  // All global loads are unconditional on clamped addresses and masked by selects afterwards:
   // a load inside a per-element branch is waited for before the next one issues.
   f32x4 qv[NLQ], kv[NLV], vv[NLV];
   auto load_tile = [&](const int* toks, int which, auto& dst) {
@@ -119,11 +120,13 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
     for (int i = 0; i < NL; ++i) {
       const int idx = tid + NT * i;
       const int row = idx / V4R, c = (idx - row * V4R) * 4;
-      const float rk = (first + row < N) ? mul : 0.f;
-      f32x4 m;
+      // selects, not a multiply by 0: the pad columns of the head-padded rows (and rows past N) may hold anything,
+      // NaN bit patterns included - nobody has to clear them
+      const bool rok = first + row < N;
+      f32x4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) m[e] = (c + e < hd) ? rk : 0.f;
-      store4<PREC>(base + row * HS + c, src[i] * m);
+      for (int e = 0; e < 4; ++e) v[e] = (rok && c + e < hd) ? src[i][e] * mul : 0.f;
+      store4<PREC>(base + row * HS + c, v);
     }
   };
 

@@ -203,7 +203,7 @@ size_t srad_op_gemm_scratch_bytes(int precision, int N, int Cin, int ntaps) {
 }
 
 // WindowAttention core (reference src/drct.py:281-299 plus the roll/partition/reverse around it):
-// qkv [B*H*W][3][heads][hdp] (head slices padded to hdp floats, hdp % 4 == 0, pad columns finite)
+// qkv [B*H*W][3][heads][hdp] (head slices padded to hdp floats, hdp % 4 == 0, pad columns never read as data)
 // -> out [B*H*W][d], raster token order.
 int srad_op_window_attn(int precision, const float* qkv, float* out, const float* table, int B, int H, int W, int ws,
                         int shift, int d, int heads, int hdp, void* stream) {

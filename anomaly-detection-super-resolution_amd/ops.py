@@ -62,7 +62,7 @@ def gemm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = N
 
 
 def window_attention(qkv: torch.Tensor, table: torch.Tensor, B: int, H: int, W: int, ws: int, shift: int,
-                     heads: int, precision: str = "fp32") -> torch.Tensor:
+                     heads: int, precision: str = "fp32", pad_value: float = 0.0) -> torch.Tensor:
     """qkv: [B*H*W, 3d] raster-ordered tokens in the reference's column order (q | k | v, heads
     contiguous) -> [B*H*W, d].  The kernel reads a head-padded layout (every head slice padded to a
     multiple of 4 floats; the engine's QKV GEMM writes it directly), so this wrapper re-lays it out."""
@@ -71,8 +71,8 @@ def window_attention(qkv: torch.Tensor, table: torch.Tensor, B: int, H: int, W: 
     d = qkv.shape[1] // 3
     hd = d // heads
     hdp = (hd + 3) // 4 * 4
-    padded = torch.nn.functional.pad(qkv.reshape(-1, 3 * heads, hd).float(), (0, hdp - hd)).reshape(-1, 3 * heads * hdp)
-    padded = padded.contiguous()
+    padded = torch.nn.functional.pad(qkv.reshape(-1, 3 * heads, hd).float(), (0, hdp - hd), value=pad_value)
+    padded = padded.reshape(-1, 3 * heads * hdp).contiguous()   # pad columns are never read as data (any value, NaN too)
     out = torch.empty(qkv.shape[0], d, dtype=torch.float32, device=qkv.device)
     L.check(L.lib().srad_op_window_attn(L.PRECISIONS[precision], L.dptr(padded), L.dptr(out),
                                         L.dptr(table.contiguous()), B, H, W, ws, shift, d, heads, hdp,

@@ -137,3 +137,17 @@ def test_bad_arguments_raise(dev):
         ops.window_attention(qkv, torch.zeros(225, 2, device=dev), 1, 30, 30, 8, 0, 2)
     with pytest.raises(RuntimeError, match="GPU only"):
         ops.layernorm(torch.zeros(4, 8), torch.zeros(8), torch.zeros(8))
+
+
+def test_window_attention_ignores_pad_columns(dev):
+    """Head slices are padded to a multiple of 4 floats; the pad columns may hold anything (NaN here): selects, not
+    multiplications by zero, keep them out of q k^T and P V."""
+    from srad_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    B, H, W, ws, d, heads = 1, 16, 16, 8, 180, 6           # head_dim 30 -> padded to 32
+    qkv = torch.randn(B * H * W, 3 * d, generator=g).to(dev)
+    table = torch.randn((2 * ws - 1) ** 2, heads, generator=g).to(dev)
+    for prec in ("fp32", "bf16"):
+        a = ops.window_attention(qkv, table, B, H, W, ws, 4, heads, precision=prec)
+        b = ops.window_attention(qkv, table, B, H, W, ws, 4, heads, precision=prec, pad_value=float("nan"))
+        assert bool(torch.isfinite(b).all()) and torch.equal(a, b)
