@@ -210,6 +210,31 @@ int srad_drct_forward_train(srad_drct_t* h, const float* x, int B, int H, int W,
       const int d = sw.d, hdp = hdp_of(d, sw.heads);
       const float* ks1 = keep_scale ? keep_scale + (size_t)(2 * bi) * B : nullptr;
       const float* ks2 = keep_scale ? keep_scale + (size_t)(2 * bi + 1) * B : nullptr;
+      const int no = k < 4 ? c.gc : E;
+      if (h->fuse_mlp && srad_qkv_attn_supported(prec, c.window_size, H, W, d, sw.heads) &&
+          srad_mlp_block_supported(prec, T, d, sw.hidden, no)) {
+        // bf16: the two fused launches of the inference path, which also leave what the backward needs
+        // (LN1(x), q|k|v, x + attn, LN2(.), fc1 pre-activation, GELU(.), block output) and apply DropPath
+        QkvAttnParams a{};
+        a.x = cur; a.ldx = D; a.ln_g = h->pt.fptr(sw.n1g); a.ln_b = h->pt.fptr(sw.n1b);
+        a.w_qkv = h->pt.ptr(sw.qkv.w); a.b_qkv = h->pt.fptr(sw.qkv.b); a.table = h->pt.fptr(sw.table);
+        a.out = sv.attn; a.ld_out = d; a.B = B; a.H = H; a.W = W; a.shift = sw.shift; a.d = d; a.heads = sw.heads;
+        a.save_xn = sv.xn1; a.save_qkv = sv.qkv; a.hdp = hdp;
+        SRAD_TRY(srad_launch_qkv_attn(a, s));
+        MlpBlockParams q{};
+        q.attn = sv.attn; q.ld_attn = d; q.shortcut = cur; q.ld_short = D;
+        q.M = T; q.d = d; q.m = sw.hidden; q.no = no;
+        q.w_proj = h->pt.frag_ptr(sw.proj.w); q.w_fc1 = h->pt.frag_ptr(sw.fc1.w); q.w_fc2 = h->pt.frag_ptr(sw.fc2.w);
+        q.w_adj = h->pt.frag_ptr(sw.adjust.w);
+        q.b_proj = h->pt.fptr(sw.proj.b); q.b_fc1 = h->pt.fptr(sw.fc1.b); q.b_fc2 = h->pt.fptr(sw.fc2.b); q.b_adj = h->pt.fptr(sw.adjust.b);
+        q.ln_g = h->pt.fptr(sw.n2g); q.ln_b = h->pt.fptr(sw.n2b);
+        q.rs1 = ks1; q.rs2 = ks2; q.rps = HW;
+        q.save_x1 = sv.x1; q.save_xn2 = sv.xn2; q.save_hpre = sv.hpre; q.save_hact = sv.hact; q.save_x2 = sv.x2;
+        if (k < 4) { q.act = SRAD_ACT_LRELU; q.slope = 0.2f; q.alpha = 1.f; q.Y = cur; q.ldy = D; q.yoff = d; }
+        else { q.act = SRAD_ACT_NONE; q.alpha = 0.2f; q.R = cur; q.ldr = D; q.Y = nxt; q.ldy = D; q.yoff = 0; }
+        SRAD_TRY(srad_launch_mlp_block(q, s));
+        continue;
+      }
       SRAD_TRY(srad_launch_layernorm(cur, D, sv.xn1, d, T, d, h->pt.fptr(sw.n1g), h->pt.fptr(sw.n1b), 1e-5f, s));
       {
         GemmParams p = fwd_gemm(h, sw.qkv, sv.xn1, d, T, sv.qkv, 3 * sw.heads * hdp);

@@ -151,6 +151,14 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
       vq[q] = src[min(o, n - 1)];
     }
   }
+  // DropPath factors of this lane's token rows (training; 1 otherwise)
+  float rs1v[NRT], rs2v[NRT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) {
+    const int smp = p.rps > 0 ? (m0 + rt * 16 + fr) / p.rps : 0;
+    rs1v[rt] = p.rs1 ? p.rs1[smp] : 1.f;
+    rs2v[rt] = p.rs2 ? p.rs2[smp] : 1.f;
+  }
   // accumulator layout of this lane: token row 16*rt + fr, columns 128*g + 16*wave + 4*fq + (0..3)
   f32x4 x1[GD][NRT];
 #pragma unroll
@@ -186,9 +194,18 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     {
       const f32x4 bp = *reinterpret_cast<const f32x4*>(v_bp + min(col4_of(g), 380));
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) x1[g][rt] += c[rt] + bp;
+      for (int rt = 0; rt < NRT; ++rt) x1[g][rt] += (c[rt] + bp) * rs1v[rt];
     }
     if constexpr (g != GD - 1) return;
+    if (p.save_x1) {
+#pragma unroll
+      for (int gg = 0; gg < GD; ++gg) {
+        const int c4 = col4_of(gg);
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+          if (c4 < d) *reinterpret_cast<f32x4*>(p.save_x1 + (size_t)(m0 + rt * 16 + fr) * d + c4) = x1[gg][rt];
+      }
+    }
     // LayerNorm2 over the d real columns of x1 -> bf16 -> A1 (all proj reads of A1 are behind a barrier)
     float sm[NRT], sq[NRT];
 #pragma unroll
@@ -232,6 +249,7 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
 #pragma unroll
       for (int rt = 0; rt < NRT; ++rt) {
         const f32x4 v = in ? (x1[gg][rt] - mu[rt]) * rstd[rt] * gam + bet : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.save_xn2 && in) *reinterpret_cast<f32x4*>(p.save_xn2 + (size_t)(m0 + rt * 16 + fr) * d + c4) = v;
         store_bf4(A1, F_LDA, rt, c4, v);
       }
     }
@@ -242,10 +260,12 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt) {
       f32x4 v = c[rt] + b1;
+      if (p.save_hpre && c4 < m) *reinterpret_cast<f32x4*>(p.save_hpre + (size_t)(m0 + rt * 16 + fr) * m + c4) = v;
       if (!(p.dbg & 4)) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
       }
+      if (p.save_hact && c4 < m) *reinterpret_cast<f32x4*>(p.save_hact + (size_t)(m0 + rt * 16 + fr) * m + c4) = v;
       store_bf4(Hs, F_LDH, rt, c4, c4 < m ? v : f32x4{0.f, 0.f, 0.f, 0.f});      // m % 4 == 0
     }
   };
@@ -254,9 +274,18 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     {
       const f32x4 b2 = *reinterpret_cast<const f32x4*>(v_b2 + min(col4_of(g), 380));
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) x1[g][rt] += c[rt] + b2;
+      for (int rt = 0; rt < NRT; ++rt) x1[g][rt] += (c[rt] + b2) * rs2v[rt];
     }
     if constexpr (g != GD - 1) return;
+    if (p.save_x2) {
+#pragma unroll
+      for (int gg = 0; gg < GD; ++gg) {
+        const int c4 = col4_of(gg);
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+          if (c4 < d) *reinterpret_cast<f32x4*>(p.save_x2 + (size_t)(m0 + rt * 16 + fr) * d + c4) = x1[gg][rt];
+      }
+    }
     // x2 -> bf16 -> A1 (its last readers, the fc1 stages, finished long ago)
 #pragma unroll
     for (int gg = 0; gg < GD; ++gg) {

@@ -159,6 +159,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
       const f32x4 g4 = *reinterpret_cast<const f32x4*>(v_g + c);
       const f32x4 b4 = *reinterpret_cast<const f32x4*>(v_b + c);
       const f32x4 v = c < d ? (a_reg[j] - mu) * rstd * g4 + b4 : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.save_xn && h == 0 && c < d) *reinterpret_cast<f32x4*>(p.save_xn + (size_t)tok[xrow] * d + c) = v;
       bf16x4 hh;
       hh[0] = (__bf16)v[0]; hh[1] = (__bf16)v[1]; hh[2] = (__bf16)v[2]; hh[3] = (__bf16)v[3];
       *reinterpret_cast<bf16x4*>(XN + xrow * QA_LDX + c) = hh;
@@ -199,6 +200,8 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
           const int which = vc / HDP, c = vc - which * HDP;       // HDP % 16 == 0: a quad stays in one slice
           const f32x4 bias = *reinterpret_cast<const f32x4*>(v_bias + which * HDP + c);
           f32x4 v = acc[ct] + bias;
+          if (p.save_qkv && c < p.hdp)
+            *reinterpret_cast<f32x4*>(p.save_qkv + (size_t)tok[rt * 16 + fr] * (3 * heads * p.hdp) + (which * heads + h) * p.hdp + c) = v;
           if (which == 0) v = v * scale;
           bf16x4 hh;
 #pragma unroll

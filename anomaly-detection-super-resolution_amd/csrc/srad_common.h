@@ -173,7 +173,10 @@ struct MlpBlockParams {
   int act; float slope, alpha;           // adjust epilogue
   const float* R; int ldr;
   float* Y; int ldy, yoff;
-  int dbg;                               // timing experiments only (tools/): 1 skip W loads, 2 skip MFMA, 4 skip GELU, 8 skip W LDS stores
+  int dbg;                               // timing experiments only (tools/): 1 skip W loads, 2 skip MFMA, 4 skip GELU
+  // ---- training (all optional): DropPath factors of the two residual branches and the tensors the backward needs ----
+  const float *rs1, *rs2; int rps;       // per-sample factors (row m belongs to sample m / rps), null = 1
+  float *save_x1, *save_xn2, *save_hpre, *save_hact, *save_x2;   // [M][d] x + attn branch, [M][d] LayerNorm2, [M][m] fc1 pre-activation, [M][m] GELU, [M][d] block output
 };
 bool srad_mlp_block_supported(int prec, int M, int d, int m, int no);
 int srad_launch_mlp_block(const MlpBlockParams& p, hipStream_t stream);
@@ -189,6 +192,9 @@ struct QkvAttnParams {
   const float* table;                      // [225][heads]
   float* out; int ld_out;                  // attention output [T][d]
   int B, H, W, shift, d, heads;
+  // ---- training (optional): what the backward needs ----
+  float* save_xn;                          // [T][d] LayerNorm1(x) (written by the head-0 workgroups)
+  float* save_qkv; int hdp;                // [T][3][heads][hdp] head-padded q | k | v (q unscaled), as the QKV GEMM writes it
 };
 bool srad_qkv_attn_supported(int prec, int ws, int H, int W, int d, int heads);
 int srad_launch_qkv_attn(const QkvAttnParams& p, hipStream_t stream);

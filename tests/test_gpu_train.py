@@ -278,3 +278,32 @@ def test_data_parallel_step_two_ranks_equals_one_rank_on_the_full_batch():
     # Adam turns noise-level gradients into +-lr steps; compare where the gradient is clearly non-zero
     big = np.abs(g_ref) > 1e-3 * gmax
     assert np.abs(res[0][2] - p_ref)[big].max() < 2e-5
+
+
+def test_bf16_training_fused_forward_matches_unfused(sr_golden, monkeypatch):
+    """bf16 mode: the training forward through the two fused block kernels (with DropPath and the saved activations
+    written from inside them) against the eight-launch path (SRAD_NO_FUSE), same DropPath masks: outputs and
+    gradients agree to bf16 rounding."""
+    name = "drct_r2_rgb_x4"
+    cfg, sd, x, y = drct_case(sr_golden, name)
+    hr = torch.from_numpy(sr_golden[name + "/hr"]).cuda()
+    xt = torch.from_numpy(x).cuda()
+    gen = torch.Generator().manual_seed(3)
+    keep = (torch.floor(0.8 + torch.rand(2 * cfg.n_rdg * 5, x.shape[0], generator=gen)) / 0.8).cuda()
+    outs, grads = {}, {}
+    for mode in ("fused", "unfused"):
+        if mode == "unfused":
+            monkeypatch.setenv("SRAD_NO_FUSE", "1")
+        else:
+            monkeypatch.delenv("SRAD_NO_FUSE", raising=False)
+        m = build_train(cfg, sd, "bf16", drop_path_rate=0.1)
+        m.keep_scale_override = keep
+        out = m(xt)
+        F.l1_loss(out, hr).backward()
+        outs[mode], grads[mode] = out.detach().clone(), m.flat_grads.clone()
+    rng = float(outs["unfused"].max() - outs["unfused"].min())
+    assert float((outs["fused"] - outs["unfused"]).abs().max()) / rng < 1e-2
+    a, b = grads["fused"].double(), grads["unfused"].double()
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    print("fused vs unfused bf16 training: cosine of the gradients", cos)
+    assert cos > 0.999
