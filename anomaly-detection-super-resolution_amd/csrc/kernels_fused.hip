@@ -370,6 +370,7 @@ template <int GD, int KGD, int GM, int KGM, int GN>
 int launch_mlp(const MlpBlockParams& p, hipStream_t stream) {
   // 16-row tiles until there are enough tokens to fill the chip several times with 64-row tiles
   if (p.M >= 32768 && p.M % 64 == 0) return launch_mlp_fm<64, GD, KGD, GM, KGM, GN>(p, stream);
+  if (p.M >= 8192 && p.M % 32 == 0) return launch_mlp_fm<32, GD, KGD, GM, KGM, GN>(p, stream);
   return launch_mlp_fm<16, GD, KGD, GM, KGM, GN>(p, stream);
 }
 // stage geometries of DRCT-L's Swin blocks (embed 180 + k*32; mlp ratio 2,2,2,1,1; adjust to 32 / 180 channels)
