@@ -436,29 +436,26 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       } else {
         dA = gn; ldA = D; aalpha = 0.2f;
       }
-      SRAD_TRY(side_waits_main());
       {
         WgradParams g = wgrad_of(h, sw.adjust, G, dA, ldA, 0, sv.x2, d, T);
         g.alpha = aalpha;
-        SRAD_TRY(srad_launch_wgrad(prec, g, wq, side));
+        SRAD_TRY(srad_launch_wgrad_deferred(prec, g, wq, side));
         GemmParams p = dgrad_gemm(h, sw.adjust, dA, ldA, T, dx2, d);
         p.alpha = aalpha;
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
       // ---- MLP branch: x2 = x1 + rs2 * fc2(gelu(fc1(LN2(x1))))                 (drct.py:510, 184-190)
-      SRAD_TRY(side_waits_main());
       {
         WgradParams g = wgrad_of(h, sw.fc2, G, dx2, d, 0, sv.hact, sw.hidden, T);
         g.row_scale = ks2; g.rps = HW;
-        SRAD_TRY(srad_launch_wgrad(prec, g, wq, side));
+        SRAD_TRY(srad_launch_wgrad_deferred(prec, g, wq, side));
         GemmParams p = dgrad_gemm(h, sw.fc2, dx2, d, T, dh, sw.hidden);
         p.row_scale = ks2; p.rps = HW; p.R = sv.hpre; p.ldr = sw.hidden; p.rmode = SRAD_RMODE_DGELU;
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
-      SRAD_TRY(side_waits_main());
       {
         WgradParams g = wgrad_of(h, sw.fc1, G, dh, sw.hidden, 0, sv.xn2, d, T);
-        SRAD_TRY(srad_launch_wgrad(prec, g, wq, side));
+        SRAD_TRY(srad_launch_wgrad_deferred(prec, g, wq, side));
         GemmParams p = dgrad_gemm(h, sw.fc1, dh, sw.hidden, T, w.dxn, d);
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
@@ -471,11 +468,10 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
         SRAD_TRY(srad_launch_ln_bwd(l, wq, s));
       }
       // ---- attention branch: x1 = x + rs1 * proj(attn(LN1(x)))                  (drct.py:477-509)
-      SRAD_TRY(side_waits_main());
       {
         WgradParams g = wgrad_of(h, sw.proj, G, dx1, d, 0, sv.attn, d, T);
         g.row_scale = ks1; g.rps = HW;
-        SRAD_TRY(srad_launch_wgrad(prec, g, wq, side));
+        SRAD_TRY(srad_launch_wgrad_deferred(prec, g, wq, side));
         GemmParams p = dgrad_gemm(h, sw.proj, dx1, d, T, w.dO, d);
         p.row_scale = ks1; p.rps = HW;
         SRAD_TRY(srad_launch_gemm(prec, p, s));
@@ -485,10 +481,9 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
                         sw.shift, d, sw.heads, hdp};
         SRAD_TRY(srad_launch_window_attn_bwd(a, wq, s));
       }
-      SRAD_TRY(side_waits_main());
       {
         WgradParams g = wgrad_of(h, sw.qkv, G, dqkv, 3 * d, 0, sv.xn1, d, T);
-        SRAD_TRY(srad_launch_wgrad(prec, g, wq, side));
+        SRAD_TRY(srad_launch_wgrad_deferred(prec, g, wq, side));
         GemmParams p = dgrad_gemm(h, sw.qkv, dqkv, 3 * d, T, w.dxn, d);
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
@@ -500,9 +495,10 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
         l.rows = T; l.C = d; l.eps = 1e-5f;
         SRAD_TRY(srad_launch_ln_bwd(l, wq, s));
       }
-      // this block's five weight gradients + LayerNorm / bias-table column sums, one launch on the side stream
-      // (after the caller's stream has written its partial rows)
+      // this block's five weight gradients as ONE launch on the side stream (all their operands exist now), then
+      // the reduce of their partials and of the LayerNorm / bias-table column sums the caller's stream has written
       SRAD_TRY(side_waits_main());
+      SRAD_TRY(srad_wgrad_launch_deferred(prec, wq, side));
       SRAD_TRY(srad_wgrad_flush(wq, side));
       if (side != s) {
         SRAD_TRY(next_event(&side_done[set]));

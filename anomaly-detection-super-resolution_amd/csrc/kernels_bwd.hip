@@ -47,8 +47,8 @@ constexpr int LNB_J4 = 2;                    // float4 chunks per lane: 2 * 256 
 constexpr int LNB_CP = 320;                  // columns of a dgamma | dbeta partial row (channel counts <= 320)
 
 template <int PREC, bool CONV>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const int ksplit, const int tn, const int tc,
-                                                    float* __restrict__ part) {
+__device__ __forceinline__ void wgrad_body(const WgradParams& p, const int ksplit, const int tn, const int tc,
+                                           float* __restrict__ part, const int L) {
   extern __shared__ __attribute__((aligned(16))) float wsm[];     // [4 waves][64][68] + [4][64] bias + flag
   constexpr int TST = 68;
   float* const dbs = wsm + 4 * 64 * TST;
@@ -57,7 +57,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const i
   // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (linear id L runs on XCD L % 8).  With the row
   // split fastest (ks = L % ksplit, ksplit a multiple of 8) every tile of one row range lands on the same XCD, so the
   // range's dY / X rows are fetched into ONE L2 and all the tiles' re-reads of them hit there.
-  const int L = blockIdx.x;
   const int ks = L % ksplit, tile_id = L / ksplit;
   const int bx = tile_id % tn, by = (tile_id / tn) % tc, tap = tile_id / (tn * tc);
   const int n0 = bx * 64, c0 = by * 64;
@@ -226,6 +225,26 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const i
   if (do_bias && tid < 64 && n0 + tid < p.n_real) p.db[n0 + tid] += vb * p.alpha;
 }
 
+template <int PREC, bool CONV>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const int ksplit, const int tn, const int tc,
+                                                    float* __restrict__ part) {
+  wgrad_body<PREC, CONV>(p, ksplit, tn, tc, part, blockIdx.x);
+}
+
+// Several Linear layers' weight gradients in ONE launch (the five of a Swin block): fewer launch ramps on the side
+// stream, and the layers' workgroups fill the chip together.  Each layer's block range starts at a multiple of 8 so
+// the XCD mapping of wgrad_body holds.
+template <int PREC>
+__global__ __launch_bounds__(256) void wgrad_multi_kernel(const WgradMulti mp) {
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < SRAD_WGRAD_MULTI; ++k)
+    if (k < mp.count && (int)blockIdx.x >= mp.blk0[k]) i = k;
+  const int L = blockIdx.x - mp.blk0[i];
+  if (L >= mp.nblk[i]) return;                       // padding blocks between layers
+  wgrad_body<PREC, false>(mp.p[i], mp.ksplit[i], mp.tn[i], mp.tc[i], mp.part[i], L);
+}
+
 // One workgroup per QUARTER of a 64 x 64 output tile of one of the batch's layers (16 rows n, one float4 per
 // thread): dW += alpha * sum_k partial[k], k in fixed order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceBatch b) {
@@ -287,15 +306,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceBatc
   }
 }
 
+struct WgradPlan { int tn, tc, ksplit; long tiles; float* part; };
+
+// tile / split geometry of one layer, its partial-tile workspace and its entry in the reduce batch
 template <int PREC>
-int launch_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s) {
-  const bool conv = p.ntaps == 9 || p.stride != 1;
-  const int tn = (p.N + 63) / 64, tc = (p.Cin + 63) / 64;
-  const long tiles = (long)tn * tc * p.ntaps;
+int plan_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s, WgradPlan& pl) {
+  pl.tn = (p.N + 63) / 64; pl.tc = (p.Cin + 63) / 64;
+  pl.tiles = (long)pl.tn * pl.tc * p.ntaps;
   constexpr int KR = PREC == SRAD_PREC_BF16 ? 32 : 4;
   // about two workgroups per CU, at least two row steps per wave; a power of two, so that from 8 up it is a multiple
   // of 8 (one XCD per row range, see the kernel) and the row ranges come out equal for the usual token counts
-  long target = (512 + tiles - 1) / tiles;
+  long target = (512 + pl.tiles - 1) / pl.tiles;
   const long kmax = (p.M + 8 * KR - 1) / (8 * KR);
   if (target > kmax) target = kmax;
   long ksplit = 1;
@@ -305,34 +326,63 @@ int launch_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s) {
     const long rows_per = ((p.M + ksplit - 1) / ksplit + 4 * KR - 1) / (4 * KR) * (4 * KR);
     ksplit = (p.M + rows_per - 1) / rows_per;
   }
-  float* part = nullptr;
+  pl.ksplit = (int)ksplit;
+  pl.part = nullptr;
   if (ksplit > 1) {
-    const size_t need = (size_t)tiles * ksplit * WG_TS;
+    const size_t need = (size_t)pl.tiles * ksplit * WG_TS;
     SRAD_REQUIRE(q.ws && need <= q.ws_floats, "wgrad: split-K workspace too small (%zu floats needed, %zu given)", need, q.ws_floats);
-    if (q.batch.count == SRAD_WGRAD_BATCH || q.used + need > q.ws_floats) SRAD_TRY(srad_wgrad_flush(q, s));
-    part = q.ws + q.used;
+    if (q.batch.count == SRAD_WGRAD_BATCH || q.used + need > q.ws_floats) {
+      SRAD_REQUIRE(q.multi.count == 0, "wgrad: split-K workspace too small for the deferred layers");
+      SRAD_TRY(srad_wgrad_flush(q, s));
+    }
+    pl.part = q.ws + q.used;
     q.used += need;
     WgradReduceItem& it = q.batch.it[q.batch.count++];
-    it.dW = p.dW; it.db = p.db; it.part = part; it.n_real = p.n_real; it.cin_real = p.cin_real; it.ntaps = p.ntaps;
-    it.tn = tn; it.tc = tc; it.ksplit = (int)ksplit; it.tile0 = q.tiles; it.alpha = p.alpha;
-    q.tiles += (int)tiles;
+    it.dW = p.dW; it.db = p.db; it.part = pl.part; it.n_real = p.n_real; it.cin_real = p.cin_real; it.ntaps = p.ntaps;
+    it.tn = pl.tn; it.tc = pl.tc; it.ksplit = (int)ksplit; it.tile0 = q.tiles; it.alpha = p.alpha;
+    q.tiles += (int)pl.tiles;
   }
-  dim3 grid((unsigned)(tiles * ksplit));
-  constexpr size_t lds = (size_t)(4 * 64 * 68 + 4 * 64) * sizeof(float);
+  return SRAD_OK;
+}
+
+constexpr size_t WG_LDS = (size_t)(4 * 64 * 68 + 4 * 64) * sizeof(float);
+
+template <int PREC>
+int launch_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s) {
+  const bool conv = p.ntaps == 9 || p.stride != 1;
+  WgradPlan pl;
+  SRAD_TRY(plan_wgrad<PREC>(p, q, s, pl));
+  dim3 grid((unsigned)(pl.tiles * pl.ksplit));
   const double K = (double)p.ntaps * p.cin_real;
   SradProfScope prof(s, SRAD_K_WGRAD, 2.0 * p.M * p.n_real * K, 4.0 * p.M * ((double)p.N + p.Cin) + 8.0 * p.n_real * K);
   auto launch = [&](auto kern) -> int {
     static bool configured = false;
     if (!configured) {
-      SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS));
       configured = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p, (int)ksplit, tn, tc, part);
+    hipLaunchKernelGGL(kern, grid, dim3(256), WG_LDS, s, p, pl.ksplit, pl.tn, pl.tc, pl.part);
     return SRAD_OK;
   };
   const int rc = conv ? launch(wgrad_kernel<PREC, true>) : launch(wgrad_kernel<PREC, false>);
   if (rc) return rc;
   SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}
+
+template <int PREC>
+int defer_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s) {
+  SRAD_REQUIRE(p.ntaps == 1 && p.stride == 1, "wgrad: only Linear layers can be deferred");
+  if (q.multi.count == SRAD_WGRAD_MULTI) SRAD_TRY(srad_wgrad_launch_deferred(PREC, q, s));
+  WgradPlan pl;
+  SRAD_TRY(plan_wgrad<PREC>(p, q, s, pl));
+  WgradMulti& m = q.multi;
+  const int i = m.count++;
+  m.p[i] = p; m.ksplit[i] = pl.ksplit; m.tn[i] = pl.tn; m.tc[i] = pl.tc; m.part[i] = pl.part;
+  m.blk0[i] = i == 0 ? 0 : (m.blk0[i - 1] + m.nblk[i - 1] + 7) / 8 * 8;
+  m.nblk[i] = (int)(pl.tiles * pl.ksplit);
+  q.multi_flops += 2.0 * p.M * p.n_real * (double)p.cin_real;
+  q.multi_bytes += 4.0 * p.M * ((double)p.N + p.Cin) + 8.0 * p.n_real * (double)p.cin_real;
   return SRAD_OK;
 }
 
@@ -694,7 +744,37 @@ int srad_wgrad_flush(WgradQueue& q, hipStream_t stream) {
   return SRAD_OK;
 }
 
-int srad_launch_wgrad(int prec, const WgradParams& p, WgradQueue& q, hipStream_t stream) {
+static int check_wgrad(const WgradParams& p);
+
+int srad_launch_wgrad_deferred(int prec, const WgradParams& p, WgradQueue& q, hipStream_t stream) {
+  SRAD_TRY(check_wgrad(p));
+  return prec == SRAD_PREC_BF16 ? defer_wgrad<SRAD_PREC_BF16>(p, q, stream) : defer_wgrad<SRAD_PREC_F32>(p, q, stream);
+}
+
+int srad_wgrad_launch_deferred(int prec, WgradQueue& q, hipStream_t stream) {
+  WgradMulti& m = q.multi;
+  if (m.count == 0) return SRAD_OK;
+  const int total = m.blk0[m.count - 1] + m.nblk[m.count - 1];
+  {
+    SradProfScope prof(stream, SRAD_K_WGRAD, q.multi_flops, q.multi_bytes);
+    auto launch = [&](auto kern) -> int {
+      static bool configured = false;
+      if (!configured) {
+        SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS));
+        configured = true;
+      }
+      hipLaunchKernelGGL(kern, dim3(total), dim3(256), WG_LDS, stream, m);
+      return SRAD_OK;
+    };
+    const int rc = prec == SRAD_PREC_BF16 ? launch(wgrad_multi_kernel<SRAD_PREC_BF16>) : launch(wgrad_multi_kernel<SRAD_PREC_F32>);
+    if (rc) return rc;
+    SRAD_CHECK_HIP(hipGetLastError());
+  }
+  m.count = 0; q.multi_flops = 0; q.multi_bytes = 0;
+  return SRAD_OK;
+}
+
+static int check_wgrad(const WgradParams& p) {
   SRAD_REQUIRE(p.M > 0 && p.N > 0 && p.Cin > 0 && p.dW, "wgrad: empty problem M=%d N=%d Cin=%d", p.M, p.N, p.Cin);
   SRAD_REQUIRE((p.N & 3) == 0 && (p.Cin & 3) == 0 && (p.ldy & 3) == 0 && (p.ldx & 3) == 0 && (p.ycol0 & 3) == 0 &&
                    ((uintptr_t)p.dY & 15) == 0 && ((uintptr_t)p.X & 15) == 0,
@@ -704,6 +784,11 @@ int srad_launch_wgrad(int prec, const WgradParams& p, WgradQueue& q, hipStream_t
   if (p.ntaps == 9 || p.stride != 1)
     SRAD_REQUIRE(p.Ho > 0 && p.Wo > 0 && p.Hi > 0 && p.Wi > 0 && p.M % (p.Ho * p.Wo) == 0, "wgrad: bad conv geometry");
   SRAD_REQUIRE(!p.row_scale || p.rps > 0, "wgrad: row_scale needs rows-per-sample");
+  return SRAD_OK;
+}
+
+int srad_launch_wgrad(int prec, const WgradParams& p, WgradQueue& q, hipStream_t stream) {
+  SRAD_TRY(check_wgrad(p));
   return prec == SRAD_PREC_BF16 ? launch_wgrad<SRAD_PREC_BF16>(p, q, stream) : launch_wgrad<SRAD_PREC_F32>(p, q, stream);
 }
 

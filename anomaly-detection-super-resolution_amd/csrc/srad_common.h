@@ -226,11 +226,24 @@ struct WgradReduceItem {
   float alpha;
 };
 struct WgradReduceBatch { WgradReduceItem it[SRAD_WGRAD_BATCH]; int count; };
+#define SRAD_WGRAD_MULTI 5
+struct WgradMulti {                            // Linear layers whose weight-gradient kernels go out as one launch
+  WgradParams p[SRAD_WGRAD_MULTI];
+  float* part[SRAD_WGRAD_MULTI];
+  int ksplit[SRAD_WGRAD_MULTI], tn[SRAD_WGRAD_MULTI], tc[SRAD_WGRAD_MULTI], blk0[SRAD_WGRAD_MULTI], nblk[SRAD_WGRAD_MULTI];
+  int count;
+};
 struct WgradQueue {
   float* ws = nullptr; size_t ws_floats = 0;   // caller-owned device workspace, 16-byte aligned
   size_t used = 0; int tiles = 0;
   WgradReduceBatch batch{};
+  WgradMulti multi{};
+  double multi_flops = 0, multi_bytes = 0;
 };
+// queue a Linear layer's weight gradient without launching; srad_wgrad_launch_deferred sends all queued ones as one
+// launch (call it before srad_wgrad_flush, which only sums partials that have been written)
+int srad_launch_wgrad_deferred(int prec, const WgradParams& p, WgradQueue& q, hipStream_t stream);
+int srad_wgrad_launch_deferred(int prec, WgradQueue& q, hipStream_t stream);
 int srad_launch_wgrad(int prec, const WgradParams& p, WgradQueue& q, hipStream_t stream);
 int srad_wgrad_flush(WgradQueue& q, hipStream_t stream);
 
