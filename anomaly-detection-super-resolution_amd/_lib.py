@@ -125,7 +125,7 @@ _SIG = {
     "srad_op_dgrad": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P,
                                 C.c_int, C.c_int, C.c_float, C.c_float, _P, _P, C.c_int, _P, C.c_size_t, _P]),
     "srad_op_layernorm_bwd": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P]),
-    "srad_op_window_attn_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+    "srad_op_window_attn_bwd": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, _P, _P]),
 }
 

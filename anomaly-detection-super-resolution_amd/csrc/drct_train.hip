@@ -479,7 +479,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       {
         AttnBwdParams a{sv.qkv, w.dO, dqkv, h->pt.fptr(sw.table), G + h->ts.flat_off[sw.table], B, H, W, c.window_size,
                         sw.shift, d, sw.heads, hdp};
-        SRAD_TRY(srad_launch_window_attn_bwd(a, wq, s));
+        SRAD_TRY(srad_launch_window_attn_bwd(prec, a, wq, s));
       }
       {
         WgradParams g = wgrad_of(h, sw.qkv, G, dqkv, 3 * d, 0, sv.xn1, d, T);

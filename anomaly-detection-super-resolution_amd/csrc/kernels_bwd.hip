@@ -675,6 +675,209 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const AttnBwdParam
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same backward with bf16 MFMA operands (v_mfma_f32_16x16x32_bf16, fp32 accumulation) for the bf16 precision
+// mode: q, k, v, dO chunks are staged as bf16; P and dS leave the softmax as bf16 tiles - dS in both orientations
+// (row-major for dq = dS k, transposed for dk = dS^T q), P transposed (dv = P^T dO) - and the second operand of
+// those three products (k, q, dO: contraction over tokens, their slow axis in LDS) comes through the transposing
+// LDS read ds_read_b64_tr_b16.  Softmax statistics, dS and the bias-table gradient stay fp32.
+// ------------------------------------------------------------------------------------------
+constexpr int AH_HS = 32 + 8, AH_PS = 64 + 8;
+constexpr size_t AH_LDS = (size_t)(4 * 64 * AH_HS + 3 * 64 * AH_PS) * sizeof(__bf16) + (size_t)(256 + 64 * 68) * sizeof(float) + 2 * 64 * sizeof(int);
+
+__global__ __launch_bounds__(256) void window_attn_bwd_bf16_kernel(const AttnBwdParams p, float* __restrict__ tpart) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* Qs = reinterpret_cast<__bf16*>(smem);          // [64][AH_HS] q * scale chunk
+  __bf16* Ks = Qs + 64 * AH_HS;
+  __bf16* Vs = Ks + 64 * AH_HS;
+  __bf16* Gs = Vs + 64 * AH_HS;                          // dO chunk
+  __bf16* Dm = Gs + 64 * AH_HS;                          // [query][key] dS
+  __bf16* DmT = Dm + 64 * AH_PS;                         // [key][query] dS
+  __bf16* PmT = DmT + 64 * AH_PS;                        // [key][query] P
+  float* tbl = reinterpret_cast<float*>(PmT + 64 * AH_PS);   // [225] (256 reserved)
+  float* Df = tbl + 256;                                 // [64][68] fp32 dS for the bias-table gradient
+  int* tok = reinterpret_cast<int*>(Df + 64 * 68);
+  int* inf = tok + 64;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int ws = 8, d = p.d, heads = p.heads, hd = d / heads, hdp = p.hdp;
+  const int ldq = 3 * heads * hdp;
+  const int h = blockIdx.y;
+  const int nWx = p.W / ws, nW = (p.H / ws) * nWx;
+  const int win = blockIdx.x;
+  const int b = win / nW, widx = win - b * nW;
+  const int wy = widx / nWx, wx = widx - wy * nWx;
+  const float scale = rsqrtf((float)hd);
+  const int tw = 2 * ws - 1;
+
+  if (tid < 64) {
+    const int py = tid / ws, px = tid - py * ws;
+    const int r = wy * ws + py, c = wx * ws + px;
+    int orr = r + p.shift; if (orr >= p.H) orr -= p.H;
+    int occ = c + p.shift; if (occ >= p.W) occ -= p.W;
+    tok[tid] = (b * p.H + orr) * p.W + occ;
+    const int rh = r < p.H - ws ? 0 : (r < p.H - p.shift ? 1 : 2);
+    const int rw = c < p.W - ws ? 0 : (c < p.W - p.shift ? 1 : 2);
+    inf[tid] = ((rh * 3 + rw) << 16) | (py << 8) | px;
+  }
+  if (tid < tw * tw) tbl[tid] = p.table[(size_t)tid * heads + h];
+  __syncthreads();
+
+  auto stage = [&](int ch, bool need_v) {
+    const int col0 = ch * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx >> 3, cl = (idx & 7) * 4, c = col0 + cl;
+      const float* base = p.qkv + (size_t)tok[row] * ldq + h * hdp + min(c, hdp - 4);
+      const f32x4 q4 = *reinterpret_cast<const f32x4*>(base);
+      const f32x4 k4 = *reinterpret_cast<const f32x4*>(base + heads * hdp);
+      const f32x4 v4 = need_v ? *reinterpret_cast<const f32x4*>(base + 2 * heads * hdp) : f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x4 qh, kh, vh;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = c + e < hd;
+        qh[e] = (__bf16)(ok ? q4[e] * scale : 0.f);
+        kh[e] = (__bf16)(ok ? k4[e] : 0.f);
+        vh[e] = (__bf16)(ok ? v4[e] : 0.f);
+      }
+      *reinterpret_cast<bf16x4*>(Qs + row * AH_HS + cl) = qh;
+      *reinterpret_cast<bf16x4*>(Ks + row * AH_HS + cl) = kh;
+      if (need_v) *reinterpret_cast<bf16x4*>(Vs + row * AH_HS + cl) = vh;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx >> 5, cl = idx & 31, c = col0 + cl;
+      const float g = p.dout[(size_t)tok[row] * d + h * hd + min(c, hd - 1)];
+      Gs[row * AH_HS + cl] = (__bf16)(c < hd ? g : 0.f);
+    }
+  };
+
+  const int nch = (hd + 31) / 32;
+  f32x4 s[4], dp[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { s[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int ch = 0; ch < nch; ++ch) {
+    if (ch > 0) __syncthreads();
+    stage(ch, true);
+    __syncthreads();
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(Qs + (wave * 16 + fr) * AH_HS + 8 * fq);
+    const bf16x8 g = *reinterpret_cast<const bf16x8*>(Gs + (wave * 16 + fr) * AH_HS + 8 * fq);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16x8 kb = *reinterpret_cast<const bf16x8*>(Ks + (j * 16 + fr) * AH_HS + 8 * fq);
+      const bf16x8 vb = *reinterpret_cast<const bf16x8*>(Vs + (j * 16 + fr) * AH_HS + 8 * fq);
+      s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, kb, s[j], 0, 0, 0);
+      dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g, vb, dp[j], 0, 0, 0);
+    }
+  }
+
+  // ---- softmax (row = 16 wave + 4 fq + e, key = 16 j + fr), dS ----
+  {
+    int kinf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kinf[j] = inf[j * 16 + fr];
+    f32x4 pr[4], dsr[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = wave * 16 + fq * 4 + e;
+      const int qi = inf[row];
+      const int qy = (qi >> 8) & 0xff, qx = qi & 0xff, qr = qi >> 16;
+      float mx = -1e30f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kyy = (kinf[j] >> 8) & 0xff, kxx = kinf[j] & 0xff, kr = kinf[j] >> 16;
+        float v = s[j][e] + tbl[(qy - kyy + ws - 1) * tw + (qx - kxx + ws - 1)];
+        if (p.shift > 0 && qr != kr) v += -100.0f;
+        s[j][e] = v;
+        mx = fmaxf(mx, v);
+      }
+      mx = srad_row16_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s[j][e] = __expf(s[j][e] - mx); sum += s[j][e]; }
+      sum = srad_row16_sum(sum);
+      const float inv = 1.0f / sum;
+      float dl = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s[j][e] *= inv; dl += s[j][e] * dp[j][e]; }
+      dl = srad_row16_sum(dl);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float ds = s[j][e] * (dp[j][e] - dl);
+        pr[j][e] = s[j][e]; dsr[j][e] = ds;
+        Dm[row * AH_PS + j * 16 + fr] = (__bf16)ds;
+        Df[row * 68 + j * 16 + fr] = ds;
+      }
+    }
+    // transposed tiles: this lane's four rows 4 fq .. 4 fq + 3 of query slab `wave` are consecutive along k
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16x4 ph, dh;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ph[e] = (__bf16)pr[j][e]; dh[e] = (__bf16)dsr[j][e]; }
+      *reinterpret_cast<bf16x4*>(PmT + (j * 16 + fr) * AH_PS + wave * 16 + 4 * fq) = ph;
+      *reinterpret_cast<bf16x4*>(DmT + (j * 16 + fr) * AH_PS + wave * 16 + 4 * fq) = dh;
+    }
+  }
+  __syncthreads();
+  if (tid < tw * tw) {                                   // bias-table gradient row of this (window, head), fp32
+    const int dy = tid / tw - (ws - 1), dx = tid - (tid / tw) * tw - (ws - 1);
+    float acc = 0.f;
+    for (int qy = max(0, dy); qy < min(ws, ws + dy); ++qy)
+      for (int qx = max(0, dx); qx < min(ws, ws + dx); ++qx)
+        acc += Df[(qy * ws + qx) * 68 + (qy - dy) * ws + (qx - dx)];
+    tpart[(size_t)win * (tw * tw * heads) + (size_t)tid * heads + h] = acc;
+  }
+
+  // ---- pass B: dq, dk, dv per 32-column chunk ----
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  const int tq = fr >> 2, tp = fr & 3;
+  for (int ch = 0; ch < nch; ++ch) {
+    if (ch > 0 || nch > 1) { __syncthreads(); stage(ch, false); __syncthreads(); }
+    f32x4 dq[2], dk[2], dv[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) { dq[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[jt] = dq[jt]; dv[jt] = dq[jt]; }
+#pragma unroll
+    for (int kk = 0; kk < 64; kk += 32) {
+      const bf16x8 a_ds = *reinterpret_cast<const bf16x8*>(Dm + (wave * 16 + fr) * AH_PS + kk + 8 * fq);
+      const bf16x8 a_dst = *reinterpret_cast<const bf16x8*>(DmT + (wave * 16 + fr) * AH_PS + kk + 8 * fq);
+      const bf16x8 a_pt = *reinterpret_cast<const bf16x8*>(PmT + (wave * 16 + fr) * AH_PS + kk + 8 * fq);
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        // B[k = token kk + 8 fq + t][j = column 16 jt + fr] of the row-major chunk tiles: two transposing reads each
+        auto tr8 = [&](const __bf16* tile) -> bf16x8 {
+          const __bf16* r0 = tile + (kk + 8 * fq + tq) * AH_HS + jt * 16 + 4 * tp;
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0 + 4 * AH_HS));
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
+          return o;
+        };
+        dq[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_ds, tr8(Ks), dq[jt], 0, 0, 0);
+        dk[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_dst, tr8(Qs), dk[jt], 0, 0, 0);
+        dv[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_pt, tr8(Gs), dv[jt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float* dst = p.dqkv + (size_t)tok[wave * 16 + fq * 4 + e] * (3 * d) + h * hd;
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        const int c = ch * 32 + jt * 16 + fr;
+        if (c < hd) {
+          dst[c] = dq[jt][e] * scale;
+          dst[d + c] = dk[jt][e];
+          dst[2 * d + c] = dv[jt][e];
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ elementwise
 __global__ void dact_kernel(const float* __restrict__ dy, int ld_dy, const float* __restrict__ y, int ld_y,
                             float* __restrict__ out, int ld_out, int rows, int C, float slope) {
@@ -825,7 +1028,7 @@ int srad_launch_ln_bwd(const LnBwdParams& p, WgradQueue& q, hipStream_t stream) 
   return SRAD_OK;
 }
 
-int srad_launch_window_attn_bwd(const AttnBwdParams& p, WgradQueue& q, hipStream_t stream) {
+int srad_launch_window_attn_bwd(int prec, const AttnBwdParams& p, WgradQueue& q, hipStream_t stream) {
   SRAD_REQUIRE(p.ws == 8, "window_attn_bwd: the training path supports window size 8 only (got %d)", p.ws);
   SRAD_REQUIRE(p.H % p.ws == 0 && p.W % p.ws == 0, "window_attn_bwd: %dx%d not a multiple of the window", p.H, p.W);
   SRAD_REQUIRE(p.d % p.heads == 0 && p.hdp % 4 == 0 && p.hdp >= p.d / p.heads, "window_attn_bwd: bad head geometry");
@@ -846,7 +1049,17 @@ int srad_launch_window_attn_bwd(const AttnBwdParams& p, WgradQueue& q, hipStream
   q.used += need;
   SRAD_TRY(queue_colsum(q, p.dtable, tpart, ncols, ncols, nwin, 1.f, stream));
   SradProfScope prof(stream, SRAD_K_ATTN_BWD, 10.0 * T * 64 * p.d, 4.0 * T * 8 * p.d);
-  hipLaunchKernelGGL(window_attn_bwd_kernel, dim3(p.B * nW, p.heads), dim3(256), AB_LDS, stream, p, tpart);
+  if (prec == SRAD_PREC_BF16) {
+    static bool configured16 = false;
+    if (!configured16) {
+      SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_bf16_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)AH_LDS));
+      configured16 = true;
+    }
+    hipLaunchKernelGGL(window_attn_bwd_bf16_kernel, dim3(p.B * nW, p.heads), dim3(256), AH_LDS, stream, p, tpart);
+  } else {
+    hipLaunchKernelGGL(window_attn_bwd_kernel, dim3(p.B * nW, p.heads), dim3(256), AB_LDS, stream, p, tpart);
+  }
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
 }

@@ -187,14 +187,14 @@ int srad_op_layernorm_bwd(const float* dxn, const float* x, int ldx, const float
   return srad_wgrad_flush(q, reinterpret_cast<hipStream_t>(stream));
 }
 
-int srad_op_window_attn_bwd(const float* qkv, const float* dout, float* dqkv, const float* table, float* dtable, int B,
-                            int H, int W, int ws, int shift, int d, int heads, int hdp, void* workspace, void* stream) {
+int srad_op_window_attn_bwd(int precision, const float* qkv, const float* dout, float* dqkv, const float* table, float* dtable,
+                            int B, int H, int W, int ws, int shift, int d, int heads, int hdp, void* workspace, void* stream) {
   SRAD_REQUIRE(qkv && dout && dqkv && table && dtable && workspace, "op_window_attn_bwd: null argument");
   AttnBwdParams a{qkv, dout, dqkv, table, dtable, B, H, W, ws, shift, d, heads, hdp};
   WgradQueue q;
   q.ws = reinterpret_cast<float*>(workspace);
   q.ws_floats = SRAD_WGRAD_WS_BYTES / sizeof(float);
-  SRAD_TRY(srad_launch_window_attn_bwd(a, q, reinterpret_cast<hipStream_t>(stream)));
+  SRAD_TRY(srad_launch_window_attn_bwd(precision, a, q, reinterpret_cast<hipStream_t>(stream)));
   return srad_wgrad_flush(q, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -273,7 +273,7 @@ struct AttnBwdParams {
   float* dtable;       // accumulated (atomicAdd)
   int B, H, W, ws, shift, d, heads, hdp;
 };
-int srad_launch_window_attn_bwd(const AttnBwdParams& p, WgradQueue& q, hipStream_t stream);   // dtable via the queue
+int srad_launch_window_attn_bwd(int prec, const AttnBwdParams& p, WgradQueue& q, hipStream_t stream);   // dtable via the queue
 
 // out[m][c] = dy[m*ld_dy + c] * (y[m*ld_y + c] > 0 ? 1 : slope), c < C  (backward through (Leaky)ReLU)
 int srad_launch_dact(const float* dy, int ld_dy, const float* y, int ld_y, float* out, int ld_out, int rows, int C,

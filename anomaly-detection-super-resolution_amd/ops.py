@@ -160,7 +160,7 @@ def layernorm_bwd(dxn: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, dres:
 
 
 def window_attention_bwd(qkv: torch.Tensor, dout: torch.Tensor, table: torch.Tensor, B: int, H: int, W: int, ws: int,
-                         shift: int, heads: int):
+                         shift: int, heads: int, precision: str = "fp32"):
     """Backward of window_attention: qkv [T, 3d] (reference column order), dout [T, d] -> (dqkv [T, 3d], dtable)."""
     _need_cuda(qkv, dout, table)
     d = qkv.shape[1] // 3
@@ -169,7 +169,7 @@ def window_attention_bwd(qkv: torch.Tensor, dout: torch.Tensor, table: torch.Ten
     padded = torch.nn.functional.pad(qkv.reshape(-1, 3 * heads, hd).float(), (0, hdp - hd)).reshape(-1, 3 * heads * hdp).contiguous()
     dqkv = torch.empty(qkv.shape[0], 3 * d, dtype=torch.float32, device=qkv.device)
     dtable = torch.zeros_like(table, dtype=torch.float32).contiguous()
-    L.check(L.lib().srad_op_window_attn_bwd(L.dptr(padded), L.dptr(dout.contiguous()), L.dptr(dqkv), L.dptr(table.contiguous()),
+    L.check(L.lib().srad_op_window_attn_bwd(L.PRECISIONS[precision], L.dptr(padded), L.dptr(dout.contiguous()), L.dptr(dqkv), L.dptr(table.contiguous()),
                                             L.dptr(dtable), B, H, W, ws, shift, d, heads, hdp, wgrad_workspace(qkv.device),
                                             L.current_stream_ptr()),
             "op_window_attn_bwd")

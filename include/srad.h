@@ -223,8 +223,9 @@ int srad_op_layernorm_bwd(const float* dxn, const float* x, int ldx, const float
                           int accumulate, float* dgamma, float* dbeta, int rows, int C, void* workspace, void* stream);
 /* Window attention backward (window size 8): qkv head-padded as for srad_op_window_attn, dout [T][d],
  * dqkv [T][3d] compact, dtable accumulated; workspace as for srad_op_wgrad */
-int srad_op_window_attn_bwd(const float* qkv, const float* dout, float* dqkv, const float* table, float* dtable, int B,
-                            int H, int W, int ws, int shift, int d, int heads, int hdp, void* workspace, void* stream);
+int srad_op_window_attn_bwd(int precision, const float* qkv, const float* dout, float* dqkv, const float* table,
+                            float* dtable, int B, int H, int W, int ws, int shift, int d, int heads, int hdp,
+                            void* workspace, void* stream);
 
 /* ------------------------------------------------------------------ diagnostics
  * Per-kernel-class device timing with HIP events on the launch stream (bench.py's roofline numbers). */
