@@ -42,8 +42,7 @@ static inline int grid_for(size_t total) {
 #define SRAD_WGRAD_PREFETCH 1   /* two register sets: measured best together with the two-stream backward */
 #endif
 constexpr int WG_TS = 64 * 64 + 64;          // floats per partial: the tile and its 64 bias sums
-constexpr int LNB_RPW = 32;                  // LayerNorm backward: rows per workgroup
-constexpr int LNB_J4 = 2;                    // float4 chunks per lane: 2 * 256 = 512 channels at most
+constexpr int LNB_RPW = 16;                  // LayerNorm backward: rows per workgroup
 constexpr int LNB_CP = 320;                  // columns of a dgamma | dbeta partial row (channel counts <= 320)
 
 template <int PREC, bool CONV>
@@ -396,16 +395,16 @@ int defer_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s) {
 // HAS_RES / ACC are template flags: a load behind a run-time test is waited for before the next one issues.
 // One wave per row, 32 rows per 4-wave workgroup.
 // Lane l owns channels [4 l, 4 l + 4) and [256 + 4 l, 256 + 4 l + 4): 16-byte loads, two per tensor per row.
-template <bool HAS_RES, bool ACC>
+template <bool HAS_RES, bool ACC, int J4>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdParams p, float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) float red[4][2][512];      // per wave: dgamma | dbeta partial rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-  int cofs[LNB_J4];
-  bool cok[LNB_J4];
-  f32x4 gam[LNB_J4], dg[LNB_J4], db[LNB_J4];
+  int cofs[J4];
+  bool cok[J4];
+  f32x4 gam[J4], dg[J4], db[J4];
 #pragma unroll
-  for (int j = 0; j < LNB_J4; ++j) {
+  for (int j = 0; j < J4; ++j) {
     const int c = 4 * lane + 256 * j;
     cok[j] = c < p.C;                          // C % 4 == 0: a float4 is all in or all out
     cofs[j] = min(c, p.C - 4);
@@ -414,57 +413,82 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdParams p, float*
   }
   const float invC = 1.0f / (float)p.C;
   const int r_end = min(p.rows, (int)(blockIdx.x + 1) * LNB_RPW);
-  for (int row = blockIdx.x * LNB_RPW + wave; row < r_end; row += 4) {
-    f32x4 xv[LNB_J4], dy[LNB_J4], rv[LNB_J4], ov[LNB_J4];
+  // two rows per wave and trip: their loads are in flight together and the four reduction chains interleave
+  for (int row0 = blockIdx.x * LNB_RPW + wave; row0 < r_end; row0 += 8) {
+    f32x4 xv[2][J4], dy[2][J4], rv[2][J4], ov[2][J4];
+    int rows_[2];
+    bool rok[2];
 #pragma unroll
-    for (int j = 0; j < LNB_J4; ++j) {
-      xv[j] = *reinterpret_cast<const f32x4*>(p.x + (size_t)row * p.ldx + cofs[j]);
-      dy[j] = *reinterpret_cast<const f32x4*>(p.dxn + (size_t)row * p.ld_dxn + cofs[j]);
-      rv[j] = z4; ov[j] = z4;
-      if constexpr (HAS_RES) rv[j] = *reinterpret_cast<const f32x4*>(p.dres + (size_t)row * p.ld_dres + cofs[j]);
-      if constexpr (ACC) ov[j] = *reinterpret_cast<const f32x4*>(p.out + (size_t)row * p.ld_out + cofs[j]);
+    for (int u = 0; u < 2; ++u) {
+      rok[u] = row0 + 4 * u < r_end;
+      rows_[u] = rok[u] ? row0 + 4 * u : row0;
+#pragma unroll
+      for (int j = 0; j < J4; ++j) {
+        xv[u][j] = *reinterpret_cast<const f32x4*>(p.x + (size_t)rows_[u] * p.ldx + cofs[j]);
+        dy[u][j] = *reinterpret_cast<const f32x4*>(p.dxn + (size_t)rows_[u] * p.ld_dxn + cofs[j]);
+        rv[u][j] = z4; ov[u][j] = z4;
+        if constexpr (HAS_RES) rv[u][j] = *reinterpret_cast<const f32x4*>(p.dres + (size_t)rows_[u] * p.ld_dres + cofs[j]);
+        if constexpr (ACC) ov[u][j] = *reinterpret_cast<const f32x4*>(p.out + (size_t)rows_[u] * p.ld_out + cofs[j]);
+      }
+    }
+    float s[2], v[2], s1[2], s2[2], rstd[2];
+    f32x4 xh[2][J4], gy[2][J4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      s[u] = 0.f;
+#pragma unroll
+      for (int j = 0; j < J4; ++j) {
+        xv[u][j] = cok[j] ? xv[u][j] : z4;
+        dy[u][j] = cok[j] && rok[u] ? dy[u][j] : z4;
+        s[u] += (xv[u][j][0] + xv[u][j][1]) + (xv[u][j][2] + xv[u][j][3]);
+      }
     }
 #pragma unroll
-    for (int j = 0; j < LNB_J4; ++j) {
-      xv[j] = cok[j] ? xv[j] : z4;
-      dy[j] = cok[j] ? dy[j] : z4;
-    }
-    float s = 0.f;
+    for (int u = 0; u < 2; ++u) s[u] = srad_wave_sum(s[u]) * invC;
 #pragma unroll
-    for (int j = 0; j < LNB_J4; ++j) s += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]);
-    s = srad_wave_sum(s);
-    const float mean = s * invC;
-    float v = 0.f;
-    f32x4 xh[LNB_J4], gy[LNB_J4];
+    for (int u = 0; u < 2; ++u) {
+      v[u] = 0.f;
 #pragma unroll
-    for (int j = 0; j < LNB_J4; ++j) {
-      xh[j] = cok[j] ? xv[j] - mean : z4;
-      v += (xh[j][0] * xh[j][0] + xh[j][1] * xh[j][1]) + (xh[j][2] * xh[j][2] + xh[j][3] * xh[j][3]);
+      for (int j = 0; j < J4; ++j) {
+        xh[u][j] = cok[j] ? xv[u][j] - s[u] : z4;
+        v[u] += (xh[u][j][0] * xh[u][j][0] + xh[u][j][1] * xh[u][j][1]) + (xh[u][j][2] * xh[u][j][2] + xh[u][j][3] * xh[u][j][3]);
+      }
     }
-    v = srad_wave_sum(v);
-    const float rstd = rsqrtf(v * invC + p.eps);
-    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < LNB_J4; ++j) {
-      xh[j] = xh[j] * rstd;
-      gy[j] = dy[j] * gam[j];
-      const f32x4 t = gy[j] * xh[j];
-      s1 += (gy[j][0] + gy[j][1]) + (gy[j][2] + gy[j][3]);
-      s2 += (t[0] + t[1]) + (t[2] + t[3]);
-      dg[j] += dy[j] * xh[j];
-      db[j] += dy[j];
-    }
-    s1 = srad_wave_sum(s1) * invC;
-    s2 = srad_wave_sum(s2) * invC;
+    for (int u = 0; u < 2; ++u) { v[u] = srad_wave_sum(v[u]); rstd[u] = rsqrtf(v[u] * invC + p.eps); }
 #pragma unroll
-    for (int j = 0; j < LNB_J4; ++j) {
-      const f32x4 o4 = (gy[j] - s1 - xh[j] * s2) * rstd + rv[j] + ov[j];
-      if (cok[j]) *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.ld_out + 4 * lane + 256 * j) = o4;
+    for (int u = 0; u < 2; ++u) {
+      s1[u] = 0.f; s2[u] = 0.f;
+#pragma unroll
+      for (int j = 0; j < J4; ++j) {
+        xh[u][j] = xh[u][j] * rstd[u];
+        gy[u][j] = dy[u][j] * gam[j];
+        const f32x4 t = gy[u][j] * xh[u][j];
+        s1[u] += (gy[u][j][0] + gy[u][j][1]) + (gy[u][j][2] + gy[u][j][3]);
+        s2[u] += (t[0] + t[1]) + (t[2] + t[3]);
+        dg[j] += dy[u][j] * xh[u][j];
+        db[j] += dy[u][j];
+      }
     }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { s1[u] = srad_wave_sum(s1[u]) * invC; s2[u] = srad_wave_sum(s2[u]) * invC; }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int j = 0; j < J4; ++j) {
+        const f32x4 o4 = (gy[u][j] - s1[u] - xh[u][j] * s2[u]) * rstd[u] + rv[u][j] + ov[u][j];
+        if (cok[j] && rok[u]) *reinterpret_cast<f32x4*>(p.out + (size_t)rows_[u] * p.ld_out + 4 * lane + 256 * j) = o4;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = J4; j < 2; ++j) {
+    *reinterpret_cast<f32x4*>(&red[wave][0][4 * lane + 256 * j]) = z4;
+    *reinterpret_cast<f32x4*>(&red[wave][1][4 * lane + 256 * j]) = z4;
   }
   // LDS float atomics cost ~13 us here (measured); plain 16-byte stores per wave, then a 4-way sum
 #pragma unroll
-  for (int j = 0; j < LNB_J4; ++j) {
+  for (int j = 0; j < J4; ++j) {
     *reinterpret_cast<f32x4*>(&red[wave][0][4 * lane + 256 * j]) = dg[j];
     *reinterpret_cast<f32x4*>(&red[wave][1][4 * lane + 256 * j]) = db[j];
   }
@@ -1020,10 +1044,15 @@ int srad_launch_ln_bwd(const LnBwdParams& p, WgradQueue& q, hipStream_t stream) 
   if (p.dgamma) SRAD_TRY(queue_colsum(q, p.dgamma, part, p.C, 2 * LNB_CP, nwg, 1.f, stream));
   if (p.dbeta) SRAD_TRY(queue_colsum(q, p.dbeta, part + LNB_CP, p.C, 2 * LNB_CP, nwg, 1.f, stream));
   SradProfScope prof(stream, SRAD_K_LN_BWD, 16.0 * p.rows * p.C, 4.0 * p.rows * p.C * (3 + (p.dres ? 1 : 0) + (p.accumulate ? 1 : 0)));
-  if (p.dres && p.accumulate) hipLaunchKernelGGL((ln_bwd_kernel<true, true>), dim3(nwg), dim3(256), 0, stream, p, part);
-  else if (p.dres) hipLaunchKernelGGL((ln_bwd_kernel<true, false>), dim3(nwg), dim3(256), 0, stream, p, part);
-  else if (p.accumulate) hipLaunchKernelGGL((ln_bwd_kernel<false, true>), dim3(nwg), dim3(256), 0, stream, p, part);
-  else hipLaunchKernelGGL((ln_bwd_kernel<false, false>), dim3(nwg), dim3(256), 0, stream, p, part);
+  auto go = [&](auto j4) {
+    constexpr int J = decltype(j4)::value;
+    if (p.dres && p.accumulate) hipLaunchKernelGGL((ln_bwd_kernel<true, true, J>), dim3(nwg), dim3(256), 0, stream, p, part);
+    else if (p.dres) hipLaunchKernelGGL((ln_bwd_kernel<true, false, J>), dim3(nwg), dim3(256), 0, stream, p, part);
+    else if (p.accumulate) hipLaunchKernelGGL((ln_bwd_kernel<false, true, J>), dim3(nwg), dim3(256), 0, stream, p, part);
+    else hipLaunchKernelGGL((ln_bwd_kernel<false, false, J>), dim3(nwg), dim3(256), 0, stream, p, part);
+  };
+  if (p.C <= 256) go(std::integral_constant<int, 1>{});
+  else go(std::integral_constant<int, 2>{});
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
 }

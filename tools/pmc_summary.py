@@ -28,6 +28,10 @@ def classify(name: str) -> str:
         return "window_attn"
     if "layernorm_kernel" in name:
         return "layernorm"
+    for key, cls in (("wgrad_multi_kernel", "wgrad"), ("wgrad_kernel", "wgrad"), ("wgrad_reduce_kernel", "wgrad_reduce"),
+                     ("ln_bwd_kernel", "layernorm_bwd"), ("window_attn_bwd", "window_attn_bwd")):
+        if key in name:
+            return cls
     return "other"
 
 
