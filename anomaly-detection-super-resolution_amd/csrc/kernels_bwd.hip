@@ -309,13 +309,14 @@ struct WgradPlan { int tn, tc, ksplit; long tiles; float* part; };
 
 // tile / split geometry of one layer, its partial-tile workspace and its entry in the reduce batch
 template <int PREC>
-int plan_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s, WgradPlan& pl) {
+int plan_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s, WgradPlan& pl, const long wg_target = 512) {
   pl.tn = (p.N + 63) / 64; pl.tc = (p.Cin + 63) / 64;
   pl.tiles = (long)pl.tn * pl.tc * p.ntaps;
   constexpr int KR = PREC == SRAD_PREC_BF16 ? 32 : 4;
-  // about two workgroups per CU, at least two row steps per wave; a power of two, so that from 8 up it is a multiple
-  // of 8 (one XCD per row range, see the kernel) and the row ranges come out equal for the usual token counts
-  long target = (512 + pl.tiles - 1) / pl.tiles;
+  // about two workgroups per CU for a launch of its own (wg_target 512; layers that share a launch ask for fewer,
+  // longer workgroups: less ramp, fewer partial tiles), at least two row steps per wave; a power of two, so that
+  // from 8 up it is a multiple of 8 (one XCD per row range, see the kernel) and the row ranges come out equal
+  long target = (wg_target + pl.tiles - 1) / pl.tiles;
   const long kmax = (p.M + 8 * KR - 1) / (8 * KR);
   if (target > kmax) target = kmax;
   long ksplit = 1;
@@ -374,7 +375,7 @@ int defer_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s) {
   SRAD_REQUIRE(p.ntaps == 1 && p.stride == 1, "wgrad: only Linear layers can be deferred");
   if (q.multi.count == SRAD_WGRAD_MULTI) SRAD_TRY(srad_wgrad_launch_deferred(PREC, q, s));
   WgradPlan pl;
-  SRAD_TRY(plan_wgrad<PREC>(p, q, s, pl));
+  SRAD_TRY(plan_wgrad<PREC>(p, q, s, pl, 144));      // the launch is shared by up to SRAD_WGRAD_MULTI layers
   WgradMulti& m = q.multi;
   const int i = m.count++;
   m.p[i] = p; m.ksplit[i] = pl.ksplit; m.tn[i] = pl.tn; m.tc[i] = pl.tc; m.part[i] = pl.part;
