@@ -530,9 +530,15 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const AttnBwdParam
   const int fr = lane & 15, fq = lane >> 4;
   const int ws = 8, d = p.d, heads = p.heads, hd = d / heads, hdp = p.hdp;
   const int ldq = 3 * heads * hdp;
-  const int h = blockIdx.y;
   const int nWx = p.W / ws, nW = (p.H / ws) * nWx;
-  const int win = blockIdx.x;
+  // workgroups are dealt round-robin over the 8 XCDs: keep all heads of a window on ONE XCD (its L2 then holds the
+  // window's dO / dqkv lines, which the heads share at 4-byte granularity, once)
+  int win, h;
+  {
+    const int L = blockIdx.x, nwin = p.B * nW;
+    if ((nwin & 7) == 0) { const int slot = L >> 3; win = (slot / heads) * 8 + (L & 7); h = slot - (slot / heads) * heads; }
+    else { win = L / heads; h = L - win * heads; }
+  }
   const int b = win / nW, widx = win - b * nW;
   const int wy = widx / nWx, wx = widx - wy * nWx;
   const float scale = rsqrtf((float)hd);
@@ -728,9 +734,15 @@ __global__ __launch_bounds__(256) void window_attn_bwd_bf16_kernel(const AttnBwd
   const int fr = lane & 15, fq = lane >> 4;
   const int ws = 8, d = p.d, heads = p.heads, hd = d / heads, hdp = p.hdp;
   const int ldq = 3 * heads * hdp;
-  const int h = blockIdx.y;
   const int nWx = p.W / ws, nW = (p.H / ws) * nWx;
-  const int win = blockIdx.x;
+  // workgroups are dealt round-robin over the 8 XCDs: keep all heads of a window on ONE XCD (its L2 then holds the
+  // window's dO / dqkv lines, which the heads share at 4-byte granularity, once)
+  int win, h;
+  {
+    const int L = blockIdx.x, nwin = p.B * nW;
+    if ((nwin & 7) == 0) { const int slot = L >> 3; win = (slot / heads) * 8 + (L & 7); h = slot - (slot / heads) * heads; }
+    else { win = L / heads; h = L - win * heads; }
+  }
   const int b = win / nW, widx = win - b * nW;
   const int wy = widx / nWx, wx = widx - wy * nWx;
   const float scale = rsqrtf((float)hd);
@@ -1086,9 +1098,9 @@ int srad_launch_window_attn_bwd(int prec, const AttnBwdParams& p, WgradQueue& q,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)AH_LDS));
       configured16 = true;
     }
-    hipLaunchKernelGGL(window_attn_bwd_bf16_kernel, dim3(p.B * nW, p.heads), dim3(256), AH_LDS, stream, p, tpart);
+    hipLaunchKernelGGL(window_attn_bwd_bf16_kernel, dim3(p.B * nW * p.heads), dim3(256), AH_LDS, stream, p, tpart);
   } else {
-    hipLaunchKernelGGL(window_attn_bwd_kernel, dim3(p.B * nW, p.heads), dim3(256), AB_LDS, stream, p, tpart);
+    hipLaunchKernelGGL(window_attn_bwd_kernel, dim3(p.B * nW * p.heads), dim3(256), AB_LDS, stream, p, tpart);
   }
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
