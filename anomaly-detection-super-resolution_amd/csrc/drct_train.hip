@@ -325,6 +325,8 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
   // the weight gradients, which nothing in the backward waits for, run on a side stream and fill the idle CUs.
   // Set SRAD_BWD_ONE_STREAM=1 to keep everything on the caller's stream.
   static const bool one_stream = getenv("SRAD_BWD_ONE_STREAM") != nullptr;
+  // bf16 mode: the MLP branch's two data gradients + LayerNorm2 backward as one kernel (SRAD_NO_FUSE=1: separate launches)
+  const bool fused_bwd = prec == SRAD_PREC_BF16 && getenv("SRAD_NO_FUSE") == nullptr;
   // (default priority: a low-priority side stream gained nothing here, and a process that had created one ran later
   //  hipGraph replays of other models at half speed - measured with bench.py's C3 leg)
   if (!one_stream && !h->side) SRAD_CHECK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
@@ -445,27 +447,40 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
       // ---- MLP branch: x2 = x1 + rs2 * fc2(gelu(fc1(LN2(x1))))                 (drct.py:510, 184-190)
+      const bool fuse_mlp = fused_bwd && h->ts.tf_off[sw.fc1.w] >= 0 && h->ts.tf_off[sw.fc2.w] >= 0 &&
+                            srad_mlp_bwd_supported(prec, T, d, sw.hidden);
       {
         WgradParams g = wgrad_of(h, sw.fc2, G, dx2, d, 0, sv.hact, sw.hidden, T);
         g.row_scale = ks2; g.rps = HW;
         SRAD_TRY(srad_launch_wgrad_deferred(prec, g, wq, side));
-        GemmParams p = dgrad_gemm(h, sw.fc2, dx2, d, T, dh, sw.hidden);
-        p.row_scale = ks2; p.rps = HW; p.R = sv.hpre; p.ldr = sw.hidden; p.rmode = SRAD_RMODE_DGELU;
-        SRAD_TRY(srad_launch_gemm(prec, p, s));
+        WgradParams g1 = wgrad_of(h, sw.fc1, G, dh, sw.hidden, 0, sv.xn2, d, T);
+        SRAD_TRY(srad_launch_wgrad_deferred(prec, g1, wq, side));
       }
-      {
-        WgradParams g = wgrad_of(h, sw.fc1, G, dh, sw.hidden, 0, sv.xn2, d, T);
-        SRAD_TRY(srad_launch_wgrad_deferred(prec, g, wq, side));
-        GemmParams p = dgrad_gemm(h, sw.fc1, dh, sw.hidden, T, w.dxn, d);
-        SRAD_TRY(srad_launch_gemm(prec, p, s));
-      }
-      {  // dx1 = dx2 + dLN2(dxn)
-        LnBwdParams l{};
-        l.dxn = w.dxn; l.ld_dxn = d; l.x = sv.x1; l.ldx = d; l.gamma = h->pt.fptr(sw.n2g);
-        l.dres = dx2; l.ld_dres = d; l.out = dx1; l.ld_out = d;
-        l.dgamma = G + h->ts.flat_off[sw.n2g]; l.dbeta = G + h->ts.flat_off[sw.n2b];
-        l.rows = T; l.C = d; l.eps = 1e-5f;
-        SRAD_TRY(srad_launch_ln_bwd(l, wq, s));
+      if (fuse_mlp) {   // both data gradients and the LayerNorm2 backward in one launch (kernels_fused_bwd.hip)
+        MlpBwdParams mb{};
+        mb.M = T; mb.d = d; mb.m = sw.hidden; mb.dx2 = dx2; mb.rs2 = ks2; mb.rps = HW;
+        mb.w_fc2t = h->ts.tarena + h->ts.tf_off[sw.fc2.w]; mb.hpre = sv.hpre; mb.dh = dh;
+        mb.w_fc1t = h->ts.tarena + h->ts.tf_off[sw.fc1.w]; mb.x1 = sv.x1; mb.ln_g = h->pt.fptr(sw.n2g); mb.dx1 = dx1;
+        mb.dgamma = G + h->ts.flat_off[sw.n2g]; mb.dbeta = G + h->ts.flat_off[sw.n2b];
+        SRAD_TRY(srad_launch_mlp_bwd(mb, wq, s));
+      } else {
+        {
+          GemmParams p = dgrad_gemm(h, sw.fc2, dx2, d, T, dh, sw.hidden);
+          p.row_scale = ks2; p.rps = HW; p.R = sv.hpre; p.ldr = sw.hidden; p.rmode = SRAD_RMODE_DGELU;
+          SRAD_TRY(srad_launch_gemm(prec, p, s));
+        }
+        {
+          GemmParams p = dgrad_gemm(h, sw.fc1, dh, sw.hidden, T, w.dxn, d);
+          SRAD_TRY(srad_launch_gemm(prec, p, s));
+        }
+        {  // dx1 = dx2 + dLN2(dxn)
+          LnBwdParams l{};
+          l.dxn = w.dxn; l.ld_dxn = d; l.x = sv.x1; l.ldx = d; l.gamma = h->pt.fptr(sw.n2g);
+          l.dres = dx2; l.ld_dres = d; l.out = dx1; l.ld_out = d;
+          l.dgamma = G + h->ts.flat_off[sw.n2g]; l.dbeta = G + h->ts.flat_off[sw.n2b];
+          l.rows = T; l.C = d; l.eps = 1e-5f;
+          SRAD_TRY(srad_launch_ln_bwd(l, wq, s));
+        }
       }
       // ---- attention branch: x1 = x + rs1 * proj(attn(LN1(x)))                  (drct.py:477-509)
       {

@@ -43,7 +43,7 @@ static inline int grid_for(size_t total) {
 #endif
 constexpr int WG_TS = 64 * 64 + 64;          // floats per partial: the tile and its 64 bias sums
 constexpr int LNB_RPW = 16;                  // LayerNorm backward: rows per workgroup
-constexpr int LNB_CP = 320;                  // columns of a dgamma | dbeta partial row (channel counts <= 320)
+constexpr int LNB_CP = SRAD_LNB_CP;                  // columns of a dgamma | dbeta partial row (channel counts <= 320)
 
 template <int PREC, bool CONV>
 __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int ksplit, const int tn, const int tc,
@@ -1042,6 +1042,17 @@ static int queue_colsum(WgradQueue& q, float* dst, const float* part, int ncols,
   return SRAD_OK;
 }
 
+int srad_wgrad_queue_ln_partials(WgradQueue& q, float* dgamma, float* dbeta, int C, int nrows, hipStream_t stream, float** part) {
+  const size_t need = (size_t)nrows * 2 * LNB_CP;
+  SRAD_REQUIRE(q.ws && need <= q.ws_floats, "ln_bwd: workspace too small");
+  if (q.batch.count + 2 > SRAD_WGRAD_BATCH || q.used + need > q.ws_floats) SRAD_TRY(srad_wgrad_flush(q, stream));
+  *part = q.ws + q.used;
+  q.used += need;
+  if (dgamma) SRAD_TRY(queue_colsum(q, dgamma, *part, C, 2 * LNB_CP, nrows, 1.f, stream));
+  if (dbeta) SRAD_TRY(queue_colsum(q, dbeta, *part + LNB_CP, C, 2 * LNB_CP, nrows, 1.f, stream));
+  return SRAD_OK;
+}
+
 int srad_launch_ln_bwd(const LnBwdParams& p, WgradQueue& q, hipStream_t stream) {
   SRAD_REQUIRE(p.rows > 0 && p.C >= 4 && p.C <= LNB_CP && (p.C & 3) == 0, "ln_bwd: channel count %d unsupported (4..%d, multiple of 4)", p.C, LNB_CP);
   SRAD_REQUIRE(((p.ldx | p.ld_dxn | p.ld_out | (p.dres ? p.ld_dres : 0)) & 3) == 0 &&
@@ -1049,13 +1060,8 @@ int srad_launch_ln_bwd(const LnBwdParams& p, WgradQueue& q, hipStream_t stream) 
                "ln_bwd: rows must be 16-byte aligned (strides multiples of 4 floats)");
   SRAD_REQUIRE(p.dxn && p.x && p.gamma && p.out, "ln_bwd: null argument");
   const int nwg = (p.rows + LNB_RPW - 1) / LNB_RPW;
-  const size_t need = (size_t)nwg * 2 * LNB_CP;
-  SRAD_REQUIRE(q.ws && need <= q.ws_floats, "ln_bwd: workspace too small");
-  if (q.batch.count + 2 > SRAD_WGRAD_BATCH || q.used + need > q.ws_floats) SRAD_TRY(srad_wgrad_flush(q, stream));
-  float* part = q.ws + q.used;
-  q.used += need;
-  if (p.dgamma) SRAD_TRY(queue_colsum(q, p.dgamma, part, p.C, 2 * LNB_CP, nwg, 1.f, stream));
-  if (p.dbeta) SRAD_TRY(queue_colsum(q, p.dbeta, part + LNB_CP, p.C, 2 * LNB_CP, nwg, 1.f, stream));
+  float* part = nullptr;
+  SRAD_TRY(srad_wgrad_queue_ln_partials(q, p.dgamma, p.dbeta, p.C, nwg, stream, &part));
   SradProfScope prof(stream, SRAD_K_LN_BWD, 16.0 * p.rows * p.C, 4.0 * p.rows * p.C * (3 + (p.dres ? 1 : 0) + (p.accumulate ? 1 : 0)));
   auto go = [&](auto j4) {
     constexpr int J = decltype(j4)::value;

@@ -1,0 +1,329 @@
+// kernels_fused_bwd.hip - backward of the MLP branch of a DRCT Swin block as ONE launch (bf16 MFMA, fp32 accumulate):
+//
+//   x2 = x1 + rs2 * fc2(GELU(fc1(LayerNorm2(x1))))                 (src/drct.py:510, 184-190)
+//
+//   dh  = (dx2 . W2) * rs2 * gelu'(hpre)     [M][m]   written: fc1's weight gradient contracts it with LN2(x1)
+//   dxn = dh . W1                             [M][d]   never leaves the CU
+//   dx1 = dx2 + LayerNorm2'(dxn; x1, gamma)   [M][d]   dgamma / dbeta as per-workgroup partial rows (split-K queue)
+//
+// Same scheme as the forward kernel (kernels_fused.hip): a workgroup owns FM token rows for the whole chain, the A
+// operands live in LDS as bf16, the two TRANSPOSED weight matrices stream from their fragment-major packs straight
+// into MFMA registers three stages ahead, results are transposed so a lane owns 4 consecutive columns of a token row.
+// It replaces two data-gradient GEMM launches and the LayerNorm backward launch of the unfused chain and the
+// [M][m] + [M][d] round trips between them.
+#include "srad_common.h"
+#include <type_traits>
+
+namespace {
+
+template <int B, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < N) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, N>(f);
+  }
+}
+
+constexpr int FB_LDA = 392;        // LDS row stride of the <=384-wide bf16 dx2 tile
+constexpr int FB_LDH = 520;        // LDS row stride of the <=512-wide bf16 dh tile
+constexpr int FB_SC = 128;         // output columns per weight stage
+
+// d/dx of the exact-erf GELU, Phi(x) + x phi(x), with erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7)
+__device__ __forceinline__ float dgelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = 1.0f / (1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float ex = __expf(-z * z);                   // exp(-x^2 / 2)
+  const float erfa = 1.0f - poly * ex;
+  return 0.5f * (1.0f + (x < 0.f ? -erfa : erfa)) + x * 0.39894228040143267794f * ex;
+}
+
+// GD / GM = 128-column groups of the block dim / hidden, KGD / KGM = 256-wide k groups of the block dim / hidden
+template <int FM, int GD, int KGD, int GM, int KGM>
+__global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, float* __restrict__ part) {
+  constexpr int NRT = FM / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* A1 = reinterpret_cast<__bf16*>(smem);                  // [FM][FB_LDA] dx2
+  __bf16* Hs = A1 + FM * FB_LDA;                                 // [FM][FB_LDH] dh
+  float* v_g = reinterpret_cast<float*>(Hs + FM * FB_LDH);       // [384] gamma
+  float* red = v_g + 384;                                        // [FM][8 waves][2] row partial sums
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int m0 = blockIdx.x * FM;
+  const int d = p.d, m = p.m;
+  const int Kd = (d + 31) & ~31, Km = (m + 31) & ~31;
+  constexpr int n_fc2 = GM * KGD, n_fc1 = GD * KGM, n_stages = n_fc2 + n_fc1;
+
+  auto stage_ptr = [&](int s, int& Kp, int& nch) -> const char* {
+    s = min(s, n_stages - 1);
+    const char* w; int kgs;
+    if (s < n_fc2) { w = (const char*)p.w_fc2t; Kp = Kd; kgs = KGD; }
+    else { s -= n_fc2; w = (const char*)p.w_fc1t; Kp = Km; kgs = KGM; }
+    const int g = s / kgs, kg = s - g * kgs;
+    nch = min(8, (Kp >> 5) - kg * 8);
+    return w + ((size_t)(g * 8 + wave) * (Kp >> 5) + kg * 8) * 1024;
+  };
+  constexpr int NSETS = 3;
+  u32x4 w_reg[NSETS][8];
+  auto load_w = [&](int s, u32x4 (&reg)[8]) {
+    int Kp, nch;
+    const char* base = stage_ptr(s, Kp, nch) + fr * 64 + fq * 16;
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + (cc < nch ? cc : 0) * 1024);
+  };
+  auto mma_stage = [&](const __bf16* A, int lda, int k0, int nch, const u32x4 (&reg)[8], f32x4 (&c)[NRT]) {
+    const __bf16* ar = A + fr * lda + k0 + 8 * fq;
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      if (cc < nch) {
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, reg[cc]);
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + rt * 16 * lda + cc * 32);
+          c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, c[rt], 0, 0, 0);
+        }
+      }
+    }
+  };
+  auto col4_of = [&](int g) { return FB_SC * g + 16 * wave + 4 * fq; };
+  auto store_bf4 = [&](__bf16* base, int ld, int rt, int c4, f32x4 v) {
+    bf16x4 h;
+    h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+    *reinterpret_cast<bf16x4*>(base + (rt * 16 + fr) * ld + c4) = h;
+  };
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- independent loads: dx2 tile (A operand layout), first weight stages, gamma, dx2 / x1 in the result layout ----
+  constexpr int NAQ = 32 * GD;
+  constexpr int NAJ = FM * NAQ / 512;
+  static_assert(FM * NAQ % 512 == 0, "dx2 tile must divide over the workgroup");
+  f32x4 a_reg[NAJ];
+#pragma unroll
+  for (int j = 0; j < NAJ; ++j) {
+    const int idx = tid + 512 * j, row = idx / NAQ, c = (idx - row * NAQ) * 4;
+    a_reg[j] = *reinterpret_cast<const f32x4*>(p.dx2 + (size_t)(m0 + row) * d + min(c, d - 4));
+  }
+#pragma unroll
+  for (int q = 0; q < NSETS; ++q) load_w(q, w_reg[q]);
+  const float gq = tid < 384 ? p.ln_g[min(tid, d - 1)] : 0.f;
+  float rs2v[NRT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) rs2v[rt] = p.rs2 ? p.rs2[(m0 + rt * 16 + fr) / p.rps] : 1.f;
+  f32x4 r2[GD][NRT], xv[GD][NRT];
+#pragma unroll
+  for (int g = 0; g < GD; ++g) {
+    const int c4 = min(col4_of(g), d - 4);
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+      r2[g][rt] = *reinterpret_cast<const f32x4*>(p.dx2 + (size_t)(m0 + rt * 16 + fr) * d + c4);
+      xv[g][rt] = *reinterpret_cast<const f32x4*>(p.x1 + (size_t)(m0 + rt * 16 + fr) * d + c4);
+    }
+  }
+  // every group's fc1 pre-activations now: they come from HBM (written a whole forward ago) and a group is only one
+  // or two stages long, so a load issued at its start would be waited for in full at its end
+  f32x4 hp[GM][NRT];
+#pragma unroll
+  for (int g = 0; g < GM; ++g) {
+    const int c4 = min(col4_of(g), m - 4);
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) hp[g][rt] = *reinterpret_cast<const f32x4*>(p.hpre + (size_t)(m0 + rt * 16 + fr) * m + c4);
+  }
+  if (tid < 384) v_g[tid] = gq;
+#pragma unroll
+  for (int j = 0; j < NAJ; ++j) {
+    const int idx = tid + 512 * j, row = idx / NAQ, c = (idx - row * NAQ) * 4;
+    const f32x4 v = c < d ? a_reg[j] : z4;
+    bf16x4 h;
+    h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+    *reinterpret_cast<bf16x4*>(A1 + row * FB_LDA + c) = h;
+  }
+
+  f32x4 dxn[GD][NRT];
+  f32x4 c[NRT];
+  static_for<0, n_stages>([&](auto S) {
+    constexpr int s = decltype(S)::value;
+    constexpr int ph = s < n_fc2 ? 0 : 1;
+    constexpr int ls = s - (ph == 0 ? 0 : n_fc2);
+    constexpr int kgs = ph == 0 ? KGD : KGM;
+    constexpr int g = ls / kgs, kg = ls - g * kgs;
+    u32x4 (&reg)[8] = w_reg[s % NSETS];
+    const int Kp = ph == 0 ? Kd : Km;
+    const int nch = min(8, (Kp >> 5) - kg * 8);
+    if constexpr (ls == 0) __syncthreads();            // the phase's activation tile (A1 / Hs) is complete
+    if constexpr (kg == 0) {
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) c[rt] = z4;
+    }
+    mma_stage(ph == 0 ? A1 : Hs, ph == 0 ? FB_LDA : FB_LDH, kg * 256, nch, reg, c);
+    load_w(s + NSETS, reg);
+    if constexpr (kg == kgs - 1) {
+      if constexpr (ph == 0) {
+        const int c4 = col4_of(g);
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = c[rt][e] * rs2v[rt] * dgelu_fast(hp[g][rt][e]);
+          v = c4 < m ? v : z4;                         // m % 4 == 0
+          if (c4 < m) *reinterpret_cast<f32x4*>(p.dh + (size_t)(m0 + rt * 16 + fr) * m + c4) = v;
+          store_bf4(Hs, FB_LDH, rt, c4, v);
+        }
+      } else {
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) dxn[g][rt] = c[rt];
+      }
+    }
+  });
+
+  // ---- LayerNorm2 backward over the d real columns (lane: token row 16 rt + fr, columns col4_of(g) + 0..3) ----
+  const float invC = 1.0f / (float)d;
+  auto row_reduce2 = [&](float (&a)[NRT], float (&b)[NRT]) {     // sums over the whole row: 4 fq groups x 8 waves
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+      a[rt] += __shfl_xor(a[rt], 16); b[rt] += __shfl_xor(b[rt], 16);
+      a[rt] += __shfl_xor(a[rt], 32); b[rt] += __shfl_xor(b[rt], 32);
+      if (fq == 0) {
+        red[((rt * 16 + fr) * 8 + wave) * 2 + 0] = a[rt];
+        red[((rt * 16 + fr) * 8 + wave) * 2 + 1] = b[rt];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+      const float* r = red + (rt * 16 + fr) * 16;
+      float su = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { su += r[2 * w]; s2 += r[2 * w + 1]; }
+      a[rt] = su; b[rt] = s2;
+    }
+  };
+  float sm[NRT], sq[NRT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) { sm[rt] = 0.f; sq[rt] = 0.f; }
+#pragma unroll
+  for (int g = 0; g < GD; ++g) {
+    const bool in = col4_of(g) < d;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+      xv[g][rt] = in ? xv[g][rt] : z4;
+      sm[rt] += (xv[g][rt][0] + xv[g][rt][1]) + (xv[g][rt][2] + xv[g][rt][3]);
+    }
+  }
+  row_reduce2(sm, sq);
+  float mu[NRT], rstd[NRT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) { mu[rt] = sm[rt] * invC; sq[rt] = 0.f; sm[rt] = 0.f; }
+#pragma unroll
+  for (int g = 0; g < GD; ++g) {
+    const bool in = col4_of(g) < d;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+      xv[g][rt] = in ? xv[g][rt] - mu[rt] : z4;                  // centred, as the forward / unfused kernels compute it
+      sq[rt] += (xv[g][rt][0] * xv[g][rt][0] + xv[g][rt][1] * xv[g][rt][1]) + (xv[g][rt][2] * xv[g][rt][2] + xv[g][rt][3] * xv[g][rt][3]);
+    }
+  }
+  __syncthreads();                                               // everyone has read the first sums
+  row_reduce2(sq, sm);
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) rstd[rt] = rsqrtf(sq[rt] * invC + 1e-5f);
+  float s1[NRT], s2[NRT];
+  f32x4 dg[GD], db[GD];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) { s1[rt] = 0.f; s2[rt] = 0.f; }
+#pragma unroll
+  for (int g = 0; g < GD; ++g) {
+    const int c4 = col4_of(g);
+    const bool in = c4 < d;
+    const f32x4 gam = *reinterpret_cast<const f32x4*>(v_g + min(c4, 380));
+    dg[g] = z4; db[g] = z4;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+      const f32x4 dy = in ? dxn[g][rt] : z4;
+      xv[g][rt] = xv[g][rt] * rstd[rt];                          // xhat
+      dg[g] += dy * xv[g][rt];
+      db[g] += dy;
+      dxn[g][rt] = dy * gam;                                     // gy
+      const f32x4 t = dxn[g][rt] * xv[g][rt];
+      s1[rt] += (dxn[g][rt][0] + dxn[g][rt][1]) + (dxn[g][rt][2] + dxn[g][rt][3]);
+      s2[rt] += (t[0] + t[1]) + (t[2] + t[3]);
+    }
+  }
+  __syncthreads();
+  row_reduce2(s1, s2);
+#pragma unroll
+  for (int g = 0; g < GD; ++g) {
+    const int c4 = col4_of(g);
+    if (c4 < d) {
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) {
+        const f32x4 o4 = (dxn[g][rt] - s1[rt] * invC - xv[g][rt] * (s2[rt] * invC)) * rstd[rt] + r2[g][rt];
+        *reinterpret_cast<f32x4*>(p.dx1 + (size_t)(m0 + rt * 16 + fr) * d + c4) = o4;
+      }
+    }
+  }
+  // dgamma / dbeta of this workgroup's rows: sum over the 16 token rows of the lane group, one partial row per workgroup
+  float* prow = part + (size_t)blockIdx.x * (2 * SRAD_LNB_CP);
+#pragma unroll
+  for (int g = 0; g < GD; ++g) {
+    const int c4 = col4_of(g);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dg[g][e] = srad_row16_sum(dg[g][e]); db[g][e] = srad_row16_sum(db[g][e]); }
+    if (fr == 0 && c4 < d) {
+      *reinterpret_cast<f32x4*>(prow + c4) = dg[g];
+      *reinterpret_cast<f32x4*>(prow + SRAD_LNB_CP + c4) = db[g];
+    }
+  }
+}
+
+struct BwdCfg { int gd, kgd, gm, kgm; };
+inline BwdCfg bwd_cfg(int d, int m) {
+  const int Kd = srad_cp(d), Km = srad_cp(m);
+  return BwdCfg{(d + FB_SC - 1) / FB_SC, (Kd + 255) / 256, (m + FB_SC - 1) / FB_SC, (Km + 255) / 256};
+}
+template <int FM, int GD, int KGD, int GM, int KGM>
+int launch_bwd_fm(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream) {
+  constexpr size_t lds = (size_t)(FM * FB_LDA + FM * FB_LDH) * 2 + (384 + FM * 16) * sizeof(float);
+  auto kern = mlp_bwd_kernel<FM, GD, KGD, GM, KGM>;
+  static bool configured = false;
+  if (!configured) {
+    SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  float* part = nullptr;
+  SRAD_TRY(srad_wgrad_queue_ln_partials(q, p.dgamma, p.dbeta, p.d, p.M / FM, stream, &part));
+  SradProfScope prof(stream, SRAD_K_MLP_BWD, 8.0 * p.M * p.d * p.m, 4.0 * p.M * (3.0 * p.d + 2.0 * p.m) + 4.0 * p.d * p.m);
+  hipLaunchKernelGGL(kern, dim3(p.M / FM), dim3(512), lds, stream, p, part);
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}
+template <int GD, int KGD, int GM, int KGM>
+int launch_bwd(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream) {
+  if (p.M >= 8192 && p.M % 32 == 0) return launch_bwd_fm<32, GD, KGD, GM, KGM>(p, q, stream);
+  return launch_bwd_fm<16, GD, KGD, GM, KGM>(p, q, stream);
+}
+// stage geometries of DRCT-L's Swin blocks (embed 180 + k*32; mlp ratio 2, 2, 2, 1, 1)
+#define SRAD_BWD_CFGS(X) X(2, 1, 3, 2) X(2, 1, 4, 2) X(3, 2, 3, 2)
+}  // namespace
+
+bool srad_mlp_bwd_supported(int prec, int M, int d, int m) {
+  if (!(prec == SRAD_PREC_BF16 && M % 16 == 0 && d % 4 == 0 && m % 4 == 0 && d >= 32 && d <= SRAD_LNB_CP && m >= 32 && m <= 512)) return false;
+  const BwdCfg c = bwd_cfg(d, m);
+#define X(a, b, cc, dd) if (c.gd == a && c.kgd == b && c.gm == cc && c.kgm == dd) return true;
+  SRAD_BWD_CFGS(X)
+#undef X
+  return false;
+}
+
+int srad_launch_mlp_bwd(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream) {
+  SRAD_REQUIRE(srad_mlp_bwd_supported(SRAD_PREC_BF16, p.M, p.d, p.m), "mlp_bwd: unsupported shape M=%d d=%d m=%d", p.M, p.d, p.m);
+  SRAD_REQUIRE(p.dx2 && p.w_fc2t && p.hpre && p.dh && p.w_fc1t && p.x1 && p.ln_g && p.dx1, "mlp_bwd: null argument");
+  SRAD_REQUIRE((((uintptr_t)p.dx2 | (uintptr_t)p.hpre | (uintptr_t)p.dh | (uintptr_t)p.x1 | (uintptr_t)p.dx1) & 15) == 0,
+               "mlp_bwd: tensors must be 16-byte aligned");
+  SRAD_REQUIRE(!p.rs2 || p.rps > 0, "mlp_bwd: rows per sample missing");
+  const BwdCfg c = bwd_cfg(p.d, p.m);
+#define X(a, b, cc, dd) if (c.gd == a && c.kgd == b && c.gm == cc && c.kgm == dd) return launch_bwd<a, b, cc, dd>(p, q, stream);
+  SRAD_BWD_CFGS(X)
+#undef X
+  return srad_set_error(SRAD_ERR_ARG, "mlp_bwd: no kernel instance for this geometry");
+}

@@ -263,6 +263,31 @@ struct LnBwdParams {
 
 // dgamma / dbeta go through the split-K queue too (per-workgroup column sums, added up at the next flush)
 int srad_launch_ln_bwd(const LnBwdParams& p, WgradQueue& q, hipStream_t stream);
+// `nrows` partial rows [dgamma SRAD_LNB_CP | dbeta SRAD_LNB_CP] in the queue's workspace + their two column-sum items
+constexpr int SRAD_LNB_CP = 320;
+int srad_wgrad_queue_ln_partials(WgradQueue& q, float* dgamma, float* dbeta, int C, int nrows, hipStream_t stream, float** part);
+
+// ------------------------------------------------------------------------------------------
+// Fused backward of the MLP branch of a Swin block (kernels_fused_bwd.hip, bf16 mode):
+//   dh  = (dx2 . W2) * rs2 * gelu'(hpre)            -> written (operand of fc1's weight gradient)
+//   dx1 = dx2 + LayerNorm2'(dh . W1)                 dgamma / dbeta partial rows -> the split-K queue
+// Weights are fragment-major packs of the TRANSPOSED Linear weights (training arena).
+// ------------------------------------------------------------------------------------------
+struct MlpBwdParams {
+  int M, d, m;
+  const float* dx2;                     // [M][d] gradient of the block output before the adjust conv
+  const float* rs2; int rps;            // DropPath factor of the MLP branch per sample (null = 1)
+  const void* w_fc2t;                   // fragments of fc2.weight^T: rows = hidden, k = d
+  const float* hpre;                    // [M][m] fc1 pre-activation
+  float* dh;                            // [M][m]
+  const void* w_fc1t;                   // fragments of fc1.weight^T: rows = d, k = hidden
+  const float* x1;                      // [M][d] LayerNorm2 input
+  const float* ln_g;
+  float* dx1;                           // [M][d]
+  float *dgamma, *dbeta;
+};
+bool srad_mlp_bwd_supported(int prec, int M, int d, int m);
+int srad_launch_mlp_bwd(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream);
 
 // Shifted-window attention backward (window size 8): recomputes P from the saved head-padded q|k|v.
 struct AttnBwdParams {
@@ -307,7 +332,7 @@ int srad_launch_nhwc_to_nchw(const float* x, int ldx, float* y, int B, int C, in
 enum {
   SRAD_K_GEMM_BN64 = 0, SRAD_K_GEMM_BN32, SRAD_K_GEMM_BN16, SRAD_K_ATTN, SRAD_K_LAYERNORM,
   SRAD_K_LAYOUT, SRAD_K_PACK, SRAD_K_SCORE, SRAD_K_MISC, SRAD_K_MLP_BLOCK, SRAD_K_QKV_ATTN,
-  SRAD_K_WGRAD, SRAD_K_ATTN_BWD, SRAD_K_LN_BWD, SRAD_K_OPTIM, SRAD_K_WGRAD_REDUCE, SRAD_K_COUNT
+  SRAD_K_WGRAD, SRAD_K_ATTN_BWD, SRAD_K_LN_BWD, SRAD_K_OPTIM, SRAD_K_WGRAD_REDUCE, SRAD_K_MLP_BWD, SRAD_K_COUNT
 };
 struct SradProfScope {
   hipStream_t s; int active;

@@ -9,6 +9,7 @@ struct TrainState {
   std::vector<int64_t> flat_off;  // per table entry: offset (floats) in the flat fp32 parameter / gradient buffers
   int64_t flat_total = 0;
   std::vector<size_t> t_off;      // per table entry: byte offset of the transposed pack in the training arena
+  std::vector<long long> tf_off;  // per table entry: byte offset of the fragment-major pack of the TRANSPOSED weight (-1: none)
   size_t t_desc_off = 0;          // byte offset of the device descriptor table inside the training arena
   size_t t_wgrad_off = 0;         // byte offset of the split-K workspace
   size_t t_bytes = 0;
@@ -22,6 +23,7 @@ struct SyncDesc {
   long long dst_off;    // bytes into the forward arena
   long long tdst_off;   // bytes into the training arena (-1: no transposed pack)
   long long fdst_off;   // bytes into the forward arena of the fragment-major bf16 pack (-1: none)
+  long long tfdst_off;  // bytes into the training arena of the fragment-major bf16 pack of the transposed weight (-1: none)
   int packed, n, cin, ntaps, Np, Cp, tRp, tKp;
   long long numel;
   unsigned blk0, nblk;
@@ -72,6 +74,18 @@ __global__ __launch_bounds__(256) void sync_params_kernel(const SyncDesc* __rest
       fdst[i] = (__bf16)((n < d.n && k < d.cin) ? src[(long long)n * d.cin + k] : 0.f);
     }
   }
+  if (d.tfdst_off >= 0) {                     // the same tiles of W^T: rows = input channels, k = output channels
+    __bf16* fdst = reinterpret_cast<__bf16*>(tarena + d.tfdst_off);
+    const long long ptotal = (long long)d.tRp * d.tKp;
+    const int ktiles = d.tKp / 32;
+    for (long long i = base + threadIdx.x; i < base + SYNC_EPB && i < ptotal; i += 256) {
+      const int kin = (int)(i & 31), rin = (int)((i >> 5) & 15);
+      const long long tile = i >> 9;
+      const int kt = (int)(tile % ktiles), nt = (int)(tile / ktiles);
+      const int c = nt * 16 + rin, n = kt * 32 + kin;
+      fdst[i] = (__bf16)((n < d.n && c < d.cin) ? src[(long long)n * d.cin + c] : 0.f);
+    }
+  }
   if (d.tdst_off >= 0) {
     const long long ttotal = (long long)d.tRp * d.ntaps * d.tKp;
     T* tdst = reinterpret_cast<T*>(tarena + d.tdst_off);
@@ -108,6 +122,11 @@ inline int train_arena_bytes(const ParamTable& pt, TrainState& ts, size_t* bytes
       ts.t_off.push_back(off);
       if (e.packed) off += srad_align_up(srad_packed_bytes(pt.prec, srad_round_up(e.cin, 4), srad_round_up(e.n, 4), e.ntaps), 256);
     }
+    for (const ParamEntry& e : pt.entries) {      // Linear layers of the fused kernels: W^T as MFMA fragments too
+      const bool frag = e.packed && e.frag_off >= 0 && e.ntaps == 1;
+      ts.tf_off.push_back(frag ? (long long)off : -1);
+      if (frag) off += srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, srad_round_up(e.cin, 4), srad_round_up(e.n, 4), 1), 256);
+    }
     ts.t_desc_off = off;
     off += srad_align_up(pt.entries.size() * sizeof(SyncDesc), 256);
     ts.t_wgrad_off = off;                       // split-K workspace of the weight-gradient kernel
@@ -131,7 +150,7 @@ inline int train_bind(const ParamTable& pt, TrainState& ts, void* train_arena, s
   for (size_t i = 0; i < pt.entries.size(); ++i) {
     const ParamEntry& e = pt.entries[i];
     SyncDesc d{};
-    d.src_off = ts.flat_off[i]; d.dst_off = (long long)e.off; d.tdst_off = -1; d.fdst_off = e.frag_off;
+    d.src_off = ts.flat_off[i]; d.dst_off = (long long)e.off; d.tdst_off = -1; d.fdst_off = e.frag_off; d.tfdst_off = -1;
     d.packed = e.packed; d.numel = e.numel;
     long long work = e.numel;
     if (e.packed) {
@@ -140,6 +159,7 @@ inline int train_bind(const ParamTable& pt, TrainState& ts, void* train_arena, s
       d.n = e.n; d.cin = e.cin; d.ntaps = e.ntaps; d.Np = srad_np(e.n); d.Cp = srad_cp(e.cin);
       d.tRp = srad_np(srad_round_up(e.cin, 4)); d.tKp = srad_cp(srad_round_up(e.n, 4));
       d.tdst_off = (long long)ts.t_off[i];
+      d.tfdst_off = ts.tf_off[i];
       const long long f = (long long)d.Np * d.ntaps * d.Cp, t = (long long)d.tRp * d.ntaps * d.tKp;
       work = f > t ? f : t;
     }

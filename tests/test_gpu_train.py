@@ -307,3 +307,39 @@ def test_bf16_training_fused_forward_matches_unfused(sr_golden, monkeypatch):
     cos = float((a * b).sum() / (a.norm() * b.norm()))
     print("fused vs unfused bf16 training: cosine of the gradients", cos)
     assert cos > 0.999
+
+
+@pytest.mark.parametrize("batch", [2, 8])
+def test_bf16_fused_mlp_backward_matches_unfused(sr_golden, monkeypatch, batch):
+    """bf16 mode: the MLP branch's backward as one kernel (both data gradients + LayerNorm2 backward, 16-row tiles
+    below 8192 tokens, 32-row tiles from there) against the three-launch chain, same forward, same DropPath masks."""
+    name = "drct_r2_rgb_x4"
+    cfg, sd, x, y = drct_case(sr_golden, name)
+    reps = batch // x.shape[0]
+    xt = torch.from_numpy(x).cuda().repeat(reps, 1, 1, 1)
+    hr = torch.from_numpy(sr_golden[name + "/hr"]).cuda().repeat(reps, 1, 1, 1)
+    hr = hr + torch.linspace(0, 20, batch, device="cuda").view(-1, 1, 1, 1)      # the copies see different gradients
+    gen = torch.Generator().manual_seed(5)
+    keep = (torch.floor(0.8 + torch.rand(2 * cfg.n_rdg * 5, batch, generator=gen)) / 0.8).cuda()
+    grads = {}
+    for mode in ("fused", "unfused"):
+        monkeypatch.delenv("SRAD_NO_FUSE", raising=False)
+        m = build_train(cfg, sd, "bf16", drop_path_rate=0.1)
+        m.keep_scale_override = keep
+        out = m(xt)
+        if mode == "unfused":
+            monkeypatch.setenv("SRAD_NO_FUSE", "1")       # read at backward time: only the backward changes
+        F.l1_loss(out, hr).backward()
+        torch.cuda.synchronize()
+        grads[mode] = m.flat_grads.clone()
+        named = {n: p.grad.clone() for n, p in m.named_parameters()}
+        grads[mode + "_named"] = named
+    monkeypatch.delenv("SRAD_NO_FUSE", raising=False)
+    a, b = grads["fused"].double(), grads["unfused"].double()
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    worst = 0.0
+    for n, g in grads["unfused_named"].items():
+        if "norm2" in n or "mlp.fc" in n:
+            worst = max(worst, float((grads["fused_named"][n] - g).norm() / g.norm().clamp_min(1e-30)))
+    print(f"fused vs unfused MLP backward (batch {batch}): cosine {cos:.7f}, worst relative L2 over norm2 / fc tensors {worst:.2e}")
+    assert cos > 0.9999 and worst < 2e-2
