@@ -62,6 +62,8 @@ _SIG = {
     "srad_l1_grad": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, _P]),
     "srad_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_int, C.c_float, _P]),
+    "srad_adam_step_dev": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
+    "srad_set4": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     # DRN
     "srad_drn_create": (C.c_int, [C.POINTER(DrnConfig), C.POINTER(_P)]),
     "srad_drn_destroy": (None, [_P]),

@@ -564,4 +564,19 @@ int srad_adam_step(float* params, const float* grads, float* exp_avg, float* exp
                           grad_scale, reinterpret_cast<hipStream_t>(stream));
 }
 
+
+/* the same step with [lr, 1 - beta1^t, sqrt(1 - beta2^t), grad_scale] in device memory (hipGraph replay of a training step) */
+int srad_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1,
+                       float beta2, float eps, float weight_decay, const float* dev_hyper, void* stream) {
+  SRAD_REQUIRE(params && grads && exp_avg && exp_avg_sq && dev_hyper && n > 0, "adam_step_dev: bad argument");
+  return srad_launch_adam_dev(params, grads, exp_avg, exp_avg_sq, (size_t)n, beta1, beta2, eps, weight_decay, dev_hyper,
+                              reinterpret_cast<hipStream_t>(stream));
+}
+
+/* dst[0..3] = (a, b, c, d) by value through a kernel: how the host hands Adam's per-step scalars to a replayed graph */
+int srad_set4(float* dst, float a, float b, float c, float d, void* stream) {
+  SRAD_REQUIRE(dst, "set4: null argument");
+  return srad_launch_set4(dst, a, b, c, d, reinterpret_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

@@ -45,7 +45,11 @@ constexpr int WG_TS = 64 * 64 + 64;          // floats per partial: the tile and
 constexpr int LNB_RPW = 16;                  // LayerNorm backward: rows per workgroup
 constexpr int LNB_CP = SRAD_LNB_CP;                  // columns of a dgamma | dbeta partial row (channel counts <= 320)
 
-template <int PREC, bool CONV>
+// FULL: Linear layers whose row splits are whole 128-row steps and whose DropPath factor is constant over a 32-row
+// wave step - no row / column / padding masks at all (columns past N / Cin read clamped real data into tile rows the
+// final store drops), the factor is one value per wave step: fewer registers (two waves per SIMD) and ~200 fewer
+// VALU instructions per step.
+template <int PREC, bool CONV, bool FULL = false>
 __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int ksplit, const int tn, const int tc,
                                            float* __restrict__ part, const int L) {
   extern __shared__ __attribute__((aligned(16))) float wsm[];     // [4 waves][64][68] + [4][64] bias + flag
@@ -86,9 +90,19 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int kspli
   // The next step's loads are issued before this step's MFMAs (two register sets).
   f32x4 av[1 + SRAD_WGRAD_PREFETCH][RL], bv[1 + SRAD_WGRAD_PREFETCH][RL];
   unsigned okm[2];                    // bit t: a row valid, bit 8 + t: b row valid
-  float rs[1 + SRAD_WGRAD_PREFETCH][RL];
+  float rs[1 + SRAD_WGRAD_PREFETCH][FULL ? 1 : RL];
   auto load_step = [&](int m0, auto set_c) {
     constexpr int set = decltype(set_c)::value;
+    if constexpr (FULL) {
+#pragma unroll
+      for (int t = 0; t < RL; ++t) {
+        const size_t mr = (size_t)(m0 + RL * fq + t);
+        av[set][t] = *reinterpret_cast<const f32x4*>(p.dY + mr * p.ldy + noff);
+        bv[set][t] = *reinterpret_cast<const f32x4*>(p.X + mr * p.ldx + coff);
+      }
+      rs[set][0] = p.row_scale ? p.row_scale[m0 / p.rps] : 1.f;
+      return;
+    }
     unsigned ok = 0u;
     [[maybe_unused]] int bb = 0, oy = 0, ox = 0;
     if constexpr (CONV) {                 // pixel of the lane's first row; the following rows step from it
@@ -126,8 +140,13 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int kspli
     f32x4 a[RL], b[RL];
 #pragma unroll
     for (int t = 0; t < RL; ++t) {
-      a[t] = ((okm[set] >> t) & 1u) ? av[set][t] * rs[set][t] : zero4;
-      b[t] = ((okm[set] >> (8 + t)) & 1u) ? bv[set][t] : zero4;
+      if constexpr (FULL) {
+        a[t] = av[set][t] * rs[set][0];
+        b[t] = bv[set][t];
+      } else {
+        a[t] = ((okm[set] >> t) & 1u) ? av[set][t] * rs[set][t] : zero4;
+        b[t] = ((okm[set] >> (8 + t)) & 1u) ? bv[set][t] : zero4;
+      }
       bsum += a[t];
     }
     if constexpr (PREC == SRAD_PREC_BF16) {
@@ -233,15 +252,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const i
 // Several Linear layers' weight gradients in ONE launch (the five of a Swin block): fewer launch ramps on the side
 // stream, and the layers' workgroups fill the chip together.  Each layer's block range starts at a multiple of 8 so
 // the XCD mapping of wgrad_body holds.
-template <int PREC>
-__global__ __launch_bounds__(256) void wgrad_multi_kernel(const WgradMulti mp) {
+template <int PREC, bool FULL>
+__global__ __launch_bounds__(256, FULL ? 2 : 1) void wgrad_multi_kernel(const WgradMulti mp) {
   int i = 0;
 #pragma unroll
   for (int k = 1; k < SRAD_WGRAD_MULTI; ++k)
     if (k < mp.count && (int)blockIdx.x >= mp.blk0[k]) i = k;
   const int L = blockIdx.x - mp.blk0[i];
   if (L >= mp.nblk[i]) return;                       // padding blocks between layers
-  wgrad_body<PREC, false>(mp.p[i], mp.ksplit[i], mp.tn[i], mp.tc[i], mp.part[i], L);
+  wgrad_body<PREC, false, FULL>(mp.p[i], mp.ksplit[i], mp.tn[i], mp.tc[i], mp.part[i], L);
 }
 
 // One workgroup per QUARTER of a 64 x 64 output tile of one of the batch's layers (16 rows n, one float4 per
@@ -957,8 +976,9 @@ __global__ void l1_grad_kernel(const float* __restrict__ a, const float* __restr
 }
 
 // torch.optim.Adam single-tensor arithmetic (torch/optim/adam.py _single_tensor_adam, amsgrad off, maximize off)
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            size_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gs) {
+__device__ __forceinline__ void adam_body(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                          float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
+                                          float bc1, float bc2_sqrt, float gs) {
   const float step_size = lr / bc1;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float grad = g[i] * gs;
@@ -970,6 +990,16 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] = w - step_size * (mi / denom);
   }
+}
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            size_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gs) {
+  adam_body(p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gs);
+}
+// the same step with the per-step scalars [lr, 1 - beta1^t, sqrt(1 - beta2^t), grad_scale] read from device memory, so
+// that a captured hipGraph of a whole training step can be replayed with a new step count / learning rate
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                size_t n, float b1, float b2, float eps, float wd, const float* __restrict__ hyper) {
+  adam_body(p, g, m, v, n, hyper[0], b1, b2, eps, wd, hyper[1], hyper[2], hyper[3]);
 }
 
 }  // namespace
@@ -1006,7 +1036,14 @@ int srad_wgrad_launch_deferred(int prec, WgradQueue& q, hipStream_t stream) {
       hipLaunchKernelGGL(kern, dim3(total), dim3(256), WG_LDS, stream, m);
       return SRAD_OK;
     };
-    const int rc = prec == SRAD_PREC_BF16 ? launch(wgrad_multi_kernel<SRAD_PREC_BF16>) : launch(wgrad_multi_kernel<SRAD_PREC_F32>);
+    bool full = prec == SRAD_PREC_BF16;            // every layer: whole 128-row steps, DropPath factor constant per wave step
+    for (int i = 0; i < m.count && full; ++i) {
+      const long rows_per = ((m.p[i].M + m.ksplit[i] - 1) / m.ksplit[i] + 127) / 128 * 128;
+      full = rows_per * m.ksplit[i] == m.p[i].M && (!m.p[i].row_scale || m.p[i].rps % 32 == 0);
+    }
+    const int rc = prec != SRAD_PREC_BF16 ? launch(wgrad_multi_kernel<SRAD_PREC_F32, false>)
+                   : full                 ? launch(wgrad_multi_kernel<SRAD_PREC_BF16, true>)
+                                          : launch(wgrad_multi_kernel<SRAD_PREC_BF16, false>);
     if (rc) return rc;
     SRAD_CHECK_HIP(hipGetLastError());
   }
@@ -1151,6 +1188,26 @@ int srad_launch_adam(float* p, const float* g, float* m, float* v, size_t n, flo
   SradProfScope prof(stream, SRAD_K_OPTIM, 12.0 * n, 28.0 * n);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps,
                      weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}
+
+int srad_launch_adam_dev(float* p, const float* g, float* m, float* v, size_t n, float beta1, float beta2, float eps,
+                         float weight_decay, const float* hyper, hipStream_t stream) {
+  SradProfScope prof(stream, SRAD_K_OPTIM, 12.0 * n, 28.0 * n);
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, m, v, n, beta1, beta2, eps, weight_decay, hyper);
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}
+
+
+namespace {
+__global__ void set4_kernel(float* __restrict__ dst, float a, float b, float c, float d) {
+  if (threadIdx.x == 0) { dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d; }
+}
+}  // namespace
+int srad_launch_set4(float* dst, float a, float b, float c, float d, hipStream_t stream) {
+  hipLaunchKernelGGL(set4_kernel, dim3(1), dim3(64), 0, stream, dst, a, b, c, d);
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
 }

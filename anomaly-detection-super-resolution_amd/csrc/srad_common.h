@@ -312,6 +312,9 @@ int srad_launch_l1_grad(const float* a, const float* b, float* out, size_t n, fl
 // torch.optim.Adam (L2-style weight decay) on flat fp32 buffers; grad_scale multiplies the gradient first
 int srad_launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int step, float grad_scale, hipStream_t stream);
+int srad_launch_set4(float* dst, float a, float b, float c, float d, hipStream_t stream);
+int srad_launch_adam_dev(float* p, const float* g, float* m, float* v, size_t n, float beta1, float beta2, float eps,
+                         float weight_decay, const float* hyper, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------
 // misc kernels

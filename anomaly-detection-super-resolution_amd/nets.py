@@ -421,7 +421,9 @@ class DRCT(_EngineModule):
         wp, wb = self._train_workspace(B, H, W, dev)
         keep = self.keep_scale_override
         if keep is None and self.drop_path_rate > 0:
-            kp = self.drop_path_keep_probs().to(dev).repeat_interleave(2)[:, None]        # [2 * blocks, 1]
+            kp = getattr(self, "_kp_dev", None)                                           # [2 * blocks, 1], cached per device
+            if kp is None or kp.device != dev:                                            # (no host copy per step: graph-capturable)
+                kp = self._kp_dev = self.drop_path_keep_probs().to(dev).repeat_interleave(2)[:, None].contiguous()
             keep = torch.floor(kp + torch.rand(kp.shape[0], B, device=dev)) / kp         # drct.py:107-119
         self._keep = None if keep is None else keep.to(device=dev, dtype=torch.float32).contiguous()
         s = self.upscale

@@ -10,7 +10,8 @@ of the earlier layers is still running.  With the ``nccl`` backend that is RCCL 
 from __future__ import annotations
 
 import math
-from typing import Optional
+import struct
+from typing import List, Optional
 
 import torch
 
@@ -42,6 +43,22 @@ class FusedAdam:
                                        L.dptr(self.exp_avg_sq), m.flat_params.numel(), lr, self.betas[0], self.betas[1],
                                        self.eps, self.weight_decay, self.step_count, grad_scale,
                                        L.current_stream_ptr()), "adam_step")
+        m.mark_params_dirty()
+
+    def hyper(self, grad_scale: float = 1.0) -> List[float]:
+        """[lr, 1 - beta1^t, sqrt(1 - beta2^t), grad_scale] of the NEXT step (``srad_adam_step_dev``)."""
+        t = self.step_count + 1
+        b1, b2 = (struct.unpack("f", struct.pack("f", b))[0] for b in self.betas)     # the betas as the C ABI sees them (fp32)
+        return [float(self.param_groups[0]["lr"]), 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t), float(grad_scale)]
+
+    def step_dev(self, dev_hyper: torch.Tensor) -> None:
+        """``step()`` with the per-step scalars read from ``dev_hyper`` (4 floats on the GPU, see ``hyper()``): the launch
+        carries no step-dependent argument, so it can sit inside a captured hipGraph.  The caller bumps ``step_count``."""
+        m = self.model
+        L.check(L.lib().srad_adam_step_dev(L.dptr(m.flat_params), L.dptr(m.flat_grads), L.dptr(self.exp_avg),
+                                           L.dptr(self.exp_avg_sq), m.flat_params.numel(), self.betas[0], self.betas[1],
+                                           self.eps, self.weight_decay, L.dptr(dev_hyper), L.current_stream_ptr()),
+                "adam_step_dev")
         m.mark_params_dirty()
 
     def state_dict(self):
@@ -132,6 +149,61 @@ def train_step(model, lr_img: torch.Tensor, hr_img: torch.Tensor, optimizer: Fus
         reducer.finish()
     optimizer.step(grad_scale=reducer.grad_scale if reducer is not None else 1.0)
     return loss
+
+
+class GraphedTrainStep:
+    """``train_step`` for one GPU as ONE hipGraph: the ~700 launches of a DRCT training step (re-pack, zero_grad, forward,
+    L1, the two-stream backward, Adam) are captured once per batch shape and replayed, which removes the 3-5 us
+    dispatch gap between dependent launches.  Per step only the two input copies, a 16-byte copy of Adam's scalars
+    (``FusedAdam.hyper``) and the graph launch are issued.  DropPath masks come from ``torch.rand`` inside the capture
+    (PyTorch's graph-safe generator advances the Philox offset per replay).  With a ``GradReducer`` (world > 1) the
+    bucket hooks launch collectives from the host in the middle of the backward, so ``train_step`` runs eagerly."""
+
+    def __init__(self, model, optimizer: FusedAdam, warmup: int = 2):
+        self.model, self.optimizer, self.warmup = model, optimizer, int(warmup)
+        self._graphs = {}          # (lr shape, hr shape) -> (graph, static lr, static hr, loss, hyper)
+        self._eager_calls = {}
+
+    def _body(self, lr_img, hr_img, hyper):
+        from . import metrics as M
+        m, opt = self.model, self.optimizer
+        opt.zero_grad()
+        sr = m._forward_train(lr_img)
+        loss = M.l1_loss(sr, hr_img)
+        dy = torch.empty_like(sr)
+        L.check(L.lib().srad_l1_grad(L.dptr(sr), L.dptr(hr_img), L.dptr(dy), sr.numel(), 1.0 / sr.numel(),
+                                     L.current_stream_ptr()), "l1_grad")
+        m._backward(dy, need_dx=False)
+        opt.step_dev(hyper)
+        return loss
+
+    def __call__(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> torch.Tensor:
+        m, opt = self.model, self.optimizer
+        key = (tuple(lr_img.shape), tuple(hr_img.shape))
+        entry = self._graphs.get(key)
+        if entry is None:
+            n = self._eager_calls.get(key, 0)
+            if n < self.warmup or m.on_bucket is not None or m.keep_scale_override is not None:
+                self._eager_calls[key] = n + 1          # allocates workspaces, configures kernels, creates the side stream
+                return train_step(m, lr_img, hr_img, opt)
+            s_lr, s_hr = lr_img.detach().float().contiguous().clone(), hr_img.detach().float().contiguous().clone()
+            hyper = torch.zeros(4, dtype=torch.float32, device=lr_img.device)
+            m.mark_params_dirty()                      # the capture starts with the re-pack of the parameters
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                loss = self._body(s_lr, s_hr, hyper)
+            entry = (g, s_lr, s_hr, loss, hyper)
+            self._graphs[key] = entry
+        g, s_lr, s_hr, loss, hyper = entry
+        s_lr.copy_(lr_img, non_blocking=True)
+        s_hr.copy_(hr_img, non_blocking=True)
+        h = opt.hyper()                                # by value through a one-thread kernel: no host copy, no sync
+        L.check(L.lib().srad_set4(L.dptr(hyper), h[0], h[1], h[2], h[3], L.current_stream_ptr()), "set4")
+        g.replay()
+        opt.step_count += 1
+        m.mark_params_dirty()                          # the replayed Adam changed the flat parameters
+        return loss.clone()                            # the graph's own output buffer is overwritten by the next replay
 
 
 def drn_loss(sr, lr_list, hr, sr2lr, dual_weight: float = 0.1) -> torch.Tensor:

@@ -132,17 +132,28 @@ def train_leg(args, torch, dist, dev, world, rank):
     g = torch.Generator(device="cpu").manual_seed(100 + rank)
     lr_img = (torch.rand(B, 1, 32, 32, generator=g) * 255.0).to(dev)
     hr_img = (torch.rand(B, 1, 128, 128, generator=g) * 255.0).to(dev)
-    steps, warm = args.train_steps, 2
+    steps, warm = args.train_steps, 3
+    graphed = world == 1 and not args.no_train_graph
+    if graphed:       # one GPU: the whole step is one replayed hipGraph (two eager steps, then the capture)
+        from srad_amd.train import GraphedTrainStep
+        gstep = GraphedTrainStep(m, opt, warmup=2)
+        step_fn = lambda: gstep(lr_img, hr_img)
+    else:             # data parallel: the bucket hooks launch RCCL all-reduces from the host during the backward
+        step_fn = lambda: train_step(m, lr_img, hr_img, opt, red)
     losses = []
     for _ in range(warm):
-        losses.append(train_step(m, lr_img, hr_img, opt, red))
+        losses.append(step_fn())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        losses.append(train_step(m, lr_img, hr_img, opt, red))
+    host_first = 0.0
+    for i in range(steps):
+        losses.append(step_fn())
+        if i == 0:
+            host_first = time.perf_counter() - t0   # enqueue time of one step into an empty queue
+    host_el = time.perf_counter() - t0            # the host has enqueued every step (it never waits for the GPU)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -153,6 +164,8 @@ def train_leg(args, torch, dist, dev, world, rank):
         el = float(t.item())
     out = {"workload": f"C4: DRCT-L x4 train step, 128px HR, {B} images per GPU (global batch {B * world}), L1 + Adam, DropPath 0.1",
            "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
+           "launch": "one hipGraph replay per step" if graphed else "eager (two streams)",
+           "host_enqueue_ms_per_step": round(host_el / steps * 1e3, 3), "host_enqueue_ms_first_step": round(host_first * 1e3, 3),
            "hr_mpixels_per_s": round(world * B * 128 * 128 * steps / el / 1e6, 3),
            "images_per_s": round(world * B * steps / el, 2),
            "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)],
@@ -261,6 +274,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-eval", action="store_true", help="skip the anomaly-eval images/s leg")
     ap.add_argument("--no-train", action="store_true", help="skip the C4 training-step leg")
+    ap.add_argument("--no-train-graph", action="store_true", help="C4 leg: eager launches instead of one hipGraph per step")
     ap.add_argument("--train-batch", type=int, default=8)
     ap.add_argument("--train-steps", type=int, default=10)
     args = ap.parse_args()

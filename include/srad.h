@@ -100,6 +100,12 @@ int srad_l1_grad(const float* a, const float* b, float* out, int64_t n, float sc
  * grad_scale multiplies the gradient first (1/world_size after a summing all-reduce) */
 int srad_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* the same step with the per-step scalars in device memory: dev_hyper = [lr, 1 - beta1^step, sqrt(1 - beta2^step),
+ * grad_scale] (4 floats), so a hipGraph capturing a whole training step can be replayed for every step */
+int srad_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1,
+                       float beta2, float eps, float weight_decay, const float* dev_hyper, void* stream);
+/* dst[0..3] = (a, b, c, d), passed by value through a kernel launch (no host copy, no synchronisation) */
+int srad_set4(float* dst, float a, float b, float c, float d, void* stream);
 
 /* ------------------------------------------------------------------ DRN-L (src/drn.py:160-270) */
 typedef struct srad_drn srad_drn_t;

@@ -343,3 +343,53 @@ def test_bf16_fused_mlp_backward_matches_unfused(sr_golden, monkeypatch, batch):
             worst = max(worst, float((grads["fused_named"][n] - g).norm() / g.norm().clamp_min(1e-30)))
     print(f"fused vs unfused MLP backward (batch {batch}): cosine {cos:.7f}, worst relative L2 over norm2 / fc tensors {worst:.2e}")
     assert cos > 0.9999 and worst < 2e-2
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_graphed_train_step_matches_eager(sr_golden, prec):
+    """The whole training step as one replayed hipGraph (two eager warm-up steps, then capture + replays) walks the
+    same parameter trajectory as the eager ``train_step``: same kernels, same fixed-order reductions -> same bits;
+    Adam's step count / learning rate reach the replays through device memory."""
+    from srad_amd.train import FusedAdam, GraphedTrainStep, train_step
+    name = "drct_r2_rgb_x4"
+    cfg, sd, x, y = drct_case(sr_golden, name)
+    xt = torch.from_numpy(x).cuda()
+    hr = torch.from_numpy(sr_golden[name + "/hr"]).cuda()
+    runs = {}
+    for mode in ("eager", "graph"):
+        m = build_train(cfg, sd, prec)
+        opt = FusedAdam(m, lr=1e-3)
+        step = GraphedTrainStep(m, opt, warmup=2) if mode == "graph" else (lambda a, b: train_step(m, a, b, opt))
+        losses = []
+        for i in range(6):
+            if i == 4:
+                opt.param_groups[0]["lr"] = 5e-4                   # a scheduler step between replays
+            losses.append(step(xt + i, hr))                        # inputs change per step too
+        torch.cuda.synchronize()
+        runs[mode] = (torch.stack([l.double() for l in losses]).cpu(), m.flat_params.clone(), opt.step_count)
+        if mode == "graph":
+            assert len(step._graphs) == 1
+    assert runs["graph"][2] == runs["eager"][2] == 6
+    assert torch.equal(runs["graph"][0], runs["eager"][0]), (runs["graph"][0], runs["eager"][0])
+    assert torch.equal(runs["graph"][1], runs["eager"][1])
+
+
+def test_graphed_train_step_draws_new_droppath_masks(sr_golden):
+    """DropPath inside the captured step: every replay draws new per-sample masks (graph-safe Philox offset)."""
+    from srad_amd.train import FusedAdam, GraphedTrainStep
+    name = "drct_r2_rgb_x4"
+    cfg, sd, x, y = drct_case(sr_golden, name)
+    xt = torch.from_numpy(x).cuda().repeat(4, 1, 1, 1)
+    hr = torch.from_numpy(sr_golden[name + "/hr"]).cuda().repeat(4, 1, 1, 1)
+    m = build_train(cfg, sd, "bf16", drop_path_rate=0.5)
+    opt = FusedAdam(m, lr=0.0)                                     # parameters stay put: only the masks change the loss
+    step = GraphedTrainStep(m, opt, warmup=1)
+    masks, losses = [], []
+    for i in range(5):
+        losses.append(float(step(xt, hr)))
+        masks.append(m._keep.clone())
+    assert len(step._graphs) == 1
+    assert len({tuple(k.flatten().tolist()) for k in masks[1:]}) >= 3          # replays 2..5: different masks
+    assert len(set(losses[1:])) >= 3
+    for k in masks:                                                # floor(keep + U) / keep: 0 or 1 / keep_prob of the RDG
+        assert bool(((k == 0) | (k >= 1.0)).all()) and bool((k[:10] == 1.0).all())      # RDG 0: rate 0 (drct.py:819)
