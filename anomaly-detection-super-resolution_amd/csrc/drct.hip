@@ -239,6 +239,7 @@ int srad_drct_create(const srad_drct_config* cfg, srad_drct_t** out) {
       sw.n1b = h->pt.add_raw(p + "norm1.bias", sw.d);
       sw.table = h->pt.add_raw(p + "attn.relative_position_bias_table", (int64_t)(2 * ws - 1) * (2 * ws - 1) * sw.heads);
       sw.qkv = h->pt.add_layer(p + "attn.qkv", 3 * sw.d, sw.d, 1, true);
+      if (cfg->precision == SRAD_PREC_BF16) h->pt.entries[sw.qkv.w].tfrag = true;   // operand of the fused qkv + LayerNorm1 backward
       const bool frag = cfg->precision == SRAD_PREC_BF16;      // operands of the fused second half (kernels_fused.hip)
       sw.proj = frag ? h->pt.add_layer_frag(p + "attn.proj", sw.d, sw.d, true) : h->pt.add_layer(p + "attn.proj", sw.d, sw.d, 1, true);
       sw.n2g = h->pt.add_raw(p + "norm2.weight", sw.d);

@@ -499,16 +499,28 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       {
         WgradParams g = wgrad_of(h, sw.qkv, G, dqkv, 3 * d, 0, sv.xn1, d, T);
         SRAD_TRY(srad_launch_wgrad_deferred(prec, g, wq, side));
-        GemmParams p = dgrad_gemm(h, sw.qkv, dqkv, 3 * d, T, w.dxn, d);
-        SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
-      {  // gc[:, :d] += dx1 + dLN1(dxn)
-        LnBwdParams l{};
-        l.dxn = w.dxn; l.ld_dxn = d; l.x = cur; l.ldx = D; l.gamma = h->pt.fptr(sw.n1g);
-        l.dres = dx1; l.ld_dres = d; l.out = gc; l.ld_out = D; l.accumulate = 1;
-        l.dgamma = G + h->ts.flat_off[sw.n1g]; l.dbeta = G + h->ts.flat_off[sw.n1b];
-        l.rows = T; l.C = d; l.eps = 1e-5f;
-        SRAD_TRY(srad_launch_ln_bwd(l, wq, s));
+      if (fused_bwd && h->ts.tf_off[sw.qkv.w] >= 0 && srad_lin_ln_bwd_supported(prec, T, 3 * d, d)) {
+        // gc[:, :d] += dx1 + dLN1(dqkv . Wqkv): data gradient + LayerNorm1 backward in one launch (kernels_fused_bwd.hip)
+        LinLnBwdParams lb{};
+        lb.M = T; lb.K = 3 * d; lb.d = d; lb.dY = dqkv; lb.ld_dy = 3 * d; lb.w_t = h->ts.tarena + h->ts.tf_off[sw.qkv.w];
+        lb.x = cur; lb.ldx = D; lb.ln_g = h->pt.fptr(sw.n1g); lb.dres = dx1; lb.ld_dres = d;
+        lb.out = gc; lb.ld_out = D; lb.accumulate = 1;
+        lb.dgamma = G + h->ts.flat_off[sw.n1g]; lb.dbeta = G + h->ts.flat_off[sw.n1b];
+        SRAD_TRY(srad_launch_lin_ln_bwd(lb, wq, s));
+      } else {
+        {
+          GemmParams p = dgrad_gemm(h, sw.qkv, dqkv, 3 * d, T, w.dxn, d);
+          SRAD_TRY(srad_launch_gemm(prec, p, s));
+        }
+        {  // gc[:, :d] += dx1 + dLN1(dxn)
+          LnBwdParams l{};
+          l.dxn = w.dxn; l.ld_dxn = d; l.x = cur; l.ldx = D; l.gamma = h->pt.fptr(sw.n1g);
+          l.dres = dx1; l.ld_dres = d; l.out = gc; l.ld_out = D; l.accumulate = 1;
+          l.dgamma = G + h->ts.flat_off[sw.n1g]; l.dbeta = G + h->ts.flat_off[sw.n1b];
+          l.rows = T; l.C = d; l.eps = 1e-5f;
+          SRAD_TRY(srad_launch_ln_bwd(l, wq, s));
+        }
       }
       // this block's five weight gradients as ONE launch on the side stream (all their operands exist now), then
       // the reduce of their partials and of the LayerNorm / bias-table column sums the caller's stream has written

@@ -14,6 +14,7 @@ struct ParamEntry {
   int n, cin, ntaps; // packed geometry (real sizes of the source tensor)
   int n_pad = 0, grp_real = 0, grp_pad = 0;   // optional padding (srad_launch_pack_weight_padded)
   long long frag_off = -1;                    // >= 0: second copy as bf16 MFMA fragments (srad_launch_pack_weight_frag)
+  bool tfrag = false;                         // training: keep W^T as bf16 MFMA fragments too (fused backward kernels)
 };
 
 struct ConvW {       // one Linear / conv layer

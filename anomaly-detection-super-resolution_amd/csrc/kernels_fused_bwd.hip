@@ -38,6 +38,114 @@ __device__ __forceinline__ float dgelu_fast(float x) {
   return 0.5f * (1.0f + (x < 0.f ? -erfa : erfa)) + x * 0.39894228040143267794f * ex;
 }
 
+// LayerNorm backward over the d real columns of FM token rows held in the transposed-result layout (lane: token row
+// 16 rt + fr, columns 128 g + 16 wave + 4 fq + 0..3): dxn = gradient of the LayerNorm output, xv = its input rows,
+// r2 = what is added to the result (residual path, previous content).  out rows = out0 + row * ld_out; the workgroup's
+// dgamma | dbeta column sums go to prow.  Statistics exactly as the forward / unfused kernels (two-pass variance).
+template <int NRT, int GD>
+__device__ __forceinline__ void ln_bwd_tail(f32x4 (&dxn)[GD][NRT], f32x4 (&xv)[GD][NRT], const f32x4 (&r2)[GD][NRT],
+                                            const float* v_g, float* red, int d, int wave, int fr, int fq, float* out0,
+                                            int ld_out, float* prow) {
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto col4_of = [&](int g) { return FB_SC * g + 16 * wave + 4 * fq; };
+  const float invC = 1.0f / (float)d;
+  auto row_reduce2 = [&](float (&a)[NRT], float (&b)[NRT]) {     // sums over the whole row: 4 fq groups x 8 waves
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+      a[rt] += __shfl_xor(a[rt], 16); b[rt] += __shfl_xor(b[rt], 16);
+      a[rt] += __shfl_xor(a[rt], 32); b[rt] += __shfl_xor(b[rt], 32);
+      if (fq == 0) {
+        red[((rt * 16 + fr) * 8 + wave) * 2 + 0] = a[rt];
+        red[((rt * 16 + fr) * 8 + wave) * 2 + 1] = b[rt];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+      const float* r = red + (rt * 16 + fr) * 16;
+      float su = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { su += r[2 * w]; s2 += r[2 * w + 1]; }
+      a[rt] = su; b[rt] = s2;
+    }
+  };
+  float sm[NRT], sq[NRT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) { sm[rt] = 0.f; sq[rt] = 0.f; }
+#pragma unroll
+  for (int g = 0; g < GD; ++g) {
+    const bool in = col4_of(g) < d;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+      xv[g][rt] = in ? xv[g][rt] : z4;
+      sm[rt] += (xv[g][rt][0] + xv[g][rt][1]) + (xv[g][rt][2] + xv[g][rt][3]);
+    }
+  }
+  row_reduce2(sm, sq);
+  float mu[NRT], rstd[NRT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) { mu[rt] = sm[rt] * invC; sq[rt] = 0.f; sm[rt] = 0.f; }
+#pragma unroll
+  for (int g = 0; g < GD; ++g) {
+    const bool in = col4_of(g) < d;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+      xv[g][rt] = in ? xv[g][rt] - mu[rt] : z4;
+      sq[rt] += (xv[g][rt][0] * xv[g][rt][0] + xv[g][rt][1] * xv[g][rt][1]) + (xv[g][rt][2] * xv[g][rt][2] + xv[g][rt][3] * xv[g][rt][3]);
+    }
+  }
+  __syncthreads();                                               // everyone has read the first sums
+  row_reduce2(sq, sm);
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) rstd[rt] = rsqrtf(sq[rt] * invC + 1e-5f);
+  float s1[NRT], s2[NRT];
+  f32x4 dg[GD], db[GD];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) { s1[rt] = 0.f; s2[rt] = 0.f; }
+#pragma unroll
+  for (int g = 0; g < GD; ++g) {
+    const int c4 = col4_of(g);
+    const bool in = c4 < d;
+    const f32x4 gam = *reinterpret_cast<const f32x4*>(v_g + min(c4, 380));
+    dg[g] = z4; db[g] = z4;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+      const f32x4 dy = in ? dxn[g][rt] : z4;
+      xv[g][rt] = xv[g][rt] * rstd[rt];                          // xhat
+      dg[g] += dy * xv[g][rt];
+      db[g] += dy;
+      dxn[g][rt] = dy * gam;                                     // gy
+      const f32x4 t = dxn[g][rt] * xv[g][rt];
+      s1[rt] += (dxn[g][rt][0] + dxn[g][rt][1]) + (dxn[g][rt][2] + dxn[g][rt][3]);
+      s2[rt] += (t[0] + t[1]) + (t[2] + t[3]);
+    }
+  }
+  __syncthreads();
+  row_reduce2(s1, s2);
+#pragma unroll
+  for (int g = 0; g < GD; ++g) {
+    const int c4 = col4_of(g);
+    if (c4 < d) {
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) {
+        const f32x4 o4 = (dxn[g][rt] - s1[rt] * invC - xv[g][rt] * (s2[rt] * invC)) * rstd[rt] + r2[g][rt];
+        *reinterpret_cast<f32x4*>(out0 + (size_t)(rt * 16 + fr) * ld_out + c4) = o4;
+      }
+    }
+  }
+  // dgamma / dbeta of this workgroup's rows: sum over the 16 token rows of the lane group, one partial row per workgroup
+#pragma unroll
+  for (int g = 0; g < GD; ++g) {
+    const int c4 = col4_of(g);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dg[g][e] = srad_row16_sum(dg[g][e]); db[g][e] = srad_row16_sum(db[g][e]); }
+    if (fr == 0 && c4 < d) {
+      *reinterpret_cast<f32x4*>(prow + c4) = dg[g];
+      *reinterpret_cast<f32x4*>(prow + SRAD_LNB_CP + c4) = db[g];
+    }
+  }
+}
+
 // GD / GM = 128-column groups of the block dim / hidden, KGD / KGM = 256-wide k groups of the block dim / hidden
 template <int FM, int GD, int KGD, int GM, int KGM>
 __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, float* __restrict__ part) {
@@ -176,105 +284,141 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
     }
   });
 
-  // ---- LayerNorm2 backward over the d real columns (lane: token row 16 rt + fr, columns col4_of(g) + 0..3) ----
-  const float invC = 1.0f / (float)d;
-  auto row_reduce2 = [&](float (&a)[NRT], float (&b)[NRT]) {     // sums over the whole row: 4 fq groups x 8 waves
-#pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) {
-      a[rt] += __shfl_xor(a[rt], 16); b[rt] += __shfl_xor(b[rt], 16);
-      a[rt] += __shfl_xor(a[rt], 32); b[rt] += __shfl_xor(b[rt], 32);
-      if (fq == 0) {
-        red[((rt * 16 + fr) * 8 + wave) * 2 + 0] = a[rt];
-        red[((rt * 16 + fr) * 8 + wave) * 2 + 1] = b[rt];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) {
-      const float* r = red + (rt * 16 + fr) * 16;
-      float su = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) { su += r[2 * w]; s2 += r[2 * w + 1]; }
-      a[rt] = su; b[rt] = s2;
-    }
-  };
-  float sm[NRT], sq[NRT];
-#pragma unroll
-  for (int rt = 0; rt < NRT; ++rt) { sm[rt] = 0.f; sq[rt] = 0.f; }
-#pragma unroll
-  for (int g = 0; g < GD; ++g) {
-    const bool in = col4_of(g) < d;
-#pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) {
-      xv[g][rt] = in ? xv[g][rt] : z4;
-      sm[rt] += (xv[g][rt][0] + xv[g][rt][1]) + (xv[g][rt][2] + xv[g][rt][3]);
-    }
-  }
-  row_reduce2(sm, sq);
-  float mu[NRT], rstd[NRT];
-#pragma unroll
-  for (int rt = 0; rt < NRT; ++rt) { mu[rt] = sm[rt] * invC; sq[rt] = 0.f; sm[rt] = 0.f; }
-#pragma unroll
-  for (int g = 0; g < GD; ++g) {
-    const bool in = col4_of(g) < d;
-#pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) {
-      xv[g][rt] = in ? xv[g][rt] - mu[rt] : z4;                  // centred, as the forward / unfused kernels compute it
-      sq[rt] += (xv[g][rt][0] * xv[g][rt][0] + xv[g][rt][1] * xv[g][rt][1]) + (xv[g][rt][2] * xv[g][rt][2] + xv[g][rt][3] * xv[g][rt][3]);
-    }
-  }
-  __syncthreads();                                               // everyone has read the first sums
-  row_reduce2(sq, sm);
-#pragma unroll
-  for (int rt = 0; rt < NRT; ++rt) rstd[rt] = rsqrtf(sq[rt] * invC + 1e-5f);
-  float s1[NRT], s2[NRT];
-  f32x4 dg[GD], db[GD];
-#pragma unroll
-  for (int rt = 0; rt < NRT; ++rt) { s1[rt] = 0.f; s2[rt] = 0.f; }
-#pragma unroll
-  for (int g = 0; g < GD; ++g) {
-    const int c4 = col4_of(g);
-    const bool in = c4 < d;
-    const f32x4 gam = *reinterpret_cast<const f32x4*>(v_g + min(c4, 380));
-    dg[g] = z4; db[g] = z4;
-#pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) {
-      const f32x4 dy = in ? dxn[g][rt] : z4;
-      xv[g][rt] = xv[g][rt] * rstd[rt];                          // xhat
-      dg[g] += dy * xv[g][rt];
-      db[g] += dy;
-      dxn[g][rt] = dy * gam;                                     // gy
-      const f32x4 t = dxn[g][rt] * xv[g][rt];
-      s1[rt] += (dxn[g][rt][0] + dxn[g][rt][1]) + (dxn[g][rt][2] + dxn[g][rt][3]);
-      s2[rt] += (t[0] + t[1]) + (t[2] + t[3]);
-    }
-  }
-  __syncthreads();
-  row_reduce2(s1, s2);
-#pragma unroll
-  for (int g = 0; g < GD; ++g) {
-    const int c4 = col4_of(g);
-    if (c4 < d) {
-#pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) {
-        const f32x4 o4 = (dxn[g][rt] - s1[rt] * invC - xv[g][rt] * (s2[rt] * invC)) * rstd[rt] + r2[g][rt];
-        *reinterpret_cast<f32x4*>(p.dx1 + (size_t)(m0 + rt * 16 + fr) * d + c4) = o4;
-      }
-    }
-  }
-  // dgamma / dbeta of this workgroup's rows: sum over the 16 token rows of the lane group, one partial row per workgroup
-  float* prow = part + (size_t)blockIdx.x * (2 * SRAD_LNB_CP);
-#pragma unroll
-  for (int g = 0; g < GD; ++g) {
-    const int c4 = col4_of(g);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { dg[g][e] = srad_row16_sum(dg[g][e]); db[g][e] = srad_row16_sum(db[g][e]); }
-    if (fr == 0 && c4 < d) {
-      *reinterpret_cast<f32x4*>(prow + c4) = dg[g];
-      *reinterpret_cast<f32x4*>(prow + SRAD_LNB_CP + c4) = db[g];
-    }
-  }
+  ln_bwd_tail<NRT, GD>(dxn, xv, r2, v_g, red, d, wave, fr, fq, p.dx1 + (size_t)m0 * d, d, part + (size_t)blockIdx.x * (2 * SRAD_LNB_CP));
 }
+
+// ------------------------------------------------------------------------------------------
+// dX = dY . W (K up to 4 x 256) + LayerNorm backward + residual: the qkv Linear / LayerNorm1 end of a Swin block.
+// GD = 128-column groups of d, KG = 256-wide k groups of K.
+// ------------------------------------------------------------------------------------------
+template <int FM, int GD, int KG>
+__global__ __launch_bounds__(512) void lin_ln_bwd_kernel(const LinLnBwdParams p, float* __restrict__ part) {
+  constexpr int NRT = FM / 16;
+  constexpr int LDA = KG * 256 + 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* A1 = reinterpret_cast<__bf16*>(smem);                  // [FM][LDA] dY
+  float* v_g = reinterpret_cast<float*>(A1 + FM * LDA);          // [384] gamma
+  float* red = v_g + 384;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int m0 = blockIdx.x * FM;
+  const int d = p.d, K = p.K;
+  const int Kp = (K + 31) & ~31;
+  constexpr int n_stages = GD * KG;
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int NSETS = 3;
+  u32x4 w_reg[NSETS][8];
+  auto load_w = [&](int s, u32x4 (&reg)[8]) {
+    s = min(s, n_stages - 1);
+    const int g = s / KG, kg = s - g * KG;
+    const int nch = min(8, (Kp >> 5) - kg * 8);
+    const char* base = (const char*)p.w_t + ((size_t)(g * 8 + wave) * (Kp >> 5) + kg * 8) * 1024 + fr * 64 + fq * 16;
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + (cc < nch ? cc : 0) * 1024);
+  };
+  auto col4_of = [&](int g) { return FB_SC * g + 16 * wave + 4 * fq; };
+#pragma unroll
+  for (int q = 0; q < NSETS; ++q) load_w(q, w_reg[q]);
+  const float gq = tid < 384 ? p.ln_g[min(tid, d - 1)] : 0.f;
+  f32x4 r2[GD][NRT], xv[GD][NRT];
+#pragma unroll
+  for (int g = 0; g < GD; ++g) {
+    const int c4 = min(col4_of(g), d - 4);
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+      const size_t row = (size_t)(m0 + rt * 16 + fr);
+      r2[g][rt] = p.dres ? *reinterpret_cast<const f32x4*>(p.dres + row * p.ld_dres + c4) : z4;
+      if (p.accumulate) r2[g][rt] += *reinterpret_cast<const f32x4*>(p.out + row * p.ld_out + c4);
+      xv[g][rt] = *reinterpret_cast<const f32x4*>(p.x + row * p.ldx + c4);
+    }
+  }
+  // dY tile -> bf16 -> A1 (zero beyond K): KQ float4 per row, eight loads in flight per thread
+  {
+    const int KQ = KG * 64;
+    const int total = FM * KQ;
+    for (int i0 = tid; i0 < total; i0 += 512 * 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = min(i0 + 512 * u, total - 1), row = idx / KQ, c = (idx - row * KQ) * 4;
+        v[u] = *reinterpret_cast<const f32x4*>(p.dY + (size_t)(m0 + row) * p.ld_dy + min(c, K - 4));
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = i0 + 512 * u;
+        if (idx < total) {
+          const int row = idx / KQ, c = (idx - row * KQ) * 4;
+          const f32x4 w = c < K ? v[u] : z4;
+          bf16x4 h;
+          h[0] = (__bf16)w[0]; h[1] = (__bf16)w[1]; h[2] = (__bf16)w[2]; h[3] = (__bf16)w[3];
+          *reinterpret_cast<bf16x4*>(A1 + row * LDA + c) = h;
+        }
+      }
+    }
+  }
+  if (tid < 384) v_g[tid] = gq;
+  __syncthreads();
+
+  f32x4 dxn[GD][NRT];
+  f32x4 c[NRT];
+  static_for<0, n_stages>([&](auto S) {
+    constexpr int s = decltype(S)::value;
+    constexpr int g = s / KG, kg = s - g * KG;
+    u32x4 (&reg)[8] = w_reg[s % NSETS];
+    const int nch = min(8, (Kp >> 5) - kg * 8);
+    if constexpr (kg == 0) {
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) c[rt] = z4;
+    }
+    {
+      const __bf16* ar = A1 + fr * LDA + kg * 256 + 8 * fq;
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) {
+        if (cc < nch) {
+          const bf16x8 b0 = __builtin_bit_cast(bf16x8, reg[cc]);
+#pragma unroll
+          for (int rt = 0; rt < NRT; ++rt) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + rt * 16 * LDA + cc * 32);
+            c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, c[rt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    load_w(s + NSETS, reg);
+    if constexpr (kg == KG - 1) {
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) dxn[g][rt] = c[rt];
+    }
+  });
+  ln_bwd_tail<NRT, GD>(dxn, xv, r2, v_g, red, d, wave, fr, fq, p.out + (size_t)m0 * p.ld_out, p.ld_out,
+                       part + (size_t)blockIdx.x * (2 * SRAD_LNB_CP));
+}
+
+template <int FM, int GD, int KG>
+int launch_lin_fm(const LinLnBwdParams& p, WgradQueue& q, hipStream_t stream) {
+  constexpr size_t lds = (size_t)FM * (KG * 256 + 8) * 2 + (384 + FM * 16) * sizeof(float);
+  auto kern = lin_ln_bwd_kernel<FM, GD, KG>;
+  static bool configured = false;
+  if (!configured) {
+    SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  float* part = nullptr;
+  SRAD_TRY(srad_wgrad_queue_ln_partials(q, p.dgamma, p.dbeta, p.d, p.M / FM, stream, &part));
+  SradProfScope prof(stream, SRAD_K_MLP_BWD, 2.0 * p.M * p.K * p.d, 4.0 * p.M * ((double)p.K + 4.0 * p.d) + 2.0 * p.K * p.d);
+  hipLaunchKernelGGL(kern, dim3(p.M / FM), dim3(512), lds, stream, p, part);
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}
+template <int GD, int KG>
+int launch_lin(const LinLnBwdParams& p, WgradQueue& q, hipStream_t stream) {
+  if (p.M >= 8192 && p.M % 32 == 0) return launch_lin_fm<32, GD, KG>(p, q, stream);
+  return launch_lin_fm<16, GD, KG>(p, q, stream);
+}
+// (128-column groups of d, 256-wide k groups of K = 3 d) of DRCT-L's Swin blocks: d = 180 .. 308
+#define SRAD_LIN_CFGS(X) X(2, 3) X(3, 4)
 
 struct BwdCfg { int gd, kgd, gm, kgm; };
 inline BwdCfg bwd_cfg(int d, int m) {
@@ -326,4 +470,26 @@ int srad_launch_mlp_bwd(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream
   SRAD_BWD_CFGS(X)
 #undef X
   return srad_set_error(SRAD_ERR_ARG, "mlp_bwd: no kernel instance for this geometry");
+}
+
+bool srad_lin_ln_bwd_supported(int prec, int M, int K, int d) {
+  if (!(prec == SRAD_PREC_BF16 && M % 16 == 0 && d % 4 == 0 && K % 4 == 0 && d >= 32 && d <= SRAD_LNB_CP && K >= 32 && K <= 1024)) return false;
+  const int gd = (d + FB_SC - 1) / FB_SC, kg = (srad_cp(K) + 255) / 256;
+#define X(a, b) if (gd == a && kg == b) return true;
+  SRAD_LIN_CFGS(X)
+#undef X
+  return false;
+}
+
+int srad_launch_lin_ln_bwd(const LinLnBwdParams& p, WgradQueue& q, hipStream_t stream) {
+  SRAD_REQUIRE(srad_lin_ln_bwd_supported(SRAD_PREC_BF16, p.M, p.K, p.d), "lin_ln_bwd: unsupported shape M=%d K=%d d=%d", p.M, p.K, p.d);
+  SRAD_REQUIRE(p.dY && p.w_t && p.x && p.ln_g && p.out, "lin_ln_bwd: null argument");
+  SRAD_REQUIRE(((p.ld_dy | p.ldx | p.ld_out | (p.dres ? p.ld_dres : 0)) & 3) == 0 &&
+                   (((uintptr_t)p.dY | (uintptr_t)p.x | (uintptr_t)p.out | (uintptr_t)p.dres) & 15) == 0,
+               "lin_ln_bwd: rows must be 16-byte aligned (strides multiples of 4 floats)");
+  const int gd = (p.d + FB_SC - 1) / FB_SC, kg = (srad_cp(p.K) + 255) / 256;
+#define X(a, b) if (gd == a && kg == b) return launch_lin<a, b>(p, q, stream);
+  SRAD_LIN_CFGS(X)
+#undef X
+  return srad_set_error(SRAD_ERR_ARG, "lin_ln_bwd: no kernel instance for this geometry");
 }

@@ -287,6 +287,21 @@ struct MlpBwdParams {
   float *dgamma, *dbeta;
 };
 bool srad_mlp_bwd_supported(int prec, int M, int d, int m);
+// dX = dY . W followed by the backward of the LayerNorm that produced the Linear's input, one launch (bf16 mode):
+//   out (+)= dres + LayerNorm'(dY . W; x, gamma)          dgamma / dbeta partial rows -> the split-K queue
+// (the qkv Linear + LayerNorm1 end of a Swin block's backward).  w_t = fragments of W^T: rows = d, k = K.
+struct LinLnBwdParams {
+  int M, K, d;
+  const float* dY; int ld_dy;           // [M][K]
+  const void* w_t;
+  const float* x; int ldx;              // LayerNorm input rows
+  const float* ln_g;
+  const float* dres; int ld_dres;       // gradient arriving over the residual path
+  float* out; int ld_out; int accumulate;
+  float *dgamma, *dbeta;
+};
+bool srad_lin_ln_bwd_supported(int prec, int M, int K, int d);
+int srad_launch_lin_ln_bwd(const LinLnBwdParams& p, WgradQueue& q, hipStream_t stream);
 int srad_launch_mlp_bwd(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream);
 
 // Shifted-window attention backward (window size 8): recomputes P from the saved head-padded q|k|v.

@@ -123,7 +123,7 @@ inline int train_arena_bytes(const ParamTable& pt, TrainState& ts, size_t* bytes
       if (e.packed) off += srad_align_up(srad_packed_bytes(pt.prec, srad_round_up(e.cin, 4), srad_round_up(e.n, 4), e.ntaps), 256);
     }
     for (const ParamEntry& e : pt.entries) {      // Linear layers of the fused kernels: W^T as MFMA fragments too
-      const bool frag = e.packed && e.frag_off >= 0 && e.ntaps == 1;
+      const bool frag = e.packed && (e.frag_off >= 0 || e.tfrag) && e.ntaps == 1;
       ts.tf_off.push_back(frag ? (long long)off : -1);
       if (frag) off += srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, srad_round_up(e.cin, 4), srad_round_up(e.n, 4), 1), 256);
     }
