@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import metrics as M
-from .train import FusedAdam, GradReducer, cosine_lr, drn_train_step, train_step
+from .train import FusedAdam, GradReducer, GraphedTrainStep, cosine_lr, drn_train_step, train_step
 
 
 def make_optimizer(opt, my_model) -> FusedAdam:
@@ -155,6 +155,10 @@ class Trainer:
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.reducer = GradReducer().attach(self.net) if self.world > 1 else None
+        # one GPU, DRCT: the whole step is one replayed hipGraph per batch shape (train.GraphedTrainStep); opt.train_graph = False
+        # keeps the eager launches.  Data parallel runs stay eager: the bucket hooks launch RCCL all-reduces mid-backward.
+        self.graph_step = (GraphedTrainStep(self.net, self.optimizer)
+                           if self.world == 1 and not dual_model and getattr(opt, "train_graph", True) else None)
         self.error_last = 1e8
         self.loss_log: List[float] = []
         self.device = next(self.net.parameters()).device
@@ -179,7 +183,8 @@ class Trainer:
                                              getattr(self.opt, "dual_weight", 0.1), self.reducer))
             else:
                 lr = lr.to(self.device, non_blocking=True)
-                losses.append(train_step(self.net, lr, hr, self.optimizer, self.reducer))
+                losses.append(self.graph_step(lr, hr) if self.graph_step is not None else
+                              train_step(self.net, lr, hr, self.optimizer, self.reducer))
             if (batch + 1) % self.opt.print_every == 0:
                 cur = float(torch.stack(losses[-self.opt.print_every:]).mean())      # the only host sync, every print_every
                 self._log('[{}/{}]\t[L1: {:.4f}]\t{:.1f}s'.format((batch + 1) * bs, len(self.train_set), cur,
