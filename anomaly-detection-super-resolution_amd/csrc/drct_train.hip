@@ -431,10 +431,15 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       wq.ws = wq_base + (size_t)set * wq_half; wq.ws_floats = wq_half;
       float *dx2 = w.dx2[set], *dx1 = w.dx1[set], *dh = w.dh[set], *dqkv = w.dqkv[set];
       // ---- adjust_k: 1x1 conv (+ LeakyReLU 0.2 | * 0.2)                        (drct.py:389-393)
+      // ---- MLP branch: x2 = x1 + rs2 * fc2(gelu(fc1(LN2(x1))))                 (drct.py:510, 184-190)
+      const int KA = k < 4 ? c.gc : E;
+      const bool fuse_mlp = fused_bwd && h->ts.tf_off[sw.fc1.w] >= 0 && h->ts.tf_off[sw.fc2.w] >= 0 &&
+                            srad_mlp_bwd_supported(prec, T, d, sw.hidden, 0);
+      const bool fuse_adj = fuse_mlp && h->ts.tf_off[sw.adjust.w] >= 0 && srad_mlp_bwd_supported(prec, T, d, sw.hidden, KA);
       const float* dA; int ldA; float aalpha = 1.f;
       if (k < 4) {
-        SRAD_TRY(srad_launch_dact(gc + d, D, cur + d, D, w.dA[set], c.gc, T, c.gc, 0.2f, s));
-        dA = w.dA[set]; ldA = c.gc;
+        if (!fuse_adj) SRAD_TRY(srad_launch_dact(gc + d, D, cur + d, D, w.dA[set], c.gc, T, c.gc, 0.2f, s));
+        dA = w.dA[set]; ldA = c.gc;          // fused: written by mlp_bwd
       } else {
         dA = gn; ldA = D; aalpha = 0.2f;
       }
@@ -442,13 +447,12 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
         WgradParams g = wgrad_of(h, sw.adjust, G, dA, ldA, 0, sv.x2, d, T);
         g.alpha = aalpha;
         SRAD_TRY(srad_launch_wgrad_deferred(prec, g, wq, side));
-        GemmParams p = dgrad_gemm(h, sw.adjust, dA, ldA, T, dx2, d);
-        p.alpha = aalpha;
-        SRAD_TRY(srad_launch_gemm(prec, p, s));
+        if (!fuse_adj) {
+          GemmParams p = dgrad_gemm(h, sw.adjust, dA, ldA, T, dx2, d);
+          p.alpha = aalpha;
+          SRAD_TRY(srad_launch_gemm(prec, p, s));
+        }
       }
-      // ---- MLP branch: x2 = x1 + rs2 * fc2(gelu(fc1(LN2(x1))))                 (drct.py:510, 184-190)
-      const bool fuse_mlp = fused_bwd && h->ts.tf_off[sw.fc1.w] >= 0 && h->ts.tf_off[sw.fc2.w] >= 0 &&
-                            srad_mlp_bwd_supported(prec, T, d, sw.hidden);
       {
         WgradParams g = wgrad_of(h, sw.fc2, G, dx2, d, 0, sv.hact, sw.hidden, T);
         g.row_scale = ks2; g.rps = HW;
@@ -462,6 +466,11 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
         mb.w_fc2t = h->ts.tarena + h->ts.tf_off[sw.fc2.w]; mb.hpre = sv.hpre; mb.dh = dh;
         mb.w_fc1t = h->ts.tarena + h->ts.tf_off[sw.fc1.w]; mb.x1 = sv.x1; mb.ln_g = h->pt.fptr(sw.n2g); mb.dx1 = dx1;
         mb.dgamma = G + h->ts.flat_off[sw.n2g]; mb.dbeta = G + h->ts.flat_off[sw.n2b];
+        if (fuse_adj) {   // ... and the adjust conv's data gradient (with its LeakyReLU') in front of them
+          mb.KA = KA; mb.w_adjt = h->ts.tarena + h->ts.tf_off[sw.adjust.w]; mb.aalpha = aalpha; mb.slope = 0.2f;
+          if (k < 4) { mb.dA = gc + d; mb.ld_dA = D; mb.y_act = cur + d; mb.ld_y = D; mb.dA_out = w.dA[set]; }
+          else { mb.dA = gn; mb.ld_dA = D; }
+        }
         SRAD_TRY(srad_launch_mlp_bwd(mb, wq, s));
       } else {
         {

@@ -147,26 +147,32 @@ __device__ __forceinline__ void ln_bwd_tail(f32x4 (&dxn)[GD][NRT], f32x4 (&xv)[G
 }
 
 // GD / GM = 128-column groups of the block dim / hidden, KGD / KGM = 256-wide k groups of the block dim / hidden
-template <int FM, int GD, int KGD, int GM, int KGM>
+// KCA > 0: the adjust 1x1 conv's data gradient runs first, in the same launch (KCA = 32-wide k chunks of its output
+// channels: 1 for the 32-channel adjust1-4, 6 for adjust5's 180): dx2 = alpha * (dA (.) lrelu'(y)) . Wadj is computed from
+// the [FM][<=192] gradient tile, written out (fc2's weight gradient reads it) and kept on chip as this kernel's input.
+template <int FM, int GD, int KGD, int GM, int KGM, int KCA>
 __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, float* __restrict__ part) {
   constexpr int NRT = FM / 16;
+  constexpr int LDAA = KCA * 32 + 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* A1 = reinterpret_cast<__bf16*>(smem);                  // [FM][FB_LDA] dx2
   __bf16* Hs = A1 + FM * FB_LDA;                                 // [FM][FB_LDH] dh
   float* v_g = reinterpret_cast<float*>(Hs + FM * FB_LDH);       // [384] gamma
   float* red = v_g + 384;                                        // [FM][8 waves][2] row partial sums
+  [[maybe_unused]] __bf16* Aa = reinterpret_cast<__bf16*>(red + FM * 16);   // [FM][LDAA] gradient of the adjust conv's output
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int m0 = blockIdx.x * FM;
   const int d = p.d, m = p.m;
   const int Kd = (d + 31) & ~31, Km = (m + 31) & ~31;
-  constexpr int n_fc2 = GM * KGD, n_fc1 = GD * KGM, n_stages = n_fc2 + n_fc1;
+  constexpr int n_adj = KCA > 0 ? GD : 0, n_fc2 = GM * KGD, n_fc1 = GD * KGM, n_stages = n_adj + n_fc2 + n_fc1;
 
   auto stage_ptr = [&](int s, int& Kp, int& nch) -> const char* {
     s = min(s, n_stages - 1);
     const char* w; int kgs;
-    if (s < n_fc2) { w = (const char*)p.w_fc2t; Kp = Kd; kgs = KGD; }
+    if (s < n_adj) { w = (const char*)p.w_adjt; Kp = KCA * 32; kgs = 1; }
+    else if ((s -= n_adj) < n_fc2) { w = (const char*)p.w_fc2t; Kp = Kd; kgs = KGD; }
     else { s -= n_fc2; w = (const char*)p.w_fc1t; Kp = Km; kgs = KGM; }
     const int g = s / kgs, kg = s - g * kgs;
     nch = min(8, (Kp >> 5) - kg * 8);
@@ -203,14 +209,19 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
   const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- independent loads: dx2 tile (A operand layout), first weight stages, gamma, dx2 / x1 in the result layout ----
-  constexpr int NAQ = 32 * GD;
-  constexpr int NAJ = FM * NAQ / 512;
-  static_assert(FM * NAQ % 512 == 0, "dx2 tile must divide over the workgroup");
+  constexpr int NAQ = KCA > 0 ? 8 * KCA : 32 * GD;            // float4 per row of the tile read from global memory
+  constexpr int NAJ = (FM * NAQ + 511) / 512;
   f32x4 a_reg[NAJ];
+  [[maybe_unused]] f32x4 y_reg[NAJ];
 #pragma unroll
   for (int j = 0; j < NAJ; ++j) {
-    const int idx = tid + 512 * j, row = idx / NAQ, c = (idx - row * NAQ) * 4;
-    a_reg[j] = *reinterpret_cast<const f32x4*>(p.dx2 + (size_t)(m0 + row) * d + min(c, d - 4));
+    const int idx = min(tid + 512 * j, FM * NAQ - 1), row = idx / NAQ, c = (idx - row * NAQ) * 4;
+    if constexpr (KCA > 0) {
+      a_reg[j] = *reinterpret_cast<const f32x4*>(p.dA + (size_t)(m0 + row) * p.ld_dA + min(c, p.KA - 4));
+      y_reg[j] = p.y_act ? *reinterpret_cast<const f32x4*>(p.y_act + (size_t)(m0 + row) * p.ld_y + min(c, p.KA - 4)) : z4;
+    } else {
+      a_reg[j] = *reinterpret_cast<const f32x4*>(p.dx2 + (size_t)(m0 + row) * d + min(c, d - 4));
+    }
   }
 #pragma unroll
   for (int q = 0; q < NSETS; ++q) load_w(q, w_reg[q]);
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
     const int c4 = min(col4_of(g), d - 4);
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt) {
-      r2[g][rt] = *reinterpret_cast<const f32x4*>(p.dx2 + (size_t)(m0 + rt * 16 + fr) * d + c4);
+      if constexpr (KCA == 0) r2[g][rt] = *reinterpret_cast<const f32x4*>(p.dx2 + (size_t)(m0 + rt * 16 + fr) * d + c4);
       xv[g][rt] = *reinterpret_cast<const f32x4*>(p.x1 + (size_t)(m0 + rt * 16 + fr) * d + c4);
     }
   }
@@ -241,32 +252,55 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
 #pragma unroll
   for (int j = 0; j < NAJ; ++j) {
     const int idx = tid + 512 * j, row = idx / NAQ, c = (idx - row * NAQ) * 4;
-    const f32x4 v = c < d ? a_reg[j] : z4;
-    bf16x4 h;
-    h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-    *reinterpret_cast<bf16x4*>(A1 + row * FB_LDA + c) = h;
+    if (idx < FM * NAQ) {
+      bf16x4 h;
+      if constexpr (KCA > 0) {           // dA = dY (.) lrelu'(y): kept for the adjust conv's weight gradient, bf16 tile in LDS
+        f32x4 v = a_reg[j];
+        if (p.y_act) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = y_reg[j][e] > 0.f ? v[e] : v[e] * p.slope;
+        }
+        v = c < p.KA ? v : z4;
+        if (p.dA_out && c < p.KA) *reinterpret_cast<f32x4*>(p.dA_out + (size_t)(m0 + row) * p.KA + c) = v;
+        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+        *reinterpret_cast<bf16x4*>(Aa + row * LDAA + c) = h;
+      } else {
+        const f32x4 v = c < d ? a_reg[j] : z4;
+        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+        *reinterpret_cast<bf16x4*>(A1 + row * FB_LDA + c) = h;
+      }
+    }
   }
 
   f32x4 dxn[GD][NRT];
   f32x4 c[NRT];
   static_for<0, n_stages>([&](auto S) {
     constexpr int s = decltype(S)::value;
-    constexpr int ph = s < n_fc2 ? 0 : 1;
-    constexpr int ls = s - (ph == 0 ? 0 : n_fc2);
-    constexpr int kgs = ph == 0 ? KGD : KGM;
+    constexpr int ph = s < n_adj ? -1 : (s < n_adj + n_fc2 ? 0 : 1);
+    constexpr int ls = s - (ph == -1 ? 0 : (ph == 0 ? n_adj : n_adj + n_fc2));
+    constexpr int kgs = ph == -1 ? 1 : (ph == 0 ? KGD : KGM);
     constexpr int g = ls / kgs, kg = ls - g * kgs;
     u32x4 (&reg)[8] = w_reg[s % NSETS];
-    const int Kp = ph == 0 ? Kd : Km;
+    const int Kp = ph == -1 ? KCA * 32 : (ph == 0 ? Kd : Km);
     const int nch = min(8, (Kp >> 5) - kg * 8);
-    if constexpr (ls == 0) __syncthreads();            // the phase's activation tile (A1 / Hs) is complete
+    if constexpr (ls == 0) __syncthreads();            // the phase's activation tile (Aa / A1 / Hs) is complete
     if constexpr (kg == 0) {
 #pragma unroll
       for (int rt = 0; rt < NRT; ++rt) c[rt] = z4;
     }
-    mma_stage(ph == 0 ? A1 : Hs, ph == 0 ? FB_LDA : FB_LDH, kg * 256, nch, reg, c);
+    mma_stage(ph == -1 ? Aa : (ph == 0 ? A1 : Hs), ph == -1 ? LDAA : (ph == 0 ? FB_LDA : FB_LDH), kg * 256, nch, reg, c);
     load_w(s + NSETS, reg);
     if constexpr (kg == kgs - 1) {
-      if constexpr (ph == 0) {
+      if constexpr (ph == -1) {                        // dx2 = alpha * dA . Wadj: residual registers, global copy, bf16 A tile
+        const int c4 = col4_of(g);
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+          const f32x4 v = c4 < d ? c[rt] * p.aalpha : z4;
+          r2[g][rt] = v;
+          if (c4 < d) *reinterpret_cast<f32x4*>(p.dx2 + (size_t)(m0 + rt * 16 + fr) * d + c4) = v;
+          store_bf4(A1, FB_LDA, rt, c4, v);
+        }
+      } else if constexpr (ph == 0) {
         const int c4 = col4_of(g);
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt) {
@@ -420,15 +454,16 @@ int launch_lin(const LinLnBwdParams& p, WgradQueue& q, hipStream_t stream) {
 // (128-column groups of d, 256-wide k groups of K = 3 d) of DRCT-L's Swin blocks: d = 180 .. 308
 #define SRAD_LIN_CFGS(X) X(2, 3) X(3, 4)
 
-struct BwdCfg { int gd, kgd, gm, kgm; };
-inline BwdCfg bwd_cfg(int d, int m) {
+struct BwdCfg { int gd, kgd, gm, kgm, kca; };
+inline BwdCfg bwd_cfg(int d, int m, int KA) {
   const int Kd = srad_cp(d), Km = srad_cp(m);
-  return BwdCfg{(d + FB_SC - 1) / FB_SC, (Kd + 255) / 256, (m + FB_SC - 1) / FB_SC, (Km + 255) / 256};
+  return BwdCfg{(d + FB_SC - 1) / FB_SC, (Kd + 255) / 256, (m + FB_SC - 1) / FB_SC, (Km + 255) / 256, (KA + 31) / 32};
 }
-template <int FM, int GD, int KGD, int GM, int KGM>
+template <int FM, int GD, int KGD, int GM, int KGM, int KCA>
 int launch_bwd_fm(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream) {
-  constexpr size_t lds = (size_t)(FM * FB_LDA + FM * FB_LDH) * 2 + (384 + FM * 16) * sizeof(float);
-  auto kern = mlp_bwd_kernel<FM, GD, KGD, GM, KGM>;
+  constexpr size_t lds = (size_t)(FM * FB_LDA + FM * FB_LDH) * 2 + (384 + FM * 16) * sizeof(float) +
+                         (KCA > 0 ? (size_t)FM * (KCA * 32 + 8) * 2 : 0);
+  auto kern = mlp_bwd_kernel<FM, GD, KGD, GM, KGM, KCA>;
   static bool configured = false;
   if (!configured) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -436,37 +471,46 @@ int launch_bwd_fm(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream) {
   }
   float* part = nullptr;
   SRAD_TRY(srad_wgrad_queue_ln_partials(q, p.dgamma, p.dbeta, p.d, p.M / FM, stream, &part));
-  SradProfScope prof(stream, SRAD_K_MLP_BWD, 8.0 * p.M * p.d * p.m, 4.0 * p.M * (3.0 * p.d + 2.0 * p.m) + 4.0 * p.d * p.m);
+  SradProfScope prof(stream, SRAD_K_MLP_BWD, 8.0 * p.M * p.d * p.m + (KCA > 0 ? 2.0 * p.M * p.d * p.KA : 0.0),
+                     4.0 * p.M * (3.0 * p.d + 2.0 * p.m) + 4.0 * p.d * p.m);
   hipLaunchKernelGGL(kern, dim3(p.M / FM), dim3(512), lds, stream, p, part);
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
 }
-template <int GD, int KGD, int GM, int KGM>
+template <int GD, int KGD, int GM, int KGM, int KCA>
 int launch_bwd(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream) {
-  if (p.M >= 8192 && p.M % 32 == 0) return launch_bwd_fm<32, GD, KGD, GM, KGM>(p, q, stream);
-  return launch_bwd_fm<16, GD, KGD, GM, KGM>(p, q, stream);
+  if (p.M >= 8192 && p.M % 32 == 0) return launch_bwd_fm<32, GD, KGD, GM, KGM, KCA>(p, q, stream);
+  return launch_bwd_fm<16, GD, KGD, GM, KGM, KCA>(p, q, stream);
 }
-// stage geometries of DRCT-L's Swin blocks (embed 180 + k*32; mlp ratio 2, 2, 2, 1, 1)
-#define SRAD_BWD_CFGS(X) X(2, 1, 3, 2) X(2, 1, 4, 2) X(3, 2, 3, 2)
+// stage geometries of DRCT-L's Swin blocks (embed 180 + k*32; mlp ratio 2, 2, 2, 1, 1); last number: 32-wide chunks of
+// the adjust conv's output channels when its data gradient is part of the launch (adjust1-4: 32, adjust5: 180), 0 = not
+#define SRAD_BWD_CFGS(X) X(2, 1, 3, 2, 0) X(2, 1, 4, 2, 0) X(3, 2, 3, 2, 0) X(2, 1, 3, 2, 1) X(2, 1, 4, 2, 1) X(3, 2, 3, 2, 1) X(3, 2, 3, 2, 6)
 }  // namespace
 
-bool srad_mlp_bwd_supported(int prec, int M, int d, int m) {
-  if (!(prec == SRAD_PREC_BF16 && M % 16 == 0 && d % 4 == 0 && m % 4 == 0 && d >= 32 && d <= SRAD_LNB_CP && m >= 32 && m <= 512)) return false;
-  const BwdCfg c = bwd_cfg(d, m);
-#define X(a, b, cc, dd) if (c.gd == a && c.kgd == b && c.gm == cc && c.kgm == dd) return true;
+bool srad_mlp_bwd_supported(int prec, int M, int d, int m, int KA) {
+  if (!(prec == SRAD_PREC_BF16 && M % 16 == 0 && d % 4 == 0 && m % 4 == 0 && d >= 32 && d <= SRAD_LNB_CP && m >= 32 && m <= 512 &&
+        KA >= 0 && KA % 4 == 0))
+    return false;
+  const BwdCfg c = bwd_cfg(d, m, KA);
+#define X(a, b, cc, dd, e) if (c.gd == a && c.kgd == b && c.gm == cc && c.kgm == dd && c.kca == e) return true;
   SRAD_BWD_CFGS(X)
 #undef X
   return false;
 }
 
 int srad_launch_mlp_bwd(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream) {
-  SRAD_REQUIRE(srad_mlp_bwd_supported(SRAD_PREC_BF16, p.M, p.d, p.m), "mlp_bwd: unsupported shape M=%d d=%d m=%d", p.M, p.d, p.m);
+  SRAD_REQUIRE(srad_mlp_bwd_supported(SRAD_PREC_BF16, p.M, p.d, p.m, p.KA), "mlp_bwd: unsupported shape M=%d d=%d m=%d KA=%d", p.M, p.d, p.m, p.KA);
   SRAD_REQUIRE(p.dx2 && p.w_fc2t && p.hpre && p.dh && p.w_fc1t && p.x1 && p.ln_g && p.dx1, "mlp_bwd: null argument");
   SRAD_REQUIRE((((uintptr_t)p.dx2 | (uintptr_t)p.hpre | (uintptr_t)p.dh | (uintptr_t)p.x1 | (uintptr_t)p.dx1) & 15) == 0,
                "mlp_bwd: tensors must be 16-byte aligned");
   SRAD_REQUIRE(!p.rs2 || p.rps > 0, "mlp_bwd: rows per sample missing");
-  const BwdCfg c = bwd_cfg(p.d, p.m);
-#define X(a, b, cc, dd) if (c.gd == a && c.kgd == b && c.gm == cc && c.kgm == dd) return launch_bwd<a, b, cc, dd>(p, q, stream);
+  if (p.KA > 0) {
+    SRAD_REQUIRE(p.dA && p.w_adjt && (p.ld_dA & 3) == 0 && ((uintptr_t)p.dA & 15) == 0 &&
+                     (!p.y_act || ((p.ld_y & 3) == 0 && ((uintptr_t)p.y_act & 15) == 0)) && ((uintptr_t)p.dA_out & 15) == 0,
+                 "mlp_bwd: the adjust gradient rows must be float4-addressable");
+  }
+  const BwdCfg c = bwd_cfg(p.d, p.m, p.KA);
+#define X(a, b, cc, dd, e) if (c.gd == a && c.kgd == b && c.gm == cc && c.kgm == dd && c.kca == e) return launch_bwd<a, b, cc, dd, e>(p, q, stream);
   SRAD_BWD_CFGS(X)
 #undef X
   return srad_set_error(SRAD_ERR_ARG, "mlp_bwd: no kernel instance for this geometry");

@@ -275,7 +275,7 @@ int srad_wgrad_queue_ln_partials(WgradQueue& q, float* dgamma, float* dbeta, int
 // ------------------------------------------------------------------------------------------
 struct MlpBwdParams {
   int M, d, m;
-  const float* dx2;                     // [M][d] gradient of the block output before the adjust conv
+  float* dx2;                           // [M][d] gradient of the block output before the adjust conv (KA > 0: written)
   const float* rs2; int rps;            // DropPath factor of the MLP branch per sample (null = 1)
   const void* w_fc2t;                   // fragments of fc2.weight^T: rows = hidden, k = d
   const float* hpre;                    // [M][m] fc1 pre-activation
@@ -285,8 +285,15 @@ struct MlpBwdParams {
   const float* ln_g;
   float* dx1;                           // [M][d]
   float *dgamma, *dbeta;
+  // ---- optional prologue (KA > 0): the adjust 1x1 conv's data gradient, dx2 = aalpha * (dA (.) lrelu'(y_act)) . Wadj ----
+  int KA;                               // output channels of the adjust conv (32 or 180), 0 = dx2 is an input
+  const float* dA; int ld_dA;           // [M][>=KA] gradient of the adjust conv's output (before its activation's derivative)
+  const float* y_act; int ld_y;         // the conv's forward output for LeakyReLU' (null: no activation)
+  float slope, aalpha;
+  float* dA_out;                        // [M][KA] dA (.) lrelu'(y): operand of the conv's weight gradient (null: not needed)
+  const void* w_adjt;                   // fragments of adjust.weight^T: rows = d, k = KA
 };
-bool srad_mlp_bwd_supported(int prec, int M, int d, int m);
+bool srad_mlp_bwd_supported(int prec, int M, int d, int m, int KA);
 // dX = dY . W followed by the backward of the LayerNorm that produced the Linear's input, one launch (bf16 mode):
 //   out (+)= dres + LayerNorm'(dY . W; x, gamma)          dgamma / dbeta partial rows -> the split-K queue
 // (the qkv Linear + LayerNorm1 end of a Swin block's backward).  w_t = fragments of W^T: rows = d, k = K.
