@@ -435,6 +435,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       const int KA = k < 4 ? c.gc : E;
       const bool fuse_mlp = fused_bwd && h->ts.tf_off[sw.fc1.w] >= 0 && h->ts.tf_off[sw.fc2.w] >= 0 &&
                             srad_mlp_bwd_supported(prec, T, d, sw.hidden, 0);
+      const bool fuse_proj = fuse_mlp && h->ts.tf_off[sw.proj.w] >= 0;      // ... and the projection's data gradient behind them
       const bool fuse_adj = fuse_mlp && h->ts.tf_off[sw.adjust.w] >= 0 && srad_mlp_bwd_supported(prec, T, d, sw.hidden, KA);
       const float* dA; int ldA; float aalpha = 1.f;
       if (k < 4) {
@@ -471,6 +472,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
           if (k < 4) { mb.dA = gc + d; mb.ld_dA = D; mb.y_act = cur + d; mb.ld_y = D; mb.dA_out = w.dA[set]; }
           else { mb.dA = gn; mb.ld_dA = D; }
         }
+        if (fuse_proj) { mb.w_projt = h->ts.tarena + h->ts.tf_off[sw.proj.w]; mb.rs1 = ks1; mb.rps = HW; mb.dO = w.dO; }
         SRAD_TRY(srad_launch_mlp_bwd(mb, wq, s));
       } else {
         {
@@ -496,9 +498,11 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
         WgradParams g = wgrad_of(h, sw.proj, G, dx1, d, 0, sv.attn, d, T);
         g.row_scale = ks1; g.rps = HW;
         SRAD_TRY(srad_launch_wgrad_deferred(prec, g, wq, side));
-        GemmParams p = dgrad_gemm(h, sw.proj, dx1, d, T, w.dO, d);
-        p.row_scale = ks1; p.rps = HW;
-        SRAD_TRY(srad_launch_gemm(prec, p, s));
+        if (!fuse_proj) {
+          GemmParams p = dgrad_gemm(h, sw.proj, dx1, d, T, w.dO, d);
+          p.row_scale = ks1; p.rps = HW;
+          SRAD_TRY(srad_launch_gemm(prec, p, s));
+        }
       }
       {
         AttnBwdParams a{sv.qkv, w.dO, dqkv, h->pt.fptr(sw.table), G + h->ts.flat_off[sw.table], B, H, W, c.window_size,

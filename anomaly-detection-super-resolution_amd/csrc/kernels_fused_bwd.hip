@@ -45,7 +45,7 @@ __device__ __forceinline__ float dgelu_fast(float x) {
 template <int NRT, int GD>
 __device__ __forceinline__ void ln_bwd_tail(f32x4 (&dxn)[GD][NRT], f32x4 (&xv)[GD][NRT], const f32x4 (&r2)[GD][NRT],
                                             const float* v_g, float* red, int d, int wave, int fr, int fq, float* out0,
-                                            int ld_out, float* prow) {
+                                            int ld_out, float* prow, __bf16* a_out = nullptr, int lda_out = 0) {
   const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
   auto col4_of = [&](int g) { return FB_SC * g + 16 * wave + 4 * fq; };
   const float invC = 1.0f / (float)d;
@@ -125,11 +125,15 @@ __device__ __forceinline__ void ln_bwd_tail(f32x4 (&dxn)[GD][NRT], f32x4 (&xv)[G
 #pragma unroll
   for (int g = 0; g < GD; ++g) {
     const int c4 = col4_of(g);
-    if (c4 < d) {
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) {
-        const f32x4 o4 = (dxn[g][rt] - s1[rt] * invC - xv[g][rt] * (s2[rt] * invC)) * rstd[rt] + r2[g][rt];
-        *reinterpret_cast<f32x4*>(out0 + (size_t)(rt * 16 + fr) * ld_out + c4) = o4;
+    for (int rt = 0; rt < NRT; ++rt) {
+      const f32x4 o4 = (dxn[g][rt] - s1[rt] * invC - xv[g][rt] * (s2[rt] * invC)) * rstd[rt] + r2[g][rt];
+      if (c4 < d) *reinterpret_cast<f32x4*>(out0 + (size_t)(rt * 16 + fr) * ld_out + c4) = o4;
+      if (a_out) {                                               // the result as the next GEMM's bf16 A tile (zero beyond d)
+        const f32x4 v = c4 < d ? o4 : z4;
+        bf16x4 h;
+        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+        *reinterpret_cast<bf16x4*>(a_out + (rt * 16 + fr) * lda_out + c4) = h;
       }
     }
   }
@@ -318,7 +322,49 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
     }
   });
 
-  ln_bwd_tail<NRT, GD>(dxn, xv, r2, v_g, red, d, wave, fr, fq, p.dx1 + (size_t)m0 * d, d, part + (size_t)blockIdx.x * (2 * SRAD_LNB_CP));
+  // ---- optional epilogue phase: the attention projection's data gradient dO = (dx1 . Wproj) * rs1 from the dx1 rows
+  //      just produced (bf16 tile in A1); its first weight stages are in flight during the LayerNorm arithmetic ----
+  constexpr int n_proj = GD * KGD;
+  auto load_wp = [&](int s, u32x4 (&reg)[8]) {
+    s = min(s, n_proj - 1);
+    const int g = s / KGD, kg = s - g * KGD;
+    const int nch = min(8, (Kd >> 5) - kg * 8);
+    const char* base = (const char*)p.w_projt + ((size_t)(g * 8 + wave) * (Kd >> 5) + kg * 8) * 1024 + fr * 64 + fq * 16;
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + (cc < nch ? cc : 0) * 1024);
+  };
+  float rs1v[NRT];
+  if (p.w_projt) {
+#pragma unroll
+    for (int q = 0; q < NSETS; ++q) load_wp(q, w_reg[q]);
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) rs1v[rt] = p.rs1 ? p.rs1[(m0 + rt * 16 + fr) / p.rps] : 1.f;
+  }
+  ln_bwd_tail<NRT, GD>(dxn, xv, r2, v_g, red, d, wave, fr, fq, p.dx1 + (size_t)m0 * d, d, part + (size_t)blockIdx.x * (2 * SRAD_LNB_CP),
+                       p.w_projt ? A1 : nullptr, FB_LDA);
+  if (p.w_projt) {
+    __syncthreads();                                             // the dx1 tile is complete
+    static_for<0, n_proj>([&](auto S) {
+      constexpr int s = decltype(S)::value;
+      constexpr int g = s / KGD, kg = s - g * KGD;
+      u32x4 (&reg)[8] = w_reg[s % NSETS];
+      const int nch = min(8, (Kd >> 5) - kg * 8);
+      if constexpr (kg == 0) {
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) c[rt] = z4;
+      }
+      mma_stage(A1, FB_LDA, kg * 256, nch, reg, c);
+      load_wp(s + NSETS, reg);
+      if constexpr (kg == KGD - 1) {
+        const int c4 = col4_of(g);
+        if (c4 < d) {
+#pragma unroll
+          for (int rt = 0; rt < NRT; ++rt)
+            *reinterpret_cast<f32x4*>(p.dO + (size_t)(m0 + rt * 16 + fr) * d + c4) = c[rt] * rs1v[rt];
+        }
+      }
+    });
+  }
 }
 
 // ------------------------------------------------------------------------------------------

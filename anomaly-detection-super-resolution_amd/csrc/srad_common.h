@@ -292,6 +292,10 @@ struct MlpBwdParams {
   float slope, aalpha;
   float* dA_out;                        // [M][KA] dA (.) lrelu'(y): operand of the conv's weight gradient (null: not needed)
   const void* w_adjt;                   // fragments of adjust.weight^T: rows = d, k = KA
+  // ---- optional epilogue (w_projt != null): the attention projection's data gradient dO = (dx1 . Wproj) * rs1 ----
+  const void* w_projt;                  // fragments of proj.weight^T: rows = d, k = d
+  const float* rs1;                     // DropPath factor of the attention branch per sample (null = 1; rows per sample = rps)
+  float* dO;                            // [M][d]
 };
 bool srad_mlp_bwd_supported(int prec, int M, int d, int m, int KA);
 // dX = dY . W followed by the backward of the LayerNorm that produced the Linear's input, one launch (bf16 mode):
