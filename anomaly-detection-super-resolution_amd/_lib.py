@@ -148,6 +148,10 @@ def lib() -> C.CDLL:
                     f"libsrad.so not found at {LIB_PATH}: build it with "
                     "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
                     "There is no CPU fallback for the product path.")
+            # PyTorch ships its own libamdhip64 (torch/lib) and libsrad.so names /opt/rocm's by SONAME: whichever is loaded
+            # first serves both.  Load torch's first - with two HIP runtimes in one process the engine's launches fail
+            # with "no ROCm-capable device is detected" (seen when build() dlopen'ed libsrad before torch was imported).
+            import torch  # noqa: F401
             l = C.CDLL(LIB_PATH)
             missing = [n for n in _SIG if not hasattr(l, n)]
             if missing:
