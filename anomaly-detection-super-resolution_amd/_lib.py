@@ -126,6 +126,13 @@ _SIG = {
     "srad_op_wgrad_workspace_bytes": (C.c_size_t, []),
     "srad_op_dgrad": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P,
                                 C.c_int, C.c_int, C.c_float, C.c_float, _P, _P, C.c_int, _P, C.c_size_t, _P]),
+    "srad_op_mlp_bwd_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "srad_op_mlp_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P,
+                                  C.c_int, _P, C.c_int, _P, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, _P,
+                                  _P, C.c_size_t, _P, _P]),
+    "srad_op_lin_ln_bwd_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "srad_op_lin_ln_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, _P, _P,
+                                     _P, C.c_size_t, _P, _P]),
     "srad_op_layernorm_bwd": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P]),
     "srad_op_window_attn_bwd": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, _P, _P]),

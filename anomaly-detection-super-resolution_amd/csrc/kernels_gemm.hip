@@ -459,7 +459,8 @@ __global__ void pack_weight_t_kernel(const float* __restrict__ src, void* __rest
 // Fragment-major bf16 pack for kernels that feed MFMA operands straight from global memory (kernels_fused.hip):
 // 16-row x 32-k tiles, tile (n / 16, k / 32) is 1 KB contiguous, row-major inside - exactly the 64 lanes x 16 bytes
 // of one v_mfma_f32_16x16x32_bf16 operand, so a wave's fragment load is one fully coalesced request.
-__global__ void pack_weight_frag_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int N, int Cin, int Np, int Kp) {
+__global__ void pack_weight_frag_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int N, int Cin, int Np, int Kp,
+                                        int sn, int sk) {
   const size_t total = (size_t)Np * Kp;
   const int ktiles = Kp / 32;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -467,7 +468,7 @@ __global__ void pack_weight_frag_kernel(const float* __restrict__ src, __bf16* _
     const size_t tile = i >> 9;
     const int kt = (int)(tile % ktiles), nt = (int)(tile / ktiles);
     const int n = nt * 16 + rin, k = kt * 32 + kin;
-    dst[i] = (__bf16)((n < N && k < Cin) ? src[(size_t)n * Cin + k] : 0.f);
+    dst[i] = (__bf16)((n < N && k < Cin) ? src[(size_t)n * sn + (size_t)k * sk] : 0.f);
   }
 }
 
@@ -605,7 +606,18 @@ int srad_launch_pack_weight_frag(const float* src, void* dst, int n, int cin, hi
   const size_t total = (size_t)Np * Kp;
   const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
   SradProfScope prof(stream, SRAD_K_PACK, 0.0, 4.0 * n * cin + 2.0 * total);
-  hipLaunchKernelGGL(pack_weight_frag_kernel, dim3(blocks), dim3(256), 0, stream, src, reinterpret_cast<__bf16*>(dst), n, cin, Np, Kp);
+  hipLaunchKernelGGL(pack_weight_frag_kernel, dim3(blocks), dim3(256), 0, stream, src, reinterpret_cast<__bf16*>(dst), n, cin, Np, Kp, cin, 1);
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}
+
+// the fragment-major pack of W^T (rows = input channels, k = output channels) from the same [n][cin] source
+int srad_launch_pack_weight_frag_t(const float* src, void* dst, int n, int cin, hipStream_t stream) {
+  const int Np = srad_np(srad_round_up(cin, 4)), Kp = srad_cp(srad_round_up(n, 4));
+  const size_t total = (size_t)Np * Kp;
+  const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+  SradProfScope prof(stream, SRAD_K_PACK, 0.0, 4.0 * n * cin + 2.0 * total);
+  hipLaunchKernelGGL(pack_weight_frag_kernel, dim3(blocks), dim3(256), 0, stream, src, reinterpret_cast<__bf16*>(dst), cin, n, Np, Kp, 1, cin);
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
 }

@@ -198,6 +198,66 @@ int srad_op_window_attn_bwd(int precision, const float* qkv, const float* dout, 
   return srad_wgrad_flush(q, reinterpret_cast<hipStream_t>(stream));
 }
 
+static size_t tfrag_bytes(int n, int cin) {   // fragment pack of W^T for W [n][cin]
+  return srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, srad_round_up(cin, 4), srad_round_up(n, 4), 1), 256);
+}
+
+size_t srad_op_mlp_bwd_scratch_bytes(int d, int m, int KA) {
+  return tfrag_bytes(m, d) + tfrag_bytes(d, m) + tfrag_bytes(d, d) + (KA > 0 ? tfrag_bytes(KA, d) : 0);
+}
+
+int srad_op_mlp_bwd(int M, int d, int m, float* dx2, const float* hpre, const float* x1, const float* gamma,
+                    const float* w_fc1, const float* w_fc2, const float* rs2, int rps, float* dh, float* dx1, float* dgamma,
+                    float* dbeta, int KA, const float* dA, int ld_dA, const float* y_act, int ld_y, float slope,
+                    float aalpha, const float* w_adj, float* dA_out, const float* w_proj, const float* rs1, float* dO,
+                    void* scratch, size_t scratch_bytes, void* workspace, void* stream) {
+  SRAD_REQUIRE(dx2 && hpre && x1 && gamma && w_fc1 && w_fc2 && dh && dx1 && scratch && workspace, "op_mlp_bwd: null argument");
+  SRAD_REQUIRE(scratch_bytes >= srad_op_mlp_bwd_scratch_bytes(d, m, KA) && ((uintptr_t)scratch & 255) == 0,
+               "op_mlp_bwd: scratch too small or not 256-byte aligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  char* sp = reinterpret_cast<char*>(scratch);
+  MlpBwdParams p{};
+  p.M = M; p.d = d; p.m = m; p.dx2 = dx2; p.rs2 = rs2; p.rps = rps; p.hpre = hpre; p.dh = dh; p.x1 = x1; p.ln_g = gamma;
+  p.dx1 = dx1; p.dgamma = dgamma; p.dbeta = dbeta;
+  p.w_fc1t = sp; SRAD_TRY(srad_launch_pack_weight_frag_t(w_fc1, sp, m, d, s)); sp += tfrag_bytes(m, d);
+  p.w_fc2t = sp; SRAD_TRY(srad_launch_pack_weight_frag_t(w_fc2, sp, d, m, s)); sp += tfrag_bytes(d, m);
+  if (w_proj) {
+    SRAD_REQUIRE(dO, "op_mlp_bwd: dO missing");
+    p.w_projt = sp; SRAD_TRY(srad_launch_pack_weight_frag_t(w_proj, sp, d, d, s));
+    p.rs1 = rs1; p.dO = dO;
+  }
+  sp += tfrag_bytes(d, d);
+  if (KA > 0) {
+    SRAD_REQUIRE(dA && w_adj, "op_mlp_bwd: adjust operands missing");
+    p.KA = KA; p.dA = dA; p.ld_dA = ld_dA; p.y_act = y_act; p.ld_y = ld_y; p.slope = slope; p.aalpha = aalpha; p.dA_out = dA_out;
+    p.w_adjt = sp; SRAD_TRY(srad_launch_pack_weight_frag_t(w_adj, sp, KA, d, s));
+  }
+  WgradQueue q;
+  q.ws = reinterpret_cast<float*>(workspace);
+  q.ws_floats = SRAD_WGRAD_WS_BYTES / sizeof(float);
+  SRAD_TRY(srad_launch_mlp_bwd(p, q, s));
+  return srad_wgrad_flush(q, s);
+}
+
+size_t srad_op_lin_ln_bwd_scratch_bytes(int K, int d) { return tfrag_bytes(K, d); }
+
+int srad_op_lin_ln_bwd(int M, int K, int d, const float* dY, const float* w, const float* x, int ldx, const float* gamma,
+                       const float* dres, float* out, int ld_out, int accumulate, float* dgamma, float* dbeta, void* scratch,
+                       size_t scratch_bytes, void* workspace, void* stream) {
+  SRAD_REQUIRE(dY && w && x && gamma && out && scratch && workspace, "op_lin_ln_bwd: null argument");
+  SRAD_REQUIRE(scratch_bytes >= tfrag_bytes(K, d) && ((uintptr_t)scratch & 255) == 0, "op_lin_ln_bwd: scratch too small or unaligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  SRAD_TRY(srad_launch_pack_weight_frag_t(w, scratch, K, d, s));
+  LinLnBwdParams p{};
+  p.M = M; p.K = K; p.d = d; p.dY = dY; p.ld_dy = K; p.w_t = scratch; p.x = x; p.ldx = ldx; p.ln_g = gamma;
+  p.dres = dres; p.ld_dres = d; p.out = out; p.ld_out = ld_out; p.accumulate = accumulate; p.dgamma = dgamma; p.dbeta = dbeta;
+  WgradQueue q;
+  q.ws = reinterpret_cast<float*>(workspace);
+  q.ws_floats = SRAD_WGRAD_WS_BYTES / sizeof(float);
+  SRAD_TRY(srad_launch_lin_ln_bwd(p, q, s));
+  return srad_wgrad_flush(q, s);
+}
+
 size_t srad_op_gemm_scratch_bytes(int precision, int N, int Cin, int ntaps) {
   return srad_packed_bytes(precision, N, Cin, ntaps);
 }

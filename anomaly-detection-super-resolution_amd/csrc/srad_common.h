@@ -142,6 +142,7 @@ int srad_launch_pack_weight_padded(int prec, const float* src, void* dst, int n,
                                    int grp_real, int grp_pad, hipStream_t stream);
 // Linear weights once more as bf16 MFMA fragments (16 x 32 tiles of 1 KB, tile-major): same byte size as the bf16 pack
 int srad_launch_pack_weight_frag(const float* src, void* dst, int n, int cin, hipStream_t stream);
+int srad_launch_pack_weight_frag_t(const float* src, void* dst, int n, int cin, hipStream_t stream);   // W^T: rows = cin, k = n
 // Data-gradient operand: the same tensor packed as the weight of the transposed convolution,
 // dst[c][8 - tap][n] (taps mirrored for 3x3, identity for 1x1), geometry (rows cin_pad, columns n_pad).
 int srad_launch_pack_weight_transposed(int prec, const float* src, void* dst, int n, int cin, int ntaps, int n_pad,

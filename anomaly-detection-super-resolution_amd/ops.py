@@ -3,7 +3,7 @@ tensors on the GPU; weights are given in PyTorch layout and packed by the librar
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
 
@@ -174,3 +174,73 @@ def window_attention_bwd(qkv: torch.Tensor, dout: torch.Tensor, table: torch.Ten
                                             L.current_stream_ptr()),
             "op_window_attn_bwd")
     return dqkv, dtable
+
+
+def _scratch(nbytes: int, device) -> Tuple[torch.Tensor, C.c_void_p, C.c_size_t]:
+    t = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+    off = (-t.data_ptr()) % 256
+    return t, C.c_void_p(t.data_ptr() + off), C.c_size_t(nbytes)
+
+
+def mlp_bwd(dx2: Optional[torch.Tensor], hpre: torch.Tensor, x1: torch.Tensor, gamma: torch.Tensor, w_fc1: torch.Tensor,
+            w_fc2: torch.Tensor, rs2: Optional[torch.Tensor] = None, rps: int = 0, adjust=None, proj=None):
+    """Fused backward of a Swin block's MLP branch (bf16 MFMA, C ABI ``srad_op_mlp_bwd``; src/drct.py:510, 184-190).
+
+    ``dx2`` [M, d] is the gradient of ``x2 = x1 + rs2 * fc2(gelu(fc1(LN(x1))))``, or None when ``adjust`` =
+    ``(dA [M, KA], y_act [M, KA] or None, slope, alpha, w_adj [KA, d])`` is given: then dx2 = alpha * (dA * lrelu'(y_act)) @ w_adj
+    is computed first.  ``proj`` = ``(w_proj [d, d], rs1 or None)`` adds dO = (dx1 @ w_proj) * rs1.
+    Returns a dict: dh [M, m], dx1 [M, d], dgamma, dbeta, and dx2 / dA (adjust) / dO (proj)."""
+    _need_cuda(hpre, x1, gamma, w_fc1, w_fc2)
+    M, d = x1.shape
+    m = hpre.shape[1]
+    dev = x1.device
+    f = lambda t: None if t is None else t.detach().float().contiguous()
+    out = {"dh": torch.empty(M, m, dtype=torch.float32, device=dev), "dx1": torch.empty(M, d, dtype=torch.float32, device=dev),
+           "dgamma": torch.zeros(d, dtype=torch.float32, device=dev), "dbeta": torch.zeros(d, dtype=torch.float32, device=dev)}
+    KA, dA, y_act, slope, alpha, w_adj, dA_out = 0, None, None, 0.0, 1.0, None, None
+    if adjust is not None:
+        dA, y_act, slope, alpha, w_adj = adjust
+        dA, y_act, w_adj = f(dA), f(y_act), f(w_adj)
+        KA = dA.shape[1]
+        dx2 = torch.empty(M, d, dtype=torch.float32, device=dev)
+        dA_out = torch.empty(M, KA, dtype=torch.float32, device=dev)
+        out["dA"] = dA_out
+    else:
+        dx2 = f(dx2).clone()
+    out["dx2"] = dx2
+    w_proj, rs1, dO = None, None, None
+    if proj is not None:
+        w_proj, rs1 = f(proj[0]), f(proj[1])
+        dO = out["dO"] = torch.empty(M, d, dtype=torch.float32, device=dev)
+    keep = [f(hpre), f(x1), f(gamma), f(w_fc1), f(w_fc2), f(rs2)]
+    nbytes = L.lib().srad_op_mlp_bwd_scratch_bytes(d, m, KA)
+    sbuf, sp, sb = _scratch(nbytes, dev)
+    L.check(L.lib().srad_op_mlp_bwd(M, d, m, L.dptr(dx2), L.dptr(keep[0]), L.dptr(keep[1]), L.dptr(keep[2]), L.dptr(keep[3]),
+                                    L.dptr(keep[4]), L.dptr(keep[5]), int(rps), L.dptr(out["dh"]), L.dptr(out["dx1"]),
+                                    L.dptr(out["dgamma"]), L.dptr(out["dbeta"]), KA, L.dptr(dA), KA, L.dptr(y_act), KA,
+                                    float(slope), float(alpha), L.dptr(w_adj), L.dptr(dA_out), L.dptr(w_proj), L.dptr(rs1),
+                                    L.dptr(dO), sp, sb, wgrad_workspace(dev), L.current_stream_ptr()), "op_mlp_bwd")
+    return out
+
+
+def lin_ln_bwd(dy: torch.Tensor, w: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, dres: Optional[torch.Tensor] = None,
+               out: Optional[torch.Tensor] = None):
+    """Data gradient of ``Linear(w [K, d])`` applied to ``LayerNorm(x)`` plus the LayerNorm backward, one launch
+    (bf16 MFMA, ``srad_op_lin_ln_bwd``): returns (dres + LN'(dy @ w) (+ out if given), dgamma, dbeta)."""
+    _need_cuda(dy, w, x, gamma)
+    M, K = dy.shape
+    d = w.shape[1]
+    dev = x.device
+    acc = out is not None
+    if out is None:
+        out = torch.empty(M, d, dtype=torch.float32, device=dev)
+    dg = torch.zeros(d, dtype=torch.float32, device=dev)
+    db = torch.zeros(d, dtype=torch.float32, device=dev)
+    keep = [dy.detach().float().contiguous(), w.detach().float().contiguous(), gamma.detach().float().contiguous(),
+            None if dres is None else dres.detach().float().contiguous()]
+    nbytes = L.lib().srad_op_lin_ln_bwd_scratch_bytes(K, d)
+    sbuf, sp, sb = _scratch(nbytes, dev)
+    L.check(L.lib().srad_op_lin_ln_bwd(M, K, d, L.dptr(keep[0]), L.dptr(keep[1]), L.dptr(x), x.stride(0), L.dptr(keep[2]),
+                                       L.dptr(keep[3]), L.dptr(out), out.stride(0), 1 if acc else 0, L.dptr(dg), L.dptr(db),
+                                       sp, sb, wgrad_workspace(dev), L.current_stream_ptr()), "op_lin_ln_bwd")
+    return out, dg, db

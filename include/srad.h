@@ -232,6 +232,24 @@ int srad_op_layernorm_bwd(const float* dxn, const float* x, int ldx, const float
 int srad_op_window_attn_bwd(int precision, const float* qkv, const float* dout, float* dqkv, const float* table,
                             float* dtable, int B, int H, int W, int ws, int shift, int d, int heads, int hdp,
                             void* workspace, void* stream);
+/* Fused backward of the MLP branch of a Swin block (bf16 MFMA; src/drct.py:510, 184-190, 389-396, 300):
+ *   [KA > 0] dx2 = aalpha * (dA (.) lrelu'(y_act)) . w_adj          (written; dA (.) lrelu' -> dA_out if given)
+ *   dh  = (dx2 . w_fc2) * rs2 * gelu'(hpre);  dx1 = dx2 + LayerNorm'(dh . w_fc1; x1, gamma);  dgamma / dbeta accumulated
+ *   [w_proj] dO = (dx1 . w_proj) * rs1
+ * Weights in PyTorch layout: w_fc1 [m][d], w_fc2 [d][m], w_adj [KA][d], w_proj [d][d]; rs1 / rs2 per sample (rps rows
+ * each) or NULL.  scratch >= srad_op_mlp_bwd_scratch_bytes (256-byte aligned), workspace as for srad_op_wgrad. */
+size_t srad_op_mlp_bwd_scratch_bytes(int d, int m, int KA);
+int srad_op_mlp_bwd(int M, int d, int m, float* dx2, const float* hpre, const float* x1, const float* gamma,
+                    const float* w_fc1, const float* w_fc2, const float* rs2, int rps, float* dh, float* dx1, float* dgamma,
+                    float* dbeta, int KA, const float* dA, int ld_dA, const float* y_act, int ld_y, float slope,
+                    float aalpha, const float* w_adj, float* dA_out, const float* w_proj, const float* rs1, float* dO,
+                    void* scratch, size_t scratch_bytes, void* workspace, void* stream);
+/* Data gradient of a Linear + backward of the LayerNorm that fed it (bf16 MFMA): out (+)= dres + LayerNorm'(dY . w; x,
+ * gamma), w [K][d] in PyTorch layout, dY [M][K]; dgamma / dbeta accumulated */
+size_t srad_op_lin_ln_bwd_scratch_bytes(int K, int d);
+int srad_op_lin_ln_bwd(int M, int K, int d, const float* dY, const float* w, const float* x, int ldx, const float* gamma,
+                       const float* dres, float* out, int ld_out, int accumulate, float* dgamma, float* dbeta, void* scratch,
+                       size_t scratch_bytes, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------ diagnostics
  * Per-kernel-class device timing with HIP events on the launch stream (bench.py's roofline numbers). */

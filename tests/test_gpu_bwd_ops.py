@@ -204,3 +204,84 @@ def test_adam_and_l1_grad_match_torch(dev):
     ad, bd = a.detach().to(dev), b.to(dev)
     L.check(L.lib().srad_l1_grad(L.dptr(ad), L.dptr(bd), L.dptr(out), 1000, 1.0 / 1000, L.current_stream_ptr()), "l1_grad")
     assert torch.equal(out.cpu(), a.grad)
+
+
+@pytest.mark.parametrize("M,d,m,KA", [(64, 180, 360, 32), (8192, 212, 424, 32), (96, 244, 488, 0), (8192 + 32, 276, 276, 32),
+                                      (48, 308, 308, 180)])
+def test_fused_mlp_backward_matches_autograd(dev, M, d, m, KA):
+    """mlp_bwd_kernel (adjust data gradient -> fc2 / GELU' / fc1 data gradients -> LayerNorm2 backward -> projection data
+    gradient) against fp32 autograd of the same chain (src/drct.py:300, 509-510, 184-190, 389-396).  Operands are rounded
+    to bf16 for the MFMAs (fp32 accumulation): tolerance 2e-2 of each tensor's largest value."""
+    from srad_amd import ops
+    g = torch.Generator().manual_seed(M + d)
+    rps = M // 4 if M % 4 == 0 else M
+    nsmp = M // rps
+    attn = torch.randn(M, d, generator=g, requires_grad=True)
+    x0 = torch.randn(M, d, generator=g)
+    w_proj = (torch.randn(d, d, generator=g) / math.sqrt(d)).requires_grad_(True)
+    w1 = torch.randn(m, d, generator=g) / math.sqrt(d)
+    b1 = torch.randn(m, generator=g) * 0.1
+    w2 = torch.randn(d, m, generator=g) / math.sqrt(m)
+    gam = (1 + 0.2 * torch.randn(d, generator=g)).requires_grad_(True)
+    bet = (0.1 * torch.randn(d, generator=g)).requires_grad_(True)
+    rs1 = torch.floor(0.7 + torch.rand(nsmp, generator=g)) / 0.7
+    rs2 = torch.floor(0.7 + torch.rand(nsmp, generator=g)) / 0.7
+    r1 = rs1.repeat_interleave(rps)[:, None]
+    r2 = rs2.repeat_interleave(rps)[:, None]
+    x1 = (x0 + r1 * (attn @ w_proj.t())).detach().requires_grad_(True)
+    hpre = (F.layer_norm(x1, (d,), gam, bet, 1e-5) @ w1.t() + b1)
+    hpre.retain_grad()
+    x2 = x1 + r2 * (F.gelu(hpre) @ w2.t())
+    x2.retain_grad()
+    if KA:
+        w_adj = torch.randn(KA, d, generator=g) / math.sqrt(d)
+        slope, alpha = (0.2, 1.0) if KA == 32 else (1.0, 0.2)        # adjust1-4: LeakyReLU 0.2; adjust5: * 0.2, no activation
+        y = F.leaky_relu(x2 @ w_adj.t(), slope) if KA == 32 else x2 @ w_adj.t()
+        dA = torch.randn(M, KA, generator=g)
+        (y * alpha).backward(dA)
+        adjust = (dA.to(dev), y.detach().to(dev) if KA == 32 else None, slope, alpha, w_adj.to(dev))
+        dx2_in = None
+    else:
+        dx2_ref = torch.randn(M, d, generator=g)
+        x2.backward(dx2_ref)
+        adjust, dx2_in = None, dx2_ref.to(dev)
+    dx1_ref = x1.grad                                               # total gradient at x1 (residual + MLP branch)
+    (x0 + r1 * (attn @ w_proj.t())).backward(dx1_ref)               # ... pushed through the projection
+    out = ops.mlp_bwd(dx2_in, hpre.detach().to(dev), x1.detach().to(dev), gam.detach().to(dev), w1.to(dev), w2.to(dev),
+                      rs2.to(dev), rps, adjust=adjust, proj=(w_proj.detach().to(dev), rs1.to(dev)))
+    tol = 2e-2
+
+    def close(a, b):
+        return float((a.cpu() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    assert close(out["dx2"], x2.grad) < tol
+    assert close(out["dh"], hpre.grad) < tol
+    assert close(out["dx1"], dx1_ref) < tol
+    assert close(out["dO"], attn.grad) < tol
+    assert close(out["dgamma"], gam.grad) < tol and close(out["dbeta"], bet.grad) < tol
+    if KA == 32:
+        assert close(out["dA"], dA * torch.where(y.detach() > 0, 1.0, slope)) < 1e-6
+
+
+@pytest.mark.parametrize("M,d", [(64, 180), (8192, 244), (8192 + 16, 276), (32, 308)])
+def test_fused_qkv_layernorm_backward_matches_autograd(dev, M, d):
+    """lin_ln_bwd_kernel: out += dres + LayerNorm1'(dqkv @ Wqkv) with dgamma / dbeta, against fp32 autograd."""
+    from srad_amd import ops
+    g = torch.Generator().manual_seed(M + d)
+    D = 308
+    xbuf = torch.randn(M, D, generator=g)                             # rows of the RDG's dense buffer: LN reads [:, :d]
+    x = xbuf[:, :d].clone().requires_grad_(True)
+    gam = (1 + 0.2 * torch.randn(d, generator=g)).requires_grad_(True)
+    bet = (0.1 * torch.randn(d, generator=g)).requires_grad_(True)
+    w = torch.randn(3 * d, d, generator=g) / math.sqrt(d)
+    dqkv = torch.randn(M, 3 * d, generator=g)
+    dres = torch.randn(M, d, generator=g)
+    prev = torch.randn(M, D, generator=g)
+    (F.layer_norm(x, (d,), gam, bet, 1e-5) @ w.t()).backward(dqkv)
+    xd = xbuf.to(dev)
+    outbuf = prev.to(dev).clone()
+    out, dg, db = ops.lin_ln_bwd(dqkv.to(dev), w.to(dev), xd[:, :d], gam.detach().to(dev), dres=dres.to(dev), out=outbuf[:, :d])
+    ref = x.grad + dres + prev[:, :d]
+    rel = lambda a, b: float((a.cpu() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    assert rel(outbuf[:, :d], ref) < 2e-2
+    assert torch.equal(outbuf[:, d:].cpu(), prev[:, d:])             # columns beyond d untouched
+    assert rel(dg, gam.grad) < 2e-2 and rel(db, bet.grad) < 2e-2
