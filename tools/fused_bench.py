@@ -21,7 +21,7 @@ s = torch.cuda.Stream()
 with torch.cuda.stream(s):
     for d, m, no in [(180, 360, 32), (244, 488, 32), (308, 308, 32), (308, 308, 180)]:
         row = []
-        for dbg in (0, 1, 2, 4, 8, 3, 10, 15):
+        for dbg in (0, 1, 2, 4, 3, 16, 19, 51):
             us = C.c_float()
             L.check(L.lib().srad_bench_mlp_block(M, d, m, no, L.dptr(attn), L.dptr(short), L.dptr(y), L.dptr(w),
                                                  C.c_void_p(scratch.data_ptr() + off), C.c_size_t(scratch.numel() - off), dbg, 100,
