@@ -243,6 +243,159 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int kspli
   if (do_bias && tid < 64 && n0 + tid < p.n_real) p.db[n0 + tid] += vb * p.alpha;
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight gradient of an 80 -> 80 channel convolution (DRN-L's 160 RCAB convolutions, src/drn.py:143-158) with ONE
+// 80 x 80 tile per tap: the 64 x 64 tiles pad 80 channels to 128 on both sides (2.56x the MFMAs and operand loads).
+// Same scheme as wgrad_body - fragments straight from global memory, contraction over the token axis, four waves on
+// different rows, partial tiles for the reduce kernel - but a lane owns FIVE consecutive channels (a 16-byte and a
+// 4-byte load at channel 5 fr): component e of the quintuple is row fr of sub-tile e, so tile row i of sub-tile en
+// stands for channel 5 i + en and the tile is 5 x 5 MFMA tiles.  bf16 MFMA, stride 1, 1 or 9 taps.
+// ------------------------------------------------------------------------------------------
+constexpr int W80_TS = 84;                          // LDS row stride of a wave's 80 x 80 partial tile
+constexpr int W80_PART = 80 * 80 + 80;              // floats per partial: the tile (row-major) and 80 bias sums
+constexpr size_t W80_LDS = (size_t)(4 * 80 * W80_TS + 4 * 80) * sizeof(float);
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <bool CONV>
+__global__ __launch_bounds__(256) void wgrad80_kernel(const WgradParams p, const int ksplit, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];
+  float* const dbs = wsm + 4 * 80 * W80_TS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int L = blockIdx.x;
+  const int ks = L % ksplit, tap = L / ksplit;      // row split fastest: one XCD per row range (see wgrad_body)
+  const int rows_per = ((p.M + ksplit - 1) / ksplit + 127) / 128 * 128;
+  const int mb = ks * rows_per;
+  const int me = min(p.M, mb + rows_per);
+  const unsigned noff = (unsigned)(5 * fr + p.ycol0), coff = (unsigned)(5 * fr);
+  [[maybe_unused]] const int pad = p.ntaps == 9 ? 1 : 0;
+  [[maybe_unused]] const int ky = p.ntaps == 9 ? tap / 3 : 0, kx = p.ntaps == 9 ? tap - (tap / 3) * 3 : 0;
+  [[maybe_unused]] const int hwo = p.Ho * p.Wo;
+
+  f32x4 acc[5][5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+
+  f32x4 av4[2][8], bv4[2][8];
+  float av1[2][8], bv1[2][8];
+  unsigned okm[2];
+  auto load_step = [&](int m0, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
+    unsigned ok = 0u;
+    [[maybe_unused]] int bb = 0, oy = 0, ox = 0;
+    if constexpr (CONV) {
+      const int mf = min(m0 + 8 * fq, p.M - 1);
+      bb = mf / hwo;
+      const int rem = mf - bb * hwo;
+      oy = rem / p.Wo;
+      ox = rem - oy * p.Wo;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int m = m0 + 8 * fq + t;
+      const int mc = min(m, p.M - 1);
+      const float* ap = p.dY + (size_t)mc * p.ldy + noff;
+      av4[set][t] = *reinterpret_cast<const f32x4u*>(ap);
+      av1[set][t] = ap[4];
+      size_t xr = (size_t)mc;
+      bool in = true;
+      if constexpr (CONV) {
+        if (t > 0 && m < p.M) {
+          ++ox;
+          if (ox == p.Wo) { ox = 0; ++oy; if (oy == p.Ho) { oy = 0; ++bb; } }
+        }
+        const int iy = oy - pad + ky, ix = ox - pad + kx;
+        in = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        xr = (size_t)((bb * p.Hi + min(max(iy, 0), p.Hi - 1)) * p.Wi + min(max(ix, 0), p.Wi - 1));
+      }
+      const float* bp = p.X + xr * p.ldx + coff;
+      bv4[set][t] = *reinterpret_cast<const f32x4u*>(bp);
+      bv1[set][t] = bp[4];
+      ok |= (m < me ? 1u : 0u) << t;
+      ok |= ((m < me && in) ? 1u : 0u) << (8 + t);
+    }
+    okm[set] = ok;
+  };
+  auto compute_step = [&](auto set_c) {
+    constexpr int set = decltype(set_c)::value;
+    bf16x8 ah[5], bh[5];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const bool aok = (okm[set] >> t) & 1u, bok = (okm[set] >> (8 + t)) & 1u;
+#pragma unroll
+      for (int e = 0; e < 5; ++e) {
+        const float a = aok ? (e < 4 ? av4[set][t][e < 4 ? e : 0] : av1[set][t]) : 0.f;
+        const float b = bok ? (e < 4 ? bv4[set][t][e < 4 ? e : 0] : bv1[set][t]) : 0.f;
+        bsum[e] += a;
+        ah[e][t] = (__bf16)a;
+        bh[e][t] = (__bf16)b;
+      }
+    }
+#pragma unroll
+    for (int en = 0; en < 5; ++en)
+#pragma unroll
+      for (int ec = 0; ec < 5; ++ec)
+        acc[en][ec] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[en], bh[ec], acc[en][ec], 0, 0, 0);
+  };
+  {
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    int m0 = mb + wave * 32;
+    if (m0 < me) load_step(m0, S0{});
+    while (m0 < me) {
+      if (m0 + 128 < me) load_step(m0 + 128, S1{});
+      compute_step(S0{});
+      m0 += 128;
+      if (m0 >= me) break;
+      if (m0 + 128 < me) load_step(m0 + 128, S0{});
+      compute_step(S1{});
+      m0 += 128;
+    }
+  }
+  // ---- the four waves' partial tiles through LDS: lane (fq, fr) element e of acc[en][ec] is
+  //      (n = 5 (4 fq + e) + en, c = 5 fr + ec) ----
+  {
+    float* const mine = wsm + wave * 80 * W80_TS;
+#pragma unroll
+    for (int en = 0; en < 5; ++en)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float* row = mine + (5 * (4 * fq + e) + en) * W80_TS + 5 * fr;
+#pragma unroll
+        for (int ec = 0; ec < 5; ++ec) row[ec] = acc[en][ec][e];
+      }
+#pragma unroll
+    for (int e = 0; e < 5; ++e) { bsum[e] += __shfl_xor(bsum[e], 16); bsum[e] += __shfl_xor(bsum[e], 32); }
+    if (fq == 0) {
+#pragma unroll
+      for (int e = 0; e < 5; ++e) dbs[wave * 80 + 5 * fr + e] = bsum[e];
+    }
+  }
+  __syncthreads();
+  const bool do_bias = p.db != nullptr && tap == 0;
+  float* const mypart = part + ((size_t)tap * ksplit + ks) * W80_PART;
+  for (int idx = tid; idx < 1600; idx += 256) {           // float4 idx of the 80 x 80 tile: n = idx / 20, c = 4 (idx % 20)
+    const int n = idx / 20, c4 = (idx - n * 20) * 4;
+    const float* q = wsm + n * W80_TS + c4;
+    const f32x4 v = (*reinterpret_cast<const f32x4*>(q) + *reinterpret_cast<const f32x4*>(q + 80 * W80_TS)) +
+                    (*reinterpret_cast<const f32x4*>(q + 2 * 80 * W80_TS) + *reinterpret_cast<const f32x4*>(q + 3 * 80 * W80_TS));
+    if (ksplit > 1) {
+      *reinterpret_cast<f32x4*>(mypart + 4 * idx) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) p.dW[((size_t)n * 80 + c4 + e) * p.ntaps + tap] += v[e] * p.alpha;
+    }
+  }
+  if (tid < 80) {
+    const float vb = (dbs[tid] + dbs[80 + tid]) + (dbs[160 + tid] + dbs[240 + tid]);
+    if (ksplit > 1) mypart[6400 + tid] = vb;
+    else if (do_bias) p.db[tid] += vb * p.alpha;
+  }
+}
+
 template <int PREC, bool CONV>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const int ksplit, const int tn, const int tc,
                                                     float* __restrict__ part) {
@@ -289,6 +442,34 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceBatc
 #pragma unroll
       for (int i = 0; i < 16; ++i) t += red[i][cl];
       d.dW[col] += t * d.alpha;
+    }
+    return;
+  }
+  if (d.w80) {
+    // one 80 x 80 tile per tap (wgrad80_kernel): a quarter = 400 float4 of the row-major tile and 20 bias sums
+    const int tap = tile_id;
+    const float* const tb = d.part + (size_t)tap * d.ksplit * W80_PART;
+    for (int j = threadIdx.x; j < 400; j += 256) {
+      const int idx = quarter * 400 + j;
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      int k = 0;
+      for (; k + 8 <= d.ksplit; k += 8) {
+        f32x4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4*>(tb + (size_t)(k + u) * W80_PART + 4 * idx);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+      }
+      for (; k < d.ksplit; ++k) v += *reinterpret_cast<const f32x4*>(tb + (size_t)k * W80_PART + 4 * idx);
+      const int n = idx / 20, c4 = (idx - n * 20) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d.dW[((size_t)n * 80 + c4 + e) * d.ntaps + tap] += v[e] * d.alpha;
+    }
+    if (d.db != nullptr && tap == 0 && threadIdx.x < 20) {
+      const int n = quarter * 20 + threadIdx.x;
+      float vb = 0.f;
+      for (int kk = 0; kk < d.ksplit; ++kk) vb += tb[(size_t)kk * W80_PART + 6400 + n];
+      d.db[n] += vb * d.alpha;
     }
     return;
   }
@@ -358,7 +539,7 @@ int plan_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s, WgradPlan& pl
     q.used += need;
     WgradReduceItem& it = q.batch.it[q.batch.count++];
     it.dW = p.dW; it.db = p.db; it.part = pl.part; it.n_real = p.n_real; it.cin_real = p.cin_real; it.ntaps = p.ntaps;
-    it.tn = pl.tn; it.tc = pl.tc; it.ksplit = (int)ksplit; it.tile0 = q.tiles; it.alpha = p.alpha;
+    it.tn = pl.tn; it.tc = pl.tc; it.ksplit = (int)ksplit; it.tile0 = q.tiles; it.alpha = p.alpha; it.w80 = 0;
     q.tiles += (int)pl.tiles;
   }
   return SRAD_OK;
@@ -366,8 +547,54 @@ int plan_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s, WgradPlan& pl
 
 constexpr size_t WG_LDS = (size_t)(4 * 64 * 68 + 4 * 64) * sizeof(float);
 
+// 80 -> 80 channels, stride 1, bf16: one 80 x 80 tile per tap
+int launch_wgrad80(const WgradParams& p, WgradQueue& q, hipStream_t s) {
+  // about two workgroups per CU; a power of two from 8 up (one XCD per row range), at least two row steps per wave
+  const long kmax = (p.M + 255) / 256;
+  long target = (512 + p.ntaps - 1) / p.ntaps;
+  if (target > kmax) target = kmax;
+  long ksplit = 1;
+  while (ksplit * 2 <= kmax && ksplit * 10 <= target * 7) ksplit *= 2;
+  {
+    const long rows_per = ((p.M + ksplit - 1) / ksplit + 127) / 128 * 128;
+    ksplit = (p.M + rows_per - 1) / rows_per;
+  }
+  float* part = nullptr;
+  if (ksplit > 1) {
+    const size_t need = (size_t)p.ntaps * ksplit * W80_PART;
+    SRAD_REQUIRE(q.ws && need <= q.ws_floats, "wgrad: split-K workspace too small (%zu floats needed, %zu given)", need, q.ws_floats);
+    if (q.batch.count == SRAD_WGRAD_BATCH || q.used + need > q.ws_floats) {
+      SRAD_REQUIRE(q.multi.count == 0, "wgrad: split-K workspace too small for the deferred layers");
+      SRAD_TRY(srad_wgrad_flush(q, s));
+    }
+    part = q.ws + q.used;
+    q.used += need;
+    WgradReduceItem& it = q.batch.it[q.batch.count++];
+    it.dW = p.dW; it.db = p.db; it.part = part; it.n_real = 80; it.cin_real = 80; it.ntaps = p.ntaps;
+    it.tn = it.tc = 1; it.ksplit = (int)ksplit; it.tile0 = q.tiles; it.alpha = p.alpha; it.w80 = 1;
+    q.tiles += p.ntaps;
+  }
+  SradProfScope prof(s, SRAD_K_WGRAD, 2.0 * p.M * 80.0 * 80.0 * p.ntaps, 4.0 * p.M * 160.0 + 8.0 * 6400.0 * p.ntaps);
+  auto launch = [&](auto kern) -> int {
+    static bool configured = false;
+    if (!configured) {
+      SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)W80_LDS));
+      configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.ntaps * ksplit)), dim3(256), W80_LDS, s, p, (int)ksplit, part);
+    return SRAD_OK;
+  };
+  const int rc = p.ntaps == 9 ? launch(wgrad80_kernel<true>) : launch(wgrad80_kernel<false>);
+  if (rc) return rc;
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}
+
 template <int PREC>
 int launch_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s) {
+  if (PREC == SRAD_PREC_BF16 && p.N == 80 && p.Cin == 80 && p.n_real == 80 && p.cin_real == 80 && p.stride == 1 && !p.row_scale &&
+      (p.ntaps == 1 || (p.Hi == p.Ho && p.Wi == p.Wo)) && getenv("SRAD_NO_WGRAD80") == nullptr)
+    return launch_wgrad80(p, q, s);
   const bool conv = p.ntaps == 9 || p.stride != 1;
   WgradPlan pl;
   SRAD_TRY(plan_wgrad<PREC>(p, q, s, pl));
@@ -1074,7 +1301,7 @@ static int queue_colsum(WgradQueue& q, float* dst, const float* part, int ncols,
   if (q.batch.count == SRAD_WGRAD_BATCH) SRAD_TRY(srad_wgrad_flush(q, stream));
   WgradReduceItem& it = q.batch.it[q.batch.count++];
   it.dW = dst; it.db = nullptr; it.part = part; it.n_real = ncols; it.cin_real = row_stride; it.ntaps = 0;   // ntaps 0: column sums
-  it.tn = it.tc = 1; it.ksplit = rows; it.tile0 = q.tiles; it.alpha = alpha;
+  it.tn = it.tc = 1; it.ksplit = rows; it.tile0 = q.tiles; it.alpha = alpha; it.w80 = 0;
   q.tiles += (ncols + 63) / 64;
   return SRAD_OK;
 }

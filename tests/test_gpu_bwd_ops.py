@@ -23,7 +23,7 @@ def dev():
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-@pytest.mark.parametrize("M,K,N", [(4096, 180, 540), (1000, 212, 32), (77, 308, 180), (8192, 360, 180), (130, 36, 4)])
+@pytest.mark.parametrize("M,K,N", [(4096, 180, 540), (1000, 212, 32), (77, 308, 180), (8192, 360, 180), (130, 36, 4), (5000, 80, 80)])
 def test_wgrad_linear(dev, prec, M, K, N):
     from srad_amd import ops
     g = torch.Generator().manual_seed(M + K + N)
@@ -51,7 +51,8 @@ def test_wgrad_linear(dev, prec, M, K, N):
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(2, 32, 32, 180, 64, 1), (1, 17, 23, 4, 180, 1), (2, 16, 12, 64, 4, 1),
-                                                   (1, 32, 32, 20, 20, 2), (1, 15, 11, 40, 80, 2)])
+                                                   (1, 32, 32, 20, 20, 2), (1, 15, 11, 40, 80, 2),
+                                                   (2, 64, 64, 80, 80, 1), (1, 17, 23, 80, 80, 1)])      # 80 -> 80: the 80-wide tile kernel (bf16)
 def test_wgrad_conv3x3(dev, prec, B, H, W, Cin, Cout, stride):
     from srad_amd import ops
     g = torch.Generator().manual_seed(B * H + Cin)
