@@ -262,6 +262,42 @@ def c3_leg(args, torch, dev):
     return out
 
 
+def drn_train_leg(args, torch, dev):
+    """DRN-L x4 training step at the C3 shape (src/trainer.py:161-205 with dual_model=True): SR net + two dual regression
+    models, composite loss, one fused Adam for the SR net and a torch Adam per dual model; batch 8, RGB, 256 px HR."""
+    from srad_amd.nets import DRN, DownBlock
+    from srad_amd.train import FusedAdam, drn_train_step
+
+    class DrnOpt:
+        n_colors, n_blocks, n_feats, negval, rgb_range, scale = 3, 40, 20, 0.2, 255.0, [2, 4]
+        precision, use_graph = args.dtype, False
+    torch.manual_seed(1)
+    m = DRN(DrnOpt()).to(dev).train()
+    m.enable_training()
+    duals = [DownBlock(DrnOpt()).to(dev) for _ in DrnOpt.scale]
+    opt = FusedAdam(m, lr=1e-4, weight_decay=1e-8)
+    dopts = [torch.optim.Adam(d.parameters(), lr=1e-4, weight_decay=1e-8) for d in duals]
+    B = 8
+    lrs = [torch.rand(B, 3, 64, 64, device=dev) * 255, torch.rand(B, 3, 128, 128, device=dev) * 255]
+    hr = torch.rand(B, 3, 256, 256, device=dev) * 255
+    for _ in range(2):
+        drn_train_step(m, duals, lrs, hr, opt, dopts)
+    torch.cuda.synchronize()
+    steps = 5
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = drn_train_step(m, duals, lrs, hr, opt, dopts)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    fl = 3.0 * m.flops(B, 64, 64)
+    out = {"workload": "DRN-L x4 train step (SR net + 2 dual models, composite loss, Adam), RGB, 256 px HR, batch 8",
+           "ms_per_step": round(dt * 1e3, 2), "images_per_s": round(B / dt, 1), "hr_mpixels_per_s": round(B * 256 * 256 / dt / 1e6, 2),
+           "model_tflops": round(fl / dt / 1e12, 1), "loss": round(float(loss), 4)}
+    del m, duals, opt, dopts
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -431,6 +467,11 @@ def main():
             result["anomaly_eval"] = anomaly_eval_leg(model, args, torch)
             result["eval_1024px_tile"] = c5_leg(args, torch, dev)
             result["drn_forward"] = c3_leg(args, torch, dev)
+            if not args.no_train:
+                try:
+                    result["drn_train"] = drn_train_leg(args, torch, dev)
+                except Exception as e:                    # a secondary leg never takes the headline line down
+                    result["drn_train"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(result))
     if world > 1:
         dist.barrier()
