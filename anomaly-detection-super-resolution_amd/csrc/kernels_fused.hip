@@ -74,14 +74,19 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
   float* const v_bp = vec; float* const v_b1 = vec + 384; float* const v_b2 = vec + 896; float* const v_ba = vec + 1280;
   float* const v_g = vec + 1664; float* const v_b = vec + 2048;
 
-  auto stage_ptr = [&](int s, int& Kp, int& nch) -> const char* {
+  // A wave whose 16 output columns all lie beyond the matrix (column groups are 128 wide: d = 276 fills 17.25 of its
+  // 24 sixteen-column tiles, the 32-channel adjust conv 2 of 8) would stream zero rows of the padded pack and multiply
+  // them: it skips both (wave-uniform scalar branch; its accumulators stay zero, which is what the epilogues expect).
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  auto stage_ptr = [&](int s, int& Kp, int& nch, bool& live) -> const char* {
     s = min(s, n_stages - 1);
-    const char* w; int kgs;
-    if (s < n_proj) { w = (const char*)p.w_proj; Kp = Kd; kgs = KGD; }
-    else if ((s -= n_proj) < n_fc1) { w = (const char*)p.w_fc1; Kp = Kd; kgs = KGD; }
-    else if ((s -= n_fc1) < n_fc2) { w = (const char*)p.w_fc2; Kp = Km; kgs = KGM; }
-    else { s -= n_fc2; w = (const char*)p.w_adj; Kp = Kd; kgs = KGD; }
+    const char* w; int kgs, nreal;
+    if (s < n_proj) { w = (const char*)p.w_proj; Kp = Kd; kgs = KGD; nreal = d; }
+    else if ((s -= n_proj) < n_fc1) { w = (const char*)p.w_fc1; Kp = Kd; kgs = KGD; nreal = m; }
+    else if ((s -= n_fc1) < n_fc2) { w = (const char*)p.w_fc2; Kp = Km; kgs = KGM; nreal = d; }
+    else { s -= n_fc2; w = (const char*)p.w_adj; Kp = Kd; kgs = KGD; nreal = no; }
     const int g = s / kgs, kg = s - g * kgs;
+    live = (g * 8 + wave_s) * 16 < nreal;
     nch = min(8, (Kp >> 5) - kg * 8);
     // fragment-major pack: 1 KB tiles (16 rows x 32 k), tile (n / 16, k / 32); this wave's row tile is g * 8 + wave
     return w + ((size_t)(g * 8 + wave) * (Kp >> 5) + kg * 8) * 1024;
@@ -99,9 +104,12 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
   u32x4 w_reg[NSETS][8];
   auto load_w = [&](int s, u32x4 (&reg)[8]) {
     int Kp, nch;
-    const char* base = stage_ptr(s, Kp, nch) + fr * 64 + fq * 16;  // row fr, k 8 fq .. of the tile: the 64 lanes cover its 1 KB
+    bool live;
+    const char* base = stage_ptr(s, Kp, nch, live) + fr * 64 + fq * 16;  // row fr, k 8 fq .. of the tile: the 64 lanes cover its 1 KB
+    if (live) {
 #pragma unroll
-    for (int cc = 0; cc < 8; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + (cc < nch ? cc : 0) * 1024);
+      for (int cc = 0; cc < 8; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + (cc < nch ? cc : 0) * 1024);
+    }
   };
   // c[rt] += (A[16 rows][k0 .. k0 + nch*32) . W[16 columns of this wave][..]^T)^T
   auto mma_stage = [&](const __bf16* A, int lda, int k0, int nch, const u32x4 (&reg)[8], f32x4 (&c)[NRT]) {
@@ -335,7 +343,8 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
 #pragma unroll
       for (int rt = 0; rt < NRT; ++rt) c[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (!(p.dbg & 2)) mma_stage(ph == 2 ? Hs : A1, ph == 2 ? F_LDH : F_LDA, kg * 256, nch, reg, c);
+    const bool live = (g * 8 + wave_s) * 16 < (ph == 0 ? d : (ph == 1 ? m : (ph == 2 ? d : no)));
+    if (!(p.dbg & 2) && live) mma_stage(ph == 2 ? Hs : A1, ph == 2 ? F_LDH : F_LDA, kg * 256, nch, reg, c);
     if (!(p.dbg & 1)) load_w(s + NSETS, reg);          // refill this set, NSETS stages ahead
     if (!(p.dbg & 16)) if constexpr (kg == kgs - 1) {
       if constexpr (ph == 0) epi_proj(std::integral_constant<int, g>{}, c);
