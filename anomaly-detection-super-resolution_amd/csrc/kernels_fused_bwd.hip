@@ -172,13 +172,16 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
   const int Kd = (d + 31) & ~31, Km = (m + 31) & ~31;
   constexpr int n_adj = KCA > 0 ? GD : 0, n_fc2 = GM * KGD, n_fc1 = GD * KGM, n_stages = n_adj + n_fc2 + n_fc1;
 
-  auto stage_ptr = [&](int s, int& Kp, int& nch) -> const char* {
+  // waves whose 16 output columns are all padding skip their weight loads and MFMAs (see mlp_block_kernel)
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  auto stage_ptr = [&](int s, int& Kp, int& nch, bool& live) -> const char* {
     s = min(s, n_stages - 1);
-    const char* w; int kgs;
-    if (s < n_adj) { w = (const char*)p.w_adjt; Kp = KCA * 32; kgs = 1; }
-    else if ((s -= n_adj) < n_fc2) { w = (const char*)p.w_fc2t; Kp = Kd; kgs = KGD; }
-    else { s -= n_fc2; w = (const char*)p.w_fc1t; Kp = Km; kgs = KGM; }
+    const char* w; int kgs, nreal;
+    if (s < n_adj) { w = (const char*)p.w_adjt; Kp = KCA * 32; kgs = 1; nreal = d; }
+    else if ((s -= n_adj) < n_fc2) { w = (const char*)p.w_fc2t; Kp = Kd; kgs = KGD; nreal = m; }
+    else { s -= n_fc2; w = (const char*)p.w_fc1t; Kp = Km; kgs = KGM; nreal = d; }
     const int g = s / kgs, kg = s - g * kgs;
+    live = (g * 8 + wave_s) * 16 < nreal;
     nch = min(8, (Kp >> 5) - kg * 8);
     return w + ((size_t)(g * 8 + wave) * (Kp >> 5) + kg * 8) * 1024;
   };
@@ -186,9 +189,12 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
   u32x4 w_reg[NSETS][8];
   auto load_w = [&](int s, u32x4 (&reg)[8]) {
     int Kp, nch;
-    const char* base = stage_ptr(s, Kp, nch) + fr * 64 + fq * 16;
+    bool live;
+    const char* base = stage_ptr(s, Kp, nch, live) + fr * 64 + fq * 16;
+    if (live) {
 #pragma unroll
-    for (int cc = 0; cc < 8; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + (cc < nch ? cc : 0) * 1024);
+      for (int cc = 0; cc < 8; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + (cc < nch ? cc : 0) * 1024);
+    }
   };
   auto mma_stage = [&](const __bf16* A, int lda, int k0, int nch, const u32x4 (&reg)[8], f32x4 (&c)[NRT]) {
     const __bf16* ar = A + fr * lda + k0 + 8 * fq;
@@ -292,7 +298,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
 #pragma unroll
       for (int rt = 0; rt < NRT; ++rt) c[rt] = z4;
     }
-    mma_stage(ph == -1 ? Aa : (ph == 0 ? A1 : Hs), ph == -1 ? LDAA : (ph == 0 ? FB_LDA : FB_LDH), kg * 256, nch, reg, c);
+    if ((g * 8 + wave_s) * 16 < (ph == 0 ? m : d))
+      mma_stage(ph == -1 ? Aa : (ph == 0 ? A1 : Hs), ph == -1 ? LDAA : (ph == 0 ? FB_LDA : FB_LDH), kg * 256, nch, reg, c);
     load_w(s + NSETS, reg);
     if constexpr (kg == kgs - 1) {
       if constexpr (ph == -1) {                        // dx2 = alpha * dA . Wadj: residual registers, global copy, bf16 A tile
@@ -330,8 +337,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
     const int g = s / KGD, kg = s - g * KGD;
     const int nch = min(8, (Kd >> 5) - kg * 8);
     const char* base = (const char*)p.w_projt + ((size_t)(g * 8 + wave) * (Kd >> 5) + kg * 8) * 1024 + fr * 64 + fq * 16;
+    if ((g * 8 + wave_s) * 16 < d) {
 #pragma unroll
-    for (int cc = 0; cc < 8; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + (cc < nch ? cc : 0) * 1024);
+      for (int cc = 0; cc < 8; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + (cc < nch ? cc : 0) * 1024);
+    }
   };
   float rs1v[NRT];
   if (p.w_projt) {
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt) c[rt] = z4;
       }
-      mma_stage(A1, FB_LDA, kg * 256, nch, reg, c);
+      if ((g * 8 + wave_s) * 16 < d) mma_stage(A1, FB_LDA, kg * 256, nch, reg, c);
       load_wp(s + NSETS, reg);
       if constexpr (kg == KGD - 1) {
         const int c4 = col4_of(g);
@@ -387,6 +396,7 @@ __global__ __launch_bounds__(512) void lin_ln_bwd_kernel(const LinLnBwdParams p,
   const int Kp = (K + 31) & ~31;
   constexpr int n_stages = GD * KG;
   const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
 
   constexpr int NSETS = 3;
   u32x4 w_reg[NSETS][8];
@@ -395,8 +405,10 @@ __global__ __launch_bounds__(512) void lin_ln_bwd_kernel(const LinLnBwdParams p,
     const int g = s / KG, kg = s - g * KG;
     const int nch = min(8, (Kp >> 5) - kg * 8);
     const char* base = (const char*)p.w_t + ((size_t)(g * 8 + wave) * (Kp >> 5) + kg * 8) * 1024 + fr * 64 + fq * 16;
+    if ((g * 8 + wave_s) * 16 < d) {                 // all-padding column tiles: no loads, no MFMAs (see mlp_block_kernel)
 #pragma unroll
-    for (int cc = 0; cc < 8; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + (cc < nch ? cc : 0) * 1024);
+      for (int cc = 0; cc < 8; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + (cc < nch ? cc : 0) * 1024);
+    }
   };
   auto col4_of = [&](int g) { return FB_SC * g + 16 * wave + 4 * fq; };
 #pragma unroll
@@ -452,7 +464,7 @@ __global__ __launch_bounds__(512) void lin_ln_bwd_kernel(const LinLnBwdParams p,
 #pragma unroll
       for (int rt = 0; rt < NRT; ++rt) c[rt] = z4;
     }
-    {
+    if ((g * 8 + wave_s) * 16 < d) {
       const __bf16* ar = A1 + fr * LDA + kg * 256 + 8 * fq;
 #pragma unroll
       for (int cc = 0; cc < 8; ++cc) {
