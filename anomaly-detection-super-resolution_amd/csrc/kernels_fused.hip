@@ -54,8 +54,11 @@ __device__ __forceinline__ float gelu_fast(float x) {
 // of the block dim / hidden.
 // FM = token rows per workgroup (16, or 64 for large token counts: every workgroup streams all four weight
 // matrices, so at 65536 tokens 16-row tiles move 4096 x 0.5 MB per launch through L2).
-template <int FM, int GD, int KGD, int GM, int KGM, int GN>
+// KCD / KCM = 32-wide k chunks of the block dim / hidden (exact: a stage loads and multiplies only its real chunks; a
+// run-time chunk count meant duplicate loads of chunk 0 or branches around the loads, both measured slower).
+template <int FM, int GD, int KGD, int GM, int KGM, int GN, int KCD, int KCM>
 __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) {
+  static_assert(KGD == (KCD + 7) / 8 && KGM == (KCM + 7) / 8, "k groups are 8 chunks wide");
   constexpr int NRT = FM / 16;       // 16-row MFMA tiles per workgroup
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* A1 = reinterpret_cast<__bf16*>(smem);                  // [FM][F_LDA] attn tile -> LN2(x1) -> x2
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
   const int fr = lane & 15, fq = lane >> 4;
   const int m0 = blockIdx.x * FM;
   const int d = p.d, m = p.m, no = p.no;
-  const int Kd = (d + 31) & ~31, Km = (m + 31) & ~31;            // packed K of the weights (multiples of 32)
+  constexpr int Kd = KCD * 32, Km = KCM * 32;                    // packed K of the weights
   constexpr int n_proj = GD * KGD, n_fc1 = GM * KGD, n_fc2 = GD * KGM, n_adj = GN * KGD;
   constexpr int n_stages = n_proj + n_fc1 + n_fc2 + n_adj;
   // offsets of the staged vectors
@@ -78,37 +81,34 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
   // 24 sixteen-column tiles, the 32-channel adjust conv 2 of 8) would stream zero rows of the padded pack and multiply
   // them: it skips both (wave-uniform scalar branch; its accumulators stay zero, which is what the epilogues expect).
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-  auto stage_ptr = [&](int s, int& Kp, int& nch, bool& live) -> const char* {
-    s = min(s, n_stages - 1);
-    const char* w; int kgs, nreal;
-    if (s < n_proj) { w = (const char*)p.w_proj; Kp = Kd; kgs = KGD; nreal = d; }
-    else if ((s -= n_proj) < n_fc1) { w = (const char*)p.w_fc1; Kp = Kd; kgs = KGD; nreal = m; }
-    else if ((s -= n_fc1) < n_fc2) { w = (const char*)p.w_fc2; Kp = Km; kgs = KGM; nreal = d; }
-    else { s -= n_fc2; w = (const char*)p.w_adj; Kp = Kd; kgs = KGD; nreal = no; }
+  // stage s: phase (0 proj, 1 fc1, 2 fc2, 3 adjust), 128-column group g, 256-wide k group kg - all compile-time
+  struct StageGeo { int ph, g, kg, nch, kc; };
+  auto geo = [](int s) constexpr -> StageGeo {
+    if (s > n_stages - 1) s = n_stages - 1;
+    int ph = 0, kgs = 1, kc = 1;
+    if (s < n_proj) { ph = 0; kgs = KGD; kc = KCD; }
+    else if ((s -= n_proj) < n_fc1) { ph = 1; kgs = KGD; kc = KCD; }
+    else if ((s -= n_fc1) < n_fc2) { ph = 2; kgs = KGM; kc = KCM; }
+    else { s -= n_fc2; ph = 3; kgs = KGD; kc = KCD; }
     const int g = s / kgs, kg = s - g * kgs;
-    live = (g * 8 + wave_s) * 16 < nreal;
-    nch = min(8, (Kp >> 5) - kg * 8);
-    // fragment-major pack: 1 KB tiles (16 rows x 32 k), tile (n / 16, k / 32); this wave's row tile is g * 8 + wave
-    return w + ((size_t)(g * 8 + wave) * (Kp >> 5) + kg * 8) * 1024;
+    const int nch = kc - kg * 8 < 8 ? kc - kg * 8 : 8;
+    return StageGeo{ph, g, kg, nch, kc};
   };
-
-  // 8 waves (two per SIMD): a lone wave issues one VALU instruction per 4 cycles, two interleave at 2, and
-  // the epilogue / staging arithmetic of this kernel is VALU-issue bound.
-  // Each wave owns 16 output columns of a 128-column stage, i.e. 16 rows of the packed weight, and NOBODY else
-  // reads them (one 16-row token tile per workgroup): the weights go straight from global memory into MFMA
-  // fragment registers, three stages ahead.  The weights are packed fragment-major for this (1 KB tiles of 16 rows x
-// 32 k, srad_launch_pack_weight_frag), so every wave load is one contiguous kilobyte; with the row-major pack the same
-// loads are 16 separate 64-byte pieces and the kernel got slower than with the LDS stage (28.7 vs 25.4 us).
-  // No LDS stage for weights, no barrier per stage; barriers remain only where the activation tile changes.
+  // 8 waves (two per SIMD), each owns 16 output columns of a 128-column stage, i.e. 16 rows of the packed weight that
+  // NOBODY else reads: the weights go straight from global memory into MFMA fragment registers, three stages ahead (no
+  // LDS stage, no barrier per stage), from the fragment-major pack (one contiguous kilobyte per wave load).
   constexpr int NSETS = 3;
   u32x4 w_reg[NSETS][8];
-  auto load_w = [&](int s, u32x4 (&reg)[8]) {
-    int Kp, nch;
-    bool live;
-    const char* base = stage_ptr(s, Kp, nch, live) + fr * 64 + fq * 16;  // row fr, k 8 fq .. of the tile: the 64 lanes cover its 1 KB
-    if (live) {
+  auto load_w = [&](auto S, u32x4 (&reg)[8]) {
+    constexpr StageGeo sg = geo(decltype(S)::value);
+    const char* w = (const char*)(sg.ph == 0 ? p.w_proj : (sg.ph == 1 ? p.w_fc1 : (sg.ph == 2 ? p.w_fc2 : p.w_adj)));
+    const int nreal = sg.ph == 0 ? d : (sg.ph == 1 ? m : (sg.ph == 2 ? d : no));
+    // fragment-major pack: 1 KB tiles (16 rows x 32 k), tile (n / 16, k / 32); this wave's row tile is g * 8 + wave;
+    // lane: row fr, k 8 fq .. of the tile - the 64 lanes cover its 1 KB
+    const char* base = w + ((size_t)(sg.g * 8 + wave) * sg.kc + sg.kg * 8) * 1024 + fr * 64 + fq * 16;
+    if ((sg.g * 8 + wave_s) * 16 < nreal) {
 #pragma unroll
-      for (int cc = 0; cc < 8; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + (cc < nch ? cc : 0) * 1024);
+      for (int cc = 0; cc < sg.nch; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + cc * 1024);
     }
   };
   // c[rt] += (A[16 rows][k0 .. k0 + nch*32) . W[16 columns of this wave][..]^T)^T
@@ -141,8 +141,7 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     a_reg[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.attn) + (size_t)(m0 + row) * p.ld_attn * 4 +
                                                (unsigned)min(c, d - 4) * 4u);
   }
-#pragma unroll
-  for (int q = 0; q < NSETS; ++q) load_w(q, w_reg[q]);
+  static_for<0, NSETS>([&](auto Q) { load_w(Q, w_reg[decltype(Q)::value]); });
   float vq[5];
   {
     // staged vectors: [0,384) b_proj, [384,896) b_fc1, [896,1280) b_fc2, [1280,1664) b_adj, [1664,2048) gamma,
@@ -335,8 +334,8 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     constexpr int kgs = ph == 2 ? KGM : KGD;
     constexpr int g = ls / kgs, kg = ls - g * kgs;
     u32x4 (&reg)[8] = w_reg[s % NSETS];
-    const int Kp = ph == 2 ? Km : Kd;
-    const int nch = min(8, (Kp >> 5) - kg * 8);
+    constexpr int Kp = ph == 2 ? Km : Kd;
+    constexpr int nch = (Kp >> 5) - kg * 8 < 8 ? (Kp >> 5) - kg * 8 : 8;
     if constexpr (ls == 0) __syncthreads();            // first stage of a phase: the activation tile (A1 / Hs) and,
                                                        // at s == 0, the staged vectors written before are visible
     if constexpr (kg == 0) {
@@ -345,7 +344,7 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     }
     const bool live = (g * 8 + wave_s) * 16 < (ph == 0 ? d : (ph == 1 ? m : (ph == 2 ? d : no)));
     if (!(p.dbg & 2) && live) mma_stage(ph == 2 ? Hs : A1, ph == 2 ? F_LDH : F_LDA, kg * 256, nch, reg, c);
-    if (!(p.dbg & 1)) load_w(s + NSETS, reg);          // refill this set, NSETS stages ahead
+    if (!(p.dbg & 1)) load_w(std::integral_constant<int, s + NSETS>{}, reg);          // refill this set, NSETS stages ahead
     if (!(p.dbg & 16)) if constexpr (kg == kgs - 1) {
       if constexpr (ph == 0) epi_proj(std::integral_constant<int, g>{}, c);
       else if constexpr (ph == 1) epi_fc1(g, c);
@@ -355,15 +354,15 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
   });
 }
 
-struct FusedCfg { int gd, kgd, gm, kgm, gn; };
+struct FusedCfg { int gd, kgd, gm, kgm, gn, kcd, kcm; };
 inline FusedCfg fused_cfg(int d, int m, int no) {
   const int Kd = srad_cp(d), Km = srad_cp(m);
-  return FusedCfg{(d + F_SC - 1) / F_SC, (Kd + 255) / 256, (m + F_SC - 1) / F_SC, (Km + 255) / 256, (no + F_SC - 1) / F_SC};
+  return FusedCfg{(d + F_SC - 1) / F_SC, (Kd + 255) / 256, (m + F_SC - 1) / F_SC, (Km + 255) / 256, (no + F_SC - 1) / F_SC, Kd / 32, Km / 32};
 }
-template <int FM, int GD, int KGD, int GM, int KGM, int GN>
+template <int FM, int GD, int KGD, int GM, int KGM, int GN, int KCD, int KCM>
 int launch_mlp_fm(const MlpBlockParams& p, hipStream_t stream) {
   constexpr size_t lds = (size_t)(FM * F_LDA + FM * F_LDH) * 2 + (F_NV + FM * 16) * sizeof(float);
-  auto kern = mlp_block_kernel<FM, GD, KGD, GM, KGM, GN>;
+  auto kern = mlp_block_kernel<FM, GD, KGD, GM, KGM, GN, KCD, KCM>;
   static bool configured = false;
   if (!configured) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -376,21 +375,22 @@ int launch_mlp_fm(const MlpBlockParams& p, hipStream_t stream) {
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
 }
-template <int GD, int KGD, int GM, int KGM, int GN>
+template <int GD, int KGD, int GM, int KGM, int GN, int KCD, int KCM>
 int launch_mlp(const MlpBlockParams& p, hipStream_t stream) {
   // 16-row tiles until there are enough tokens to fill the chip several times with 64-row tiles
   if (const char* e = getenv("SRAD_MLP_FM")) {                 // tools/: timing experiments
     const int fm = atoi(e);
-    if (fm == 64 && p.M % 64 == 0) return launch_mlp_fm<64, GD, KGD, GM, KGM, GN>(p, stream);
-    if (fm == 32 && p.M % 32 == 0) return launch_mlp_fm<32, GD, KGD, GM, KGM, GN>(p, stream);
-    if (fm == 16) return launch_mlp_fm<16, GD, KGD, GM, KGM, GN>(p, stream);
+    if (fm == 64 && p.M % 64 == 0) return launch_mlp_fm<64, GD, KGD, GM, KGM, GN, KCD, KCM>(p, stream);
+    if (fm == 32 && p.M % 32 == 0) return launch_mlp_fm<32, GD, KGD, GM, KGM, GN, KCD, KCM>(p, stream);
+    if (fm == 16) return launch_mlp_fm<16, GD, KGD, GM, KGM, GN, KCD, KCM>(p, stream);
   }
-  if (p.M >= 32768 && p.M % 64 == 0) return launch_mlp_fm<64, GD, KGD, GM, KGM, GN>(p, stream);
-  if (p.M >= 8192 && p.M % 32 == 0) return launch_mlp_fm<32, GD, KGD, GM, KGM, GN>(p, stream);
-  return launch_mlp_fm<16, GD, KGD, GM, KGM, GN>(p, stream);
+  if (p.M >= 32768 && p.M % 64 == 0) return launch_mlp_fm<64, GD, KGD, GM, KGM, GN, KCD, KCM>(p, stream);
+  if (p.M >= 8192 && p.M % 32 == 0) return launch_mlp_fm<32, GD, KGD, GM, KGM, GN, KCD, KCM>(p, stream);
+  return launch_mlp_fm<16, GD, KGD, GM, KGM, GN, KCD, KCM>(p, stream);
 }
-// stage geometries of DRCT-L's Swin blocks (embed 180 + k*32; mlp ratio 2,2,2,1,1; adjust to 32 / 180 channels)
-#define SRAD_FUSED_CFGS(X) X(2, 1, 3, 2, 1) X(2, 1, 4, 2, 1) X(3, 2, 3, 2, 1) X(3, 2, 3, 2, 2)
+// stage geometries of DRCT-L's five Swin blocks (embed 180 + k*32; mlp ratio 2,2,2,1,1; adjust to 32 / 180 channels):
+// (column groups of d, k groups of d, column groups of m, k groups of m, column groups of the adjust output, k chunks of d, of m)
+#define SRAD_FUSED_CFGS(X) X(2, 1, 3, 2, 1, 6, 12) X(2, 1, 4, 2, 1, 7, 14) X(2, 1, 4, 2, 1, 8, 16) X(3, 2, 3, 2, 1, 9, 9) X(3, 2, 3, 2, 2, 10, 10)
 }  // namespace
 
 bool srad_mlp_block_supported(int prec, int M, int d, int m, int no) {
@@ -398,7 +398,7 @@ bool srad_mlp_block_supported(int prec, int M, int d, int m, int no) {
         m <= 512 && no >= 4 && no <= 384))
     return false;
   const FusedCfg c = fused_cfg(d, m, no);
-#define X(a, b, cc, dd, e) if (c.gd == a && c.kgd == b && c.gm == cc && c.kgm == dd && c.gn == e) return true;
+#define X(a, b, cc, dd, e, f, g) if (c.gd == a && c.kgd == b && c.gm == cc && c.kgm == dd && c.gn == e && c.kcd == f && c.kcm == g) return true;
   SRAD_FUSED_CFGS(X)
 #undef X
   return false;
@@ -411,7 +411,7 @@ int srad_launch_mlp_block(const MlpBlockParams& p, hipStream_t stream) {
                    ((uintptr_t)p.Y & 15) == 0 && (!p.R || ((p.ldr & 3) == 0 && ((uintptr_t)p.R & 15) == 0)),
                "mlp_block: shortcut / output / residual rows must be float4-addressable");
   const FusedCfg c = fused_cfg(p.d, p.m, p.no);
-#define X(a, b, cc, dd, e) if (c.gd == a && c.kgd == b && c.gm == cc && c.kgm == dd && c.gn == e) return launch_mlp<a, b, cc, dd, e>(p, stream);
+#define X(a, b, cc, dd, e, f, g) if (c.gd == a && c.kgd == b && c.gm == cc && c.kgm == dd && c.gn == e && c.kcd == f && c.kcm == g) return launch_mlp<a, b, cc, dd, e, f, g>(p, stream);
   SRAD_FUSED_CFGS(X)
 #undef X
   return srad_set_error(SRAD_ERR_ARG, "mlp_block: no kernel instance for this geometry");

@@ -19,7 +19,7 @@ scratch = torch.empty(4 << 20, dtype=torch.uint8, device=dev)
 off = (-scratch.data_ptr()) % 256
 s = torch.cuda.Stream()
 with torch.cuda.stream(s):
-    for d, m, no in [(180, 360, 32), (244, 488, 32), (308, 308, 32), (308, 308, 180)]:
+    for d, m, no in [(180, 360, 32), (212, 424, 32), (244, 488, 32), (276, 276, 32), (308, 308, 180)]:      # DRCT-L's five Swin blocks
         row = []
         for dbg in (0, 1, 2, 4, 3, 16, 19, 51):
             us = C.c_float()
