@@ -154,8 +154,10 @@ __device__ __forceinline__ void ln_bwd_tail(f32x4 (&dxn)[GD][NRT], f32x4 (&xv)[G
 // KCA > 0: the adjust 1x1 conv's data gradient runs first, in the same launch (KCA = 32-wide k chunks of its output
 // channels: 1 for the 32-channel adjust1-4, 6 for adjust5's 180): dx2 = alpha * (dA (.) lrelu'(y)) . Wadj is computed from
 // the [FM][<=192] gradient tile, written out (fc2's weight gradient reads it) and kept on chip as this kernel's input.
-template <int FM, int GD, int KGD, int GM, int KGM, int KCA>
+// KCD / KCM = exact 32-wide k chunks of the block dim / hidden (a stage loads and multiplies only its real chunks).
+template <int FM, int GD, int KCD, int GM, int KCM, int KCA>
 __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, float* __restrict__ part) {
+  constexpr int KGD = (KCD + 7) / 8, KGM = (KCM + 7) / 8;       // 256-wide k groups
   constexpr int NRT = FM / 16;
   constexpr int LDAA = KCA * 32 + 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -169,31 +171,32 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
   const int fr = lane & 15, fq = lane >> 4;
   const int m0 = blockIdx.x * FM;
   const int d = p.d, m = p.m;
-  const int Kd = (d + 31) & ~31, Km = (m + 31) & ~31;
   constexpr int n_adj = KCA > 0 ? GD : 0, n_fc2 = GM * KGD, n_fc1 = GD * KGM, n_stages = n_adj + n_fc2 + n_fc1;
 
   // waves whose 16 output columns are all padding skip their weight loads and MFMAs (see mlp_block_kernel)
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-  auto stage_ptr = [&](int s, int& Kp, int& nch, bool& live) -> const char* {
-    s = min(s, n_stages - 1);
-    const char* w; int kgs, nreal;
-    if (s < n_adj) { w = (const char*)p.w_adjt; Kp = KCA * 32; kgs = 1; nreal = d; }
-    else if ((s -= n_adj) < n_fc2) { w = (const char*)p.w_fc2t; Kp = Kd; kgs = KGD; nreal = m; }
-    else { s -= n_fc2; w = (const char*)p.w_fc1t; Kp = Km; kgs = KGM; nreal = d; }
+  // stage s: phase (-1 adjust, 0 fc2^T, 1 fc1^T), 128-column group g, 256-wide k group kg - all compile-time
+  struct StageGeo { int ph, g, kg, nch, kc; };
+  auto geo = [](int s) constexpr -> StageGeo {
+    if (s > n_stages - 1) s = n_stages - 1;
+    int ph = 0, kgs = 1, kc = 1;
+    if (s < n_adj) { ph = -1; kgs = 1; kc = KCA; }
+    else if ((s -= n_adj) < n_fc2) { ph = 0; kgs = KGD; kc = KCD; }
+    else { s -= n_fc2; ph = 1; kgs = KGM; kc = KCM; }
     const int g = s / kgs, kg = s - g * kgs;
-    live = (g * 8 + wave_s) * 16 < nreal;
-    nch = min(8, (Kp >> 5) - kg * 8);
-    return w + ((size_t)(g * 8 + wave) * (Kp >> 5) + kg * 8) * 1024;
+    const int nch = kc - kg * 8 < 8 ? kc - kg * 8 : 8;
+    return StageGeo{ph, g, kg, nch, kc};
   };
   constexpr int NSETS = 3;
   u32x4 w_reg[NSETS][8];
-  auto load_w = [&](int s, u32x4 (&reg)[8]) {
-    int Kp, nch;
-    bool live;
-    const char* base = stage_ptr(s, Kp, nch, live) + fr * 64 + fq * 16;
-    if (live) {
+  auto load_w = [&](auto S, u32x4 (&reg)[8]) {
+    constexpr StageGeo sg = geo(decltype(S)::value);
+    const char* w = (const char*)(sg.ph == -1 ? p.w_adjt : (sg.ph == 0 ? p.w_fc2t : p.w_fc1t));
+    const int nreal = sg.ph == 0 ? m : d;
+    const char* base = w + ((size_t)(sg.g * 8 + wave) * sg.kc + sg.kg * 8) * 1024 + fr * 64 + fq * 16;
+    if ((sg.g * 8 + wave_s) * 16 < nreal) {
 #pragma unroll
-      for (int cc = 0; cc < 8; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + (cc < nch ? cc : 0) * 1024);
+      for (int cc = 0; cc < sg.nch; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + cc * 1024);
     }
   };
   auto mma_stage = [&](const __bf16* A, int lda, int k0, int nch, const u32x4 (&reg)[8], f32x4 (&c)[NRT]) {
@@ -233,8 +236,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
       a_reg[j] = *reinterpret_cast<const f32x4*>(p.dx2 + (size_t)(m0 + row) * d + min(c, d - 4));
     }
   }
-#pragma unroll
-  for (int q = 0; q < NSETS; ++q) load_w(q, w_reg[q]);
+  static_for<0, NSETS>([&](auto Q) { load_w(Q, w_reg[decltype(Q)::value]); });
   const float gq = tid < 384 ? p.ln_g[min(tid, d - 1)] : 0.f;
   float rs2v[NRT];
 #pragma unroll
@@ -291,8 +293,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
     constexpr int kgs = ph == -1 ? 1 : (ph == 0 ? KGD : KGM);
     constexpr int g = ls / kgs, kg = ls - g * kgs;
     u32x4 (&reg)[8] = w_reg[s % NSETS];
-    const int Kp = ph == -1 ? KCA * 32 : (ph == 0 ? Kd : Km);
-    const int nch = min(8, (Kp >> 5) - kg * 8);
+    constexpr int kc = ph == -1 ? KCA : (ph == 0 ? KCD : KCM);
+    constexpr int nch = kc - kg * 8 < 8 ? kc - kg * 8 : 8;
     if constexpr (ls == 0) __syncthreads();            // the phase's activation tile (Aa / A1 / Hs) is complete
     if constexpr (kg == 0) {
 #pragma unroll
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
     }
     if ((g * 8 + wave_s) * 16 < (ph == 0 ? m : d))
       mma_stage(ph == -1 ? Aa : (ph == 0 ? A1 : Hs), ph == -1 ? LDAA : (ph == 0 ? FB_LDA : FB_LDH), kg * 256, nch, reg, c);
-    load_w(s + NSETS, reg);
+    load_w(std::integral_constant<int, s + NSETS>{}, reg);
     if constexpr (kg == kgs - 1) {
       if constexpr (ph == -1) {                        // dx2 = alpha * dA . Wadj: residual registers, global copy, bf16 A tile
         const int c4 = col4_of(g);
@@ -332,20 +334,19 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
   // ---- optional epilogue phase: the attention projection's data gradient dO = (dx1 . Wproj) * rs1 from the dx1 rows
   //      just produced (bf16 tile in A1); its first weight stages are in flight during the LayerNorm arithmetic ----
   constexpr int n_proj = GD * KGD;
-  auto load_wp = [&](int s, u32x4 (&reg)[8]) {
-    s = min(s, n_proj - 1);
-    const int g = s / KGD, kg = s - g * KGD;
-    const int nch = min(8, (Kd >> 5) - kg * 8);
-    const char* base = (const char*)p.w_projt + ((size_t)(g * 8 + wave) * (Kd >> 5) + kg * 8) * 1024 + fr * 64 + fq * 16;
+  auto load_wp = [&](auto S, u32x4 (&reg)[8]) {
+    constexpr int sc = decltype(S)::value < n_proj - 1 ? decltype(S)::value : n_proj - 1;
+    constexpr int g = sc / KGD, kg = sc - g * KGD;
+    constexpr int nch = KCD - kg * 8 < 8 ? KCD - kg * 8 : 8;
+    const char* base = (const char*)p.w_projt + ((size_t)(g * 8 + wave) * KCD + kg * 8) * 1024 + fr * 64 + fq * 16;
     if ((g * 8 + wave_s) * 16 < d) {
 #pragma unroll
-      for (int cc = 0; cc < 8; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + (cc < nch ? cc : 0) * 1024);
+      for (int cc = 0; cc < nch; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + cc * 1024);
     }
   };
   float rs1v[NRT];
   if (p.w_projt) {
-#pragma unroll
-    for (int q = 0; q < NSETS; ++q) load_wp(q, w_reg[q]);
+    static_for<0, NSETS>([&](auto Q) { load_wp(Q, w_reg[decltype(Q)::value]); });
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt) rs1v[rt] = p.rs1 ? p.rs1[(m0 + rt * 16 + fr) / p.rps] : 1.f;
   }
@@ -357,13 +358,13 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
       constexpr int s = decltype(S)::value;
       constexpr int g = s / KGD, kg = s - g * KGD;
       u32x4 (&reg)[8] = w_reg[s % NSETS];
-      const int nch = min(8, (Kd >> 5) - kg * 8);
+      constexpr int nch = KCD - kg * 8 < 8 ? KCD - kg * 8 : 8;
       if constexpr (kg == 0) {
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt) c[rt] = z4;
       }
       if ((g * 8 + wave_s) * 16 < d) mma_stage(A1, FB_LDA, kg * 256, nch, reg, c);
-      load_wp(s + NSETS, reg);
+      load_wp(std::integral_constant<int, s + NSETS>{}, reg);
       if constexpr (kg == KGD - 1) {
         const int c4 = col4_of(g);
         if (c4 < d) {
@@ -380,8 +381,9 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
 // dX = dY . W (K up to 4 x 256) + LayerNorm backward + residual: the qkv Linear / LayerNorm1 end of a Swin block.
 // GD = 128-column groups of d, KG = 256-wide k groups of K.
 // ------------------------------------------------------------------------------------------
-template <int FM, int GD, int KG>
+template <int FM, int GD, int KC>
 __global__ __launch_bounds__(512) void lin_ln_bwd_kernel(const LinLnBwdParams p, float* __restrict__ part) {
+  constexpr int KG = (KC + 7) / 8;                               // KC = exact 32-wide k chunks of K
   constexpr int NRT = FM / 16;
   constexpr int LDA = KG * 256 + 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -393,26 +395,24 @@ __global__ __launch_bounds__(512) void lin_ln_bwd_kernel(const LinLnBwdParams p,
   const int fr = lane & 15, fq = lane >> 4;
   const int m0 = blockIdx.x * FM;
   const int d = p.d, K = p.K;
-  const int Kp = (K + 31) & ~31;
   constexpr int n_stages = GD * KG;
   const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
 
   constexpr int NSETS = 3;
   u32x4 w_reg[NSETS][8];
-  auto load_w = [&](int s, u32x4 (&reg)[8]) {
-    s = min(s, n_stages - 1);
-    const int g = s / KG, kg = s - g * KG;
-    const int nch = min(8, (Kp >> 5) - kg * 8);
-    const char* base = (const char*)p.w_t + ((size_t)(g * 8 + wave) * (Kp >> 5) + kg * 8) * 1024 + fr * 64 + fq * 16;
+  auto load_w = [&](auto S, u32x4 (&reg)[8]) {
+    constexpr int sc = decltype(S)::value < n_stages - 1 ? decltype(S)::value : n_stages - 1;
+    constexpr int g = sc / KG, kg = sc - g * KG;
+    constexpr int nch = KC - kg * 8 < 8 ? KC - kg * 8 : 8;
+    const char* base = (const char*)p.w_t + ((size_t)(g * 8 + wave) * KC + kg * 8) * 1024 + fr * 64 + fq * 16;
     if ((g * 8 + wave_s) * 16 < d) {                 // all-padding column tiles: no loads, no MFMAs (see mlp_block_kernel)
 #pragma unroll
-      for (int cc = 0; cc < 8; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + (cc < nch ? cc : 0) * 1024);
+      for (int cc = 0; cc < nch; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + cc * 1024);
     }
   };
   auto col4_of = [&](int g) { return FB_SC * g + 16 * wave + 4 * fq; };
-#pragma unroll
-  for (int q = 0; q < NSETS; ++q) load_w(q, w_reg[q]);
+  static_for<0, NSETS>([&](auto Q) { load_w(Q, w_reg[decltype(Q)::value]); });
   const float gq = tid < 384 ? p.ln_g[min(tid, d - 1)] : 0.f;
   f32x4 r2[GD][NRT], xv[GD][NRT];
 #pragma unroll
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(512) void lin_ln_bwd_kernel(const LinLnBwdParams p,
     constexpr int s = decltype(S)::value;
     constexpr int g = s / KG, kg = s - g * KG;
     u32x4 (&reg)[8] = w_reg[s % NSETS];
-    const int nch = min(8, (Kp >> 5) - kg * 8);
+    constexpr int nch = KC - kg * 8 < 8 ? KC - kg * 8 : 8;
     if constexpr (kg == 0) {
 #pragma unroll
       for (int rt = 0; rt < NRT; ++rt) c[rt] = z4;
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(512) void lin_ln_bwd_kernel(const LinLnBwdParams p,
         }
       }
     }
-    load_w(s + NSETS, reg);
+    load_w(std::integral_constant<int, s + NSETS>{}, reg);
     if constexpr (kg == KG - 1) {
 #pragma unroll
       for (int rt = 0; rt < NRT; ++rt) dxn[g][rt] = c[rt];
@@ -488,10 +488,11 @@ __global__ __launch_bounds__(512) void lin_ln_bwd_kernel(const LinLnBwdParams p,
                        part + (size_t)blockIdx.x * (2 * SRAD_LNB_CP));
 }
 
-template <int FM, int GD, int KG>
+template <int FM, int GD, int KC>
 int launch_lin_fm(const LinLnBwdParams& p, WgradQueue& q, hipStream_t stream) {
+  constexpr int KG = (KC + 7) / 8;
   constexpr size_t lds = (size_t)FM * (KG * 256 + 8) * 2 + (384 + FM * 16) * sizeof(float);
-  auto kern = lin_ln_bwd_kernel<FM, GD, KG>;
+  auto kern = lin_ln_bwd_kernel<FM, GD, KC>;
   static bool configured = false;
   if (!configured) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -504,24 +505,23 @@ int launch_lin_fm(const LinLnBwdParams& p, WgradQueue& q, hipStream_t stream) {
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
 }
-template <int GD, int KG>
+template <int GD, int KC>
 int launch_lin(const LinLnBwdParams& p, WgradQueue& q, hipStream_t stream) {
-  if (p.M >= 8192 && p.M % 32 == 0) return launch_lin_fm<32, GD, KG>(p, q, stream);
-  return launch_lin_fm<16, GD, KG>(p, q, stream);
+  if (p.M >= 8192 && p.M % 32 == 0) return launch_lin_fm<32, GD, KC>(p, q, stream);
+  return launch_lin_fm<16, GD, KC>(p, q, stream);
 }
-// (128-column groups of d, 256-wide k groups of K = 3 d) of DRCT-L's Swin blocks: d = 180 .. 308
-#define SRAD_LIN_CFGS(X) X(2, 3) X(3, 4)
+// (128-column groups of d, 32-wide k chunks of K = 3 d) of DRCT-L's Swin blocks: d = 180, 212, 244, 276, 308
+#define SRAD_LIN_CFGS(X) X(2, 17) X(2, 20) X(2, 23) X(3, 26) X(3, 29)
 
-struct BwdCfg { int gd, kgd, gm, kgm, kca; };
+struct BwdCfg { int gd, kcd, gm, kcm, kca; };
 inline BwdCfg bwd_cfg(int d, int m, int KA) {
-  const int Kd = srad_cp(d), Km = srad_cp(m);
-  return BwdCfg{(d + FB_SC - 1) / FB_SC, (Kd + 255) / 256, (m + FB_SC - 1) / FB_SC, (Km + 255) / 256, (KA + 31) / 32};
+  return BwdCfg{(d + FB_SC - 1) / FB_SC, srad_cp(d) / 32, (m + FB_SC - 1) / FB_SC, srad_cp(m) / 32, (KA + 31) / 32};
 }
-template <int FM, int GD, int KGD, int GM, int KGM, int KCA>
+template <int FM, int GD, int KCD, int GM, int KCM, int KCA>
 int launch_bwd_fm(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream) {
   constexpr size_t lds = (size_t)(FM * FB_LDA + FM * FB_LDH) * 2 + (384 + FM * 16) * sizeof(float) +
                          (KCA > 0 ? (size_t)FM * (KCA * 32 + 8) * 2 : 0);
-  auto kern = mlp_bwd_kernel<FM, GD, KGD, GM, KGM, KCA>;
+  auto kern = mlp_bwd_kernel<FM, GD, KCD, GM, KCM, KCA>;
   static bool configured = false;
   if (!configured) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -535,14 +535,16 @@ int launch_bwd_fm(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream) {
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
 }
-template <int GD, int KGD, int GM, int KGM, int KCA>
+template <int GD, int KCD, int GM, int KCM, int KCA>
 int launch_bwd(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream) {
-  if (p.M >= 8192 && p.M % 32 == 0) return launch_bwd_fm<32, GD, KGD, GM, KGM, KCA>(p, q, stream);
-  return launch_bwd_fm<16, GD, KGD, GM, KGM, KCA>(p, q, stream);
+  if (p.M >= 8192 && p.M % 32 == 0) return launch_bwd_fm<32, GD, KCD, GM, KCM, KCA>(p, q, stream);
+  return launch_bwd_fm<16, GD, KCD, GM, KCM, KCA>(p, q, stream);
 }
 // stage geometries of DRCT-L's Swin blocks (embed 180 + k*32; mlp ratio 2, 2, 2, 1, 1); last number: 32-wide chunks of
 // the adjust conv's output channels when its data gradient is part of the launch (adjust1-4: 32, adjust5: 180), 0 = not
-#define SRAD_BWD_CFGS(X) X(2, 1, 3, 2, 0) X(2, 1, 4, 2, 0) X(3, 2, 3, 2, 0) X(2, 1, 3, 2, 1) X(2, 1, 4, 2, 1) X(3, 2, 3, 2, 1) X(3, 2, 3, 2, 6)
+#define SRAD_BWD_CFGS(X) \
+  X(2, 6, 3, 12, 0) X(2, 7, 4, 14, 0) X(2, 8, 4, 16, 0) X(3, 9, 3, 9, 0) X(3, 10, 3, 10, 0) \
+  X(2, 6, 3, 12, 1) X(2, 7, 4, 14, 1) X(2, 8, 4, 16, 1) X(3, 9, 3, 9, 1) X(3, 10, 3, 10, 6)
 }  // namespace
 
 bool srad_mlp_bwd_supported(int prec, int M, int d, int m, int KA) {
@@ -550,7 +552,7 @@ bool srad_mlp_bwd_supported(int prec, int M, int d, int m, int KA) {
         KA >= 0 && KA % 4 == 0))
     return false;
   const BwdCfg c = bwd_cfg(d, m, KA);
-#define X(a, b, cc, dd, e) if (c.gd == a && c.kgd == b && c.gm == cc && c.kgm == dd && c.kca == e) return true;
+#define X(a, b, cc, dd, e) if (c.gd == a && c.kcd == b && c.gm == cc && c.kcm == dd && c.kca == e) return true;
   SRAD_BWD_CFGS(X)
 #undef X
   return false;
@@ -568,7 +570,7 @@ int srad_launch_mlp_bwd(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream
                  "mlp_bwd: the adjust gradient rows must be float4-addressable");
   }
   const BwdCfg c = bwd_cfg(p.d, p.m, p.KA);
-#define X(a, b, cc, dd, e) if (c.gd == a && c.kgd == b && c.gm == cc && c.kgm == dd && c.kca == e) return launch_bwd<a, b, cc, dd, e>(p, q, stream);
+#define X(a, b, cc, dd, e) if (c.gd == a && c.kcd == b && c.gm == cc && c.kcm == dd && c.kca == e) return launch_bwd<a, b, cc, dd, e>(p, q, stream);
   SRAD_BWD_CFGS(X)
 #undef X
   return srad_set_error(SRAD_ERR_ARG, "mlp_bwd: no kernel instance for this geometry");
@@ -576,8 +578,8 @@ int srad_launch_mlp_bwd(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream
 
 bool srad_lin_ln_bwd_supported(int prec, int M, int K, int d) {
   if (!(prec == SRAD_PREC_BF16 && M % 16 == 0 && d % 4 == 0 && K % 4 == 0 && d >= 32 && d <= SRAD_LNB_CP && K >= 32 && K <= 1024)) return false;
-  const int gd = (d + FB_SC - 1) / FB_SC, kg = (srad_cp(K) + 255) / 256;
-#define X(a, b) if (gd == a && kg == b) return true;
+  const int gd = (d + FB_SC - 1) / FB_SC, kc = srad_cp(K) / 32;
+#define X(a, b) if (gd == a && kc == b) return true;
   SRAD_LIN_CFGS(X)
 #undef X
   return false;
@@ -589,8 +591,8 @@ int srad_launch_lin_ln_bwd(const LinLnBwdParams& p, WgradQueue& q, hipStream_t s
   SRAD_REQUIRE(((p.ld_dy | p.ldx | p.ld_out | (p.dres ? p.ld_dres : 0)) & 3) == 0 &&
                    (((uintptr_t)p.dY | (uintptr_t)p.x | (uintptr_t)p.out | (uintptr_t)p.dres) & 15) == 0,
                "lin_ln_bwd: rows must be 16-byte aligned (strides multiples of 4 floats)");
-  const int gd = (p.d + FB_SC - 1) / FB_SC, kg = (srad_cp(p.K) + 255) / 256;
-#define X(a, b) if (gd == a && kg == b) return launch_lin<a, b>(p, q, stream);
+  const int gd = (p.d + FB_SC - 1) / FB_SC, kc = srad_cp(p.K) / 32;
+#define X(a, b) if (gd == a && kc == b) return launch_lin<a, b>(p, q, stream);
   SRAD_LIN_CFGS(X)
 #undef X
   return srad_set_error(SRAD_ERR_ARG, "lin_ln_bwd: no kernel instance for this geometry");
