@@ -94,7 +94,7 @@ int forward_body(srad_drct* h, const float* x, int B, int H, int W, float* y, co
         // (drct.py:477-504, 278-299)
         QkvAttnParams a{};
         a.x = cur; a.ldx = D; a.ln_g = h->pt.fptr(sw.n1g); a.ln_b = h->pt.fptr(sw.n1b);
-        a.w_qkv = h->pt.ptr(sw.qkv.w); a.b_qkv = h->pt.fptr(sw.qkv.b); a.table = h->pt.fptr(sw.table);
+        a.w_qkv = h->pt.frag_ptr(sw.qkv.w); a.b_qkv = h->pt.fptr(sw.qkv.b); a.table = h->pt.fptr(sw.table);
         a.out = w.attn; a.ld_out = d; a.B = B; a.H = H; a.W = W; a.shift = sw.shift; a.d = d; a.heads = sw.heads;
         SRAD_TRY(srad_launch_qkv_attn(a, s));
       } else {
@@ -240,6 +240,7 @@ int srad_drct_create(const srad_drct_config* cfg, srad_drct_t** out) {
       sw.table = h->pt.add_raw(p + "attn.relative_position_bias_table", (int64_t)(2 * ws - 1) * (2 * ws - 1) * sw.heads);
       sw.qkv = h->pt.add_layer(p + "attn.qkv", 3 * sw.d, sw.d, 1, true);
       if (cfg->precision == SRAD_PREC_BF16) h->pt.entries[sw.qkv.w].tfrag = true;   // operand of the fused qkv + LayerNorm1 backward
+      if (cfg->precision == SRAD_PREC_BF16 && sw.d % sw.heads == 0) h->pt.add_qkv_frag(sw.qkv, sw.d, sw.heads);   // fused attention kernel
       const bool frag = cfg->precision == SRAD_PREC_BF16;      // operands of the fused second half (kernels_fused.hip)
       sw.proj = frag ? h->pt.add_layer_frag(p + "attn.proj", sw.d, sw.d, true) : h->pt.add_layer(p + "attn.proj", sw.d, sw.d, 1, true);
       sw.n2g = h->pt.add_raw(p + "norm2.weight", sw.d);

@@ -217,7 +217,7 @@ int srad_drct_forward_train(srad_drct_t* h, const float* x, int B, int H, int W,
         // (LN1(x), q|k|v, x + attn, LN2(.), fc1 pre-activation, GELU(.), block output) and apply DropPath
         QkvAttnParams a{};
         a.x = cur; a.ldx = D; a.ln_g = h->pt.fptr(sw.n1g); a.ln_b = h->pt.fptr(sw.n1b);
-        a.w_qkv = h->pt.ptr(sw.qkv.w); a.b_qkv = h->pt.fptr(sw.qkv.b); a.table = h->pt.fptr(sw.table);
+        a.w_qkv = h->pt.frag_ptr(sw.qkv.w); a.b_qkv = h->pt.fptr(sw.qkv.b); a.table = h->pt.fptr(sw.table);
         a.out = sv.attn; a.ld_out = d; a.B = B; a.H = H; a.W = W; a.shift = sw.shift; a.d = d; a.heads = sw.heads;
         a.save_xn = sv.xn1; a.save_qkv = sv.qkv; a.hdp = hdp;
         SRAD_TRY(srad_launch_qkv_attn(a, s));

@@ -15,6 +15,7 @@ struct ParamEntry {
   int n_pad = 0, grp_real = 0, grp_pad = 0;   // optional padding (srad_launch_pack_weight_padded)
   long long frag_off = -1;                    // >= 0: second copy as bf16 MFMA fragments (srad_launch_pack_weight_frag)
   bool tfrag = false;                         // training: keep W^T as bf16 MFMA fragments too (fused backward kernels)
+  int qkv_heads = 0;                          // > 0: frag_off holds the per-head [q | k | v] fragment pack (srad_launch_pack_qkv_frag)
 };
 
 struct ConvW {       // one Linear / conv layer
@@ -81,6 +82,12 @@ struct ParamTable {
     bytes += srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, n, cin, 1), 256);
     return c;
   }
+  // qkv Linear of a Swin block that is also kept as per-head fragments (the fused attention kernel's operand)
+  void add_qkv_frag(const ConvW& c, int d, int heads) {
+    entries[c.w].frag_off = (long long)bytes;
+    entries[c.w].qkv_heads = heads;
+    bytes += srad_align_up(srad_qkv_frag_bytes(d, heads), 256);
+  }
   const void* ptr(int idx) const { return idx < 0 ? nullptr : arena + entries[idx].off; }
   const void* frag_ptr(int idx) const { return idx < 0 || entries[idx].frag_off < 0 ? nullptr : arena + entries[idx].frag_off; }
   const float* fptr(int idx) const { return reinterpret_cast<const float*>(ptr(idx)); }
@@ -94,7 +101,8 @@ struct ParamTable {
       return srad_set_error(SRAD_ERR_ARG, "set_param(%s): got %lld elements, expected %lld", name, (long long)numel,
                             (long long)e.numel);
     if (e.packed) {
-      if (e.frag_off >= 0) SRAD_TRY(srad_launch_pack_weight_frag(src, arena + e.frag_off, e.n, e.cin, s));
+      if (e.frag_off >= 0 && e.qkv_heads > 0) SRAD_TRY(srad_launch_pack_qkv_frag(src, arena + e.frag_off, e.cin, e.qkv_heads, s));
+      else if (e.frag_off >= 0) SRAD_TRY(srad_launch_pack_weight_frag(src, arena + e.frag_off, e.n, e.cin, s));
       return srad_launch_pack_weight_padded(prec, src, arena + e.off, e.n, e.cin, e.ntaps, e.n_pad > 0 ? e.n_pad : e.n, e.grp_real, e.grp_pad, s);
     }
     if (e.n_pad > numel) SRAD_CHECK_HIP(hipMemsetAsync(arena + e.off, 0, (size_t)e.n_pad * 4, s));

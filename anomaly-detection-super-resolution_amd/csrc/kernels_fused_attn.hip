@@ -6,7 +6,8 @@
 //
 // with the cyclic shift / window partition / reverse (drct.py:482-504) as token index arithmetic.
 // The window's 64 tokens (window size 8) are gathered once, normalised in registers, and stay in LDS as
-// the A operand; the head's three weight slices are streamed through a 64-row LDS stage buffer; q, k, v
+// the A operand; the head's three weight slices stream from a per-head fragment pack straight into MFMA
+// registers (no LDS weight stage: 33.8 KB less LDS, two workgroups per CU for the 6-head blocks); q, k, v
 // never exist in HBM.  This replaces the LN1+QKV GEMM launch, its [T][3d] round trip and the attention
 // launch.  Same rules as kernels_gemm.hip / kernels_fused.hip (unconditional clamped loads, selects for
 // padding, template-unrolled stages, transposed MFMA results so a lane owns 4 consecutive columns).
@@ -23,7 +24,6 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-constexpr int QA_LDW = 264;    // weight stage row stride
 constexpr int QA_LDP = 72;     // probability tile row stride
 
 // HDT = ceil(head_dim / 16) (2, 3, 4, 5 or 8), KC = ceil(d / 32) 32-wide k chunks (<= 10)
@@ -35,14 +35,13 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
   constexpr int HDP32 = (HDP + 31) & ~31;  // k extent of the q.k^T MFMA steps
   constexpr int HS = HDP32 + 8;            // q/k/v LDS row stride
   constexpr int NV = 3 * HDP;              // virtual output columns [q | k | v]
-  constexpr int NS = (NV + 63) / 64;       // 64-column stages
+  constexpr int NS = (NV + 127) / 128;     // 128-column stages: each of the 8 waves owns 16 of them
   constexpr int n_stages = NS * KG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* XN = reinterpret_cast<__bf16*>(smem);                 // [64][QA_LDX]
   __bf16* QKV = XN + 64 * QA_LDX;                               // [3][64][HS]
-  __bf16* Ws = QKV + 3 * 64 * HS;                               // [64][QA_LDW] weight stage
-  __bf16* Ps = Ws;                                              // [64][QA_LDP] probabilities (after the GEMM)
-  float* v_g = reinterpret_cast<float*>(Ws + 64 * QA_LDW);      // [320] gamma
+  __bf16* Ps = QKV + 3 * 64 * HS;                               // [64][QA_LDP] probabilities
+  float* v_g = reinterpret_cast<float*>(Ps + 64 * QA_LDP);      // [320] gamma
   float* v_b = v_g + 320;                                       // [320] beta
   float* v_bias = v_b + 320;                                    // [3][HDP] q|k|v bias of this head (0 in padding)
   float* tbl = v_bias + 3 * HDP;                                // [225] relative position bias of this head
@@ -52,9 +51,9 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const int rt = wave & 3, chh = wave >> 2;                     // GEMM: row tile, 32-column half of a stage
+  const int rt = wave & 3, chh = wave >> 2;                     // P.V: row tile, column-tile parity
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const int d = p.d, heads = p.heads, hd = d / heads;
-  constexpr int Kp = KC * 32;
   // grid = (windows, heads): linear ids of one window's heads differ by a multiple of 8 when the window
   // count is, so they share an XCD and the window's x rows are fetched into one L2 only
   const int h = blockIdx.y, win = blockIdx.x;
@@ -75,28 +74,22 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
   }
   __syncthreads();
 
-  // ---- weight stages: 64 virtual rows [q_h | k_h | v_h], each slice padded to HDP rows ----
+  // ---- weights: the head's 3 * HDP virtual rows [q_h | k_h | v_h] as fragments (srad_launch_pack_qkv_frag).  A wave owns 16
+  //      virtual columns of a 128-column stage for all 64 tokens and NOBODY else reads their weights, so they go straight
+  //      from global memory into MFMA operand registers, three stages ahead, issued before the window is even gathered:
+  //      no LDS weight stage, no barrier per stage (as in mlp_block_kernel). ----
   constexpr int NSETS = 3;
-  u32x4 w_reg[NSETS][4];
-  const int w_seg = tid & 31, w_row = tid >> 5;                 // virtual rows w_row + 16*j (j < 4)
-  const char* const Wb = reinterpret_cast<const char*>(p.w_qkv);
-  auto load_w = [&](int s, u32x4 (&reg)[4]) {
-    s = min(s, n_stages - 1);
-    const int st = s / KG, kg = s - st * KG;
-    const int nch = min(8, KC - kg * 8);
-    const int seg = w_seg < nch * 4 ? w_seg : 0;
+  u32x4 w_reg[NSETS][8];
+  const char* const Wh = reinterpret_cast<const char*>(p.w_qkv) + (size_t)h * (NV / 16) * KC * 1024;
+  auto load_w = [&](auto S, u32x4 (&reg)[8]) {
+    constexpr int sc = decltype(S)::value < n_stages - 1 ? decltype(S)::value : n_stages - 1;
+    constexpr int st = sc / KG, kg = sc - st * KG;
+    constexpr int nch = KC - kg * 8 < 8 ? KC - kg * 8 : 8;
+    const char* base = Wh + ((size_t)(st * 8 + wave) * KC + kg * 8) * 1024 + fr * 64 + fq * 16;
+    if ((st * 8 + wave_s) * 16 < NV) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int vr = st * 64 + w_row + 16 * j;
-      const int which = min(vr / HDP, 2), c = min(vr - (vr / HDP) * HDP, hd - 1);
-      const int row = which * d + h * hd + c;
-      reg[j] = *reinterpret_cast<const u32x4*>(Wb + ((size_t)row * Kp + kg * 256) * 2 + seg * 16);
+      for (int cc = 0; cc < nch; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + cc * 1024);
     }
-  };
-  auto store_w = [&](const u32x4 (&reg)[4]) {
-    char* dst = reinterpret_cast<char*>(Ws) + (w_row * QA_LDW) * 2 + w_seg * 16;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(dst + j * 16 * QA_LDW * 2) = reg[j];
   };
 
   // ---- issue the loads: window rows of x (gathered), first weight stages, vectors ----
@@ -107,8 +100,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
 #pragma unroll
     for (int j = 0; j < KC; ++j) a_reg[j] = *reinterpret_cast<const f32x4*>(src + (unsigned)min(j * 32 + col4 * 4, d - 4) * 4u);
   }
-#pragma unroll
-  for (int q = 0; q < NSETS; ++q) load_w(q, w_reg[q]);
+  static_for<0, NSETS>([&](auto Q) { load_w(Q, w_reg[decltype(Q)::value]); });
   {
     // gamma | beta (320 each), bias (3*HDP), table (225): <= 640 + 384 + 225 = 1249 values, 3 per thread
     float vq[3];
@@ -165,48 +157,48 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
       *reinterpret_cast<bf16x4*>(XN + xrow * QA_LDX + c) = hh;
     }
   }
+  __syncthreads();                                                // the normalised window is in LDS
 
-  // ---- q|k|v = xn . W^T : stages of 64 virtual columns, transposed result (lane: token fr, 4 columns) ----
-  f32x4 acc[2];
+  // ---- q|k|v = xn . W^T : 128 virtual columns per stage, transposed result (lane: token fr of row tile t, 4 columns) ----
+  f32x4 acc[4];
   static_for<0, n_stages>([&](auto S) {
     constexpr int s = decltype(S)::value;
     constexpr int st = s / KG, kg = s - st * KG;
-    u32x4 (&reg)[4] = w_reg[s % NSETS];
+    u32x4 (&reg)[8] = w_reg[s % NSETS];
     constexpr int nch = KC - kg * 8 < 8 ? KC - kg * 8 : 8;
-    store_w(reg);
-    __syncthreads();
-    load_w(s + NSETS, reg);
-    if constexpr (kg == 0) { acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0]; }
-    {
-      const __bf16* ar = XN + (rt * 16 + fr) * QA_LDX + kg * 256 + 8 * fq;
-      const __bf16* wr = Ws + (chh * 32 + fr) * QA_LDW + 8 * fq;
+    const bool live = (st * 8 + wave_s) * 16 < NV;
+    if constexpr (kg == 0) {
 #pragma unroll
-      for (int cc = 0; cc < 8; ++cc) {
-        if (cc < nch) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + cc * 32);
-          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wr + cc * 32);
-          const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wr + 16 * QA_LDW + cc * 32);
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, a, acc[1], 0, 0, 0);
+      for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (live) {
+      const __bf16* ar = XN + fr * QA_LDX + kg * 256 + 8 * fq;
+#pragma unroll
+      for (int cc = 0; cc < nch; ++cc) {
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, reg[cc]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + t * 16 * QA_LDX + cc * 32);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, acc[t], 0, 0, 0);
         }
       }
     }
-    __syncthreads();
+    load_w(std::integral_constant<int, s + NSETS>{}, reg);
     if constexpr (kg == KG - 1) {
+      if (live) {
+        const int vc = (st * 8 + wave) * 16 + 4 * fq;             // virtual column of element 0
+        const int which = vc / HDP, c = vc - which * HDP;         // HDP % 16 == 0: the wave's 16 columns stay in one slice
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(v_bias + which * HDP + c);
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const int vc = st * 64 + chh * 32 + ct * 16 + 4 * fq;     // virtual column of element 0
-        if (vc < NV) {
-          const int which = vc / HDP, c = vc - which * HDP;       // HDP % 16 == 0: a quad stays in one slice
-          const f32x4 bias = *reinterpret_cast<const f32x4*>(v_bias + which * HDP + c);
-          f32x4 v = acc[ct] + bias;
+        for (int t = 0; t < 4; ++t) {
+          f32x4 v = acc[t] + bias;
           if (p.save_qkv && c < p.hdp)
-            *reinterpret_cast<f32x4*>(p.save_qkv + (size_t)tok[rt * 16 + fr] * (3 * heads * p.hdp) + (which * heads + h) * p.hdp + c) = v;
+            *reinterpret_cast<f32x4*>(p.save_qkv + (size_t)tok[t * 16 + fr] * (3 * heads * p.hdp) + (which * heads + h) * p.hdp + c) = v;
           if (which == 0) v = v * scale;
           bf16x4 hh;
 #pragma unroll
           for (int e = 0; e < 4; ++e) hh[e] = (__bf16)(c + e < hd ? v[e] : 0.f);
-          *reinterpret_cast<bf16x4*>(QKV + (which * 64 + rt * 16 + fr) * HS + c) = hh;
+          *reinterpret_cast<bf16x4*>(QKV + (which * 64 + t * 16 + fr) * HS + c) = hh;
         }
       }
     }
@@ -294,7 +286,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
 template <int HDT, int KC>
 int launch_qa(const QkvAttnParams& p, hipStream_t stream) {
   constexpr int HDP = 16 * HDT, HS = ((HDP + 31) & ~31) + 8;
-  constexpr size_t lds = (size_t)(64 * (KC * 32 + 8) + 3 * 64 * HS + 64 * QA_LDW) * 2 +
+  constexpr size_t lds = (size_t)(64 * (KC * 32 + 8) + 3 * 64 * HS + 64 * QA_LDP) * 2 +
                          (size_t)(640 + 3 * HDP + 232 + 64) * sizeof(float) + 128 * sizeof(int);
   auto kern = qkv_attn_kernel<HDT, KC>;
   static bool configured = false;

@@ -472,6 +472,20 @@ __global__ void pack_weight_frag_kernel(const float* __restrict__ src, __bf16* _
   }
 }
 
+__global__ void pack_qkv_frag_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int d, int heads, int hd, int HDP, int Kp) {
+  const size_t total = (size_t)heads * 3 * HDP * Kp;
+  const int ktiles = Kp / 32, rtiles = 3 * HDP / 16;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int kin = (int)(i & 31), rin = (int)((i >> 5) & 15);
+    const size_t tile = i >> 9;
+    const int kt = (int)(tile % ktiles);
+    const int rg = (int)(tile / ktiles);
+    const int h = rg / rtiles, vr = (rg - h * rtiles) * 16 + rin;
+    const int which = vr / HDP, c = vr - which * HDP, k = kt * 32 + kin;
+    dst[i] = (__bf16)((c < hd && k < d) ? src[(size_t)(which * d + h * hd + c) * d + k] : 0.f);
+  }
+}
+
 template <int PREC, int BM, int BN, int WMV, int WNV, bool LN, bool CONV, bool SPECIAL, int CPS_ = 0>
 int launch_one(const GemmParams& p, hipStream_t s) {
   constexpr int CPS = CPS_ ? CPS_ : (PREC == SRAD_PREC_BF16 ? 8 : 4);
@@ -618,6 +632,16 @@ int srad_launch_pack_weight_frag_t(const float* src, void* dst, int n, int cin, 
   const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
   SradProfScope prof(stream, SRAD_K_PACK, 0.0, 4.0 * n * cin + 2.0 * total);
   hipLaunchKernelGGL(pack_weight_frag_kernel, dim3(blocks), dim3(256), 0, stream, src, reinterpret_cast<__bf16*>(dst), cin, n, Np, Kp, 1, cin);
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}
+
+int srad_launch_pack_qkv_frag(const float* src, void* dst, int d, int heads, hipStream_t stream) {
+  const int hd = d / heads, HDP = srad_qkv_hdp(d, heads), Kp = srad_cp(d);
+  const size_t total = (size_t)heads * 3 * HDP * Kp;
+  const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+  SradProfScope prof(stream, SRAD_K_PACK, 0.0, 12.0 * d * d + 2.0 * total);
+  hipLaunchKernelGGL(pack_qkv_frag_kernel, dim3(blocks), dim3(256), 0, stream, src, reinterpret_cast<__bf16*>(dst), d, heads, hd, HDP, Kp);
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
 }

@@ -143,6 +143,11 @@ int srad_launch_pack_weight_padded(int prec, const float* src, void* dst, int n,
 // Linear weights once more as bf16 MFMA fragments (16 x 32 tiles of 1 KB, tile-major): same byte size as the bf16 pack
 int srad_launch_pack_weight_frag(const float* src, void* dst, int n, int cin, hipStream_t stream);
 int srad_launch_pack_weight_frag_t(const float* src, void* dst, int n, int cin, hipStream_t stream);   // W^T: rows = cin, k = n
+// qkv.weight [3d][d] as per-head fragments: head h owns 3 * HDP virtual rows [q_h | k_h | v_h], each slice padded with zero
+// rows from head_dim to HDP = ceil16(head_dim); layout [head][virtual row / 16][k / 32][16 x 32] (1 KB tiles)
+static inline int srad_qkv_hdp(int d, int heads) { return srad_round_up(d / heads, 16); }
+static inline size_t srad_qkv_frag_bytes(int d, int heads) { return (size_t)heads * 3 * srad_qkv_hdp(d, heads) * srad_cp(d) * 2; }
+int srad_launch_pack_qkv_frag(const float* src, void* dst, int d, int heads, hipStream_t stream);
 // Data-gradient operand: the same tensor packed as the weight of the transposed convolution,
 // dst[c][8 - tap][n] (taps mirrored for 3x3, identity for 1x1), geometry (rows cin_pad, columns n_pad).
 int srad_launch_pack_weight_transposed(int prec, const float* src, void* dst, int n, int cin, int ntaps, int n_pad,
@@ -189,7 +194,7 @@ int srad_launch_mlp_block(const MlpBlockParams& p, hipStream_t stream);
 struct QkvAttnParams {
   const float* x; int ldx;                 // block input rows [T][ldx] (columns [0, d) are read)
   const float *ln_g, *ln_b;
-  const void* w_qkv; const float* b_qkv;   // packed bf16 [ceil128(3d)][ceil32(d)], bias [3d]
+  const void* w_qkv; const float* b_qkv;   // per-head fragment pack (srad_launch_pack_qkv_frag), bias [3d]
   const float* table;                      // [225][heads]
   float* out; int ld_out;                  // attention output [T][d]
   int B, H, W, shift, d, heads;

@@ -25,6 +25,7 @@ struct SyncDesc {
   long long fdst_off;   // bytes into the forward arena of the fragment-major bf16 pack (-1: none)
   long long tfdst_off;  // bytes into the training arena of the fragment-major bf16 pack of the transposed weight (-1: none)
   int packed, n, cin, ntaps, Np, Cp, tRp, tKp;
+  int qkv_heads;        // > 0: the fragment pack at fdst_off is the per-head [q | k | v] layout
   long long numel;
   unsigned blk0, nblk;
 };
@@ -62,7 +63,20 @@ __global__ __launch_bounds__(256) void sync_params_kernel(const SyncDesc* __rest
     if (n < d.n && c < d.cin) v = src[((long long)n * d.cin + c) * d.ntaps + tap];
     dst[i] = (T)v;
   }
-  if (d.fdst_off >= 0) {                      // 16 x 32 tiles, tile-major (srad_launch_pack_weight_frag)
+  if (d.fdst_off >= 0 && d.qkv_heads > 0) {   // per-head [q | k | v] fragments (srad_launch_pack_qkv_frag)
+    __bf16* fdst = reinterpret_cast<__bf16*>(arena + d.fdst_off);
+    const int dd = d.cin, hd = dd / d.qkv_heads, HDP = (hd + 15) / 16 * 16;
+    const long long ptotal = (long long)d.qkv_heads * 3 * HDP * d.Cp;
+    const int ktiles = d.Cp / 32, rtiles = 3 * HDP / 16;
+    for (long long i = base + threadIdx.x; i < base + SYNC_EPB && i < ptotal; i += 256) {
+      const int kin = (int)(i & 31), rin = (int)((i >> 5) & 15);
+      const long long tile = i >> 9;
+      const int kt = (int)(tile % ktiles), rg = (int)(tile / ktiles);
+      const int h = rg / rtiles, vr = (rg - h * rtiles) * 16 + rin;
+      const int which = vr / HDP, c = vr - which * HDP, k = kt * 32 + kin;
+      fdst[i] = (__bf16)((c < hd && k < dd) ? src[(long long)(which * dd + h * hd + c) * dd + k] : 0.f);
+    }
+  } else if (d.fdst_off >= 0) {               // 16 x 32 tiles, tile-major (srad_launch_pack_weight_frag)
     __bf16* fdst = reinterpret_cast<__bf16*>(arena + d.fdst_off);
     const long long ptotal = (long long)d.Np * d.Cp;
     const int ktiles = d.Cp / 32;
@@ -160,8 +174,13 @@ inline int train_bind(const ParamTable& pt, TrainState& ts, void* train_arena, s
       d.tRp = srad_np(srad_round_up(e.cin, 4)); d.tKp = srad_cp(srad_round_up(e.n, 4));
       d.tdst_off = (long long)ts.t_off[i];
       d.tfdst_off = ts.tf_off[i];
+      d.qkv_heads = e.qkv_heads;
       const long long f = (long long)d.Np * d.ntaps * d.Cp, t = (long long)d.tRp * d.ntaps * d.tKp;
       work = f > t ? f : t;
+      if (e.qkv_heads > 0) {                   // the per-head pack can be longer than the plain one (head slices padded to 16)
+        const long long q = (long long)(srad_qkv_frag_bytes(e.cin, e.qkv_heads) / 2);
+        if (q > work) work = q;
+      }
     }
     d.blk0 = blk;
     d.nblk = (unsigned)((work + SYNC_EPB - 1) / SYNC_EPB);
