@@ -581,58 +581,94 @@ __global__ void zero_upsample_kernel(const float* __restrict__ dy, float* __rest
 
 // CALayer backward (src/drn.py:123-139) for all images of the batch in ONE workgroup (the work is C * C/16 MACs per
 // image): dgate = sum of the pool_dot partials; through the sigmoid, the two 1x1 convs and the ReLU back to the mean;
-// dpool[b][c] = dmean[c] / HW.  Weight / bias gradients are summed over the images in LDS and added to the flat
-// gradient buffer without atomics.
+// dpool[b][c] = dmean[c] / HW.  Weight / bias gradients are summed over the images in registers and added to the flat
+// gradient buffer without atomics.  The images are processed eight at a time with the work spread over (image, channel)
+// pairs and the two small weight matrices staged in LDS: the first version walked the images one after the other with
+// the C/16 hidden units on C/16 threads reading the weights from global memory - 94 us per launch, 80 launches per step.
+constexpr int CAB_G = 8;
 __global__ __launch_bounds__(256) void ca_bwd_kernel(const float* __restrict__ part, int nchunk, const float* __restrict__ pool,
                                                      const float* __restrict__ gate, float inv_hw, int B, int C, int Cr,
                                                      const float* __restrict__ w1, const float* __restrict__ b1,
                                                      const float* __restrict__ w2, float* __restrict__ dw1,
                                                      float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
                                                      float* __restrict__ dpool) {
-  __shared__ float mean[512], s[512], hid[64], dhid[64];
-  __shared__ float a_w1[512 * 8], a_w2[512 * 8];     // C * Cr <= 4096 entries each
-  __shared__ float a_b1[64], a_b2[512];
+  __shared__ float s[CAB_G][512], mean[CAB_G][512];
+  __shared__ float hid[CAB_G][64], dhid[CAB_G][64];
+  __shared__ float lw1[4096], lw2[4096], lb1[64];    // C * Cr <= 4096 entries each
   const int tid = threadIdx.x;
-  for (int i = tid; i < C * Cr; i += 256) { a_w1[i] = 0.f; a_w2[i] = 0.f; }
-  for (int i = tid; i < C; i += 256) a_b2[i] = 0.f;
-  if (tid < Cr) a_b1[tid] = 0.f;
-  __syncthreads();
-  for (int b = 0; b < B; ++b) {
-    for (int c = tid; c < C; c += 256) {
+  const int nw = C * Cr;
+  for (int i = tid; i < nw; i += 256) { lw1[i] = w1[i]; lw2[i] = w2[i]; }
+  if (tid < Cr) lb1[tid] = b1[tid];
+  float aw1[16], aw2[16], ab2[2] = {0.f, 0.f}, ab1 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { aw1[q] = 0.f; aw2[q] = 0.f; }
+  for (int b0 = 0; b0 < B; b0 += CAB_G) {
+    const int g = min(CAB_G, B - b0);
+    __syncthreads();                                       // weights staged / the previous pass is fully consumed
+    for (int idx = tid; idx < g * C; idx += 256) {         // dgate through the sigmoid, mean
+      const int bb = idx / C, c = idx - bb * C, b = b0 + bb;
+      const float* pp = part + (size_t)b * nchunk * C + c;
       float dg = 0.f;
-      for (int k = 0; k < nchunk; ++k) dg += part[((size_t)b * nchunk + k) * C + c];
+      int k = 0;
+      for (; k + 8 <= nchunk; k += 8) {                    // eight loads in flight
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = pp[(size_t)(k + u) * C];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dg += t[u];
+      }
+      for (; k < nchunk; ++k) dg += pp[(size_t)k * C];
       const float gt = gate[(size_t)b * C + c];
-      s[c] = dg * gt * (1.f - gt);                       // through the sigmoid
-      mean[c] = pool[(size_t)b * C + c] * inv_hw;
+      s[bb][c] = dg * gt * (1.f - gt);
+      mean[bb][c] = pool[(size_t)b * C + c] * inv_hw;
     }
     __syncthreads();
-    if (tid < Cr) {
-      float acc = b1[tid];
-      for (int c = 0; c < C; ++c) acc += w1[tid * C + c] * mean[c];
-      hid[tid] = fmaxf(acc, 0.f);
-      float dh = 0.f;
-      for (int c = 0; c < C; ++c) dh += s[c] * w2[c * Cr + tid];
-      dhid[tid] = acc > 0.f ? dh : 0.f;
-      a_b1[tid] += dhid[tid];
+    for (int idx = tid; idx < g * Cr; idx += 256) {        // hidden units of every image
+      const int bb = idx / Cr, j = idx - bb * Cr;
+      float acc = lb1[j], dh = 0.f;
+      for (int c = 0; c < C; ++c) {
+        acc += lw1[j * C + c] * mean[bb][c];
+        dh += s[bb][c] * lw2[c * Cr + j];
+      }
+      hid[bb][j] = fmaxf(acc, 0.f);
+      dhid[bb][j] = acc > 0.f ? dh : 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < C * Cr; i += 256) {
-      const int c = i / Cr, j = i - c * Cr;              // w2 [C][Cr]
-      a_w2[i] += s[c] * hid[j];
-      const int j1 = i / C, c1 = i - j1 * C;             // w1 [Cr][C]
-      a_w1[i] += dhid[j1] * mean[c1];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {                         // weight gradients, summed over the pass's images
+      const int i = tid + 256 * q;
+      if (i < nw) {
+        const int c = i / Cr, j = i - c * Cr;              // w2 [C][Cr]
+        const int j1 = i / C, c1 = i - j1 * C;             // w1 [Cr][C]
+        float t2 = 0.f, t1 = 0.f;
+        for (int bb = 0; bb < g; ++bb) { t2 += s[bb][c] * hid[bb][j]; t1 += dhid[bb][j1] * mean[bb][c1]; }
+        aw2[q] += t2; aw1[q] += t1;
+      }
     }
-    for (int c = tid; c < C; c += 256) {
-      a_b2[c] += s[c];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int c = tid + 256 * q;
+      if (c < C) for (int bb = 0; bb < g; ++bb) ab2[q] += s[bb][c];
+    }
+    if (tid < Cr) for (int bb = 0; bb < g; ++bb) ab1 += dhid[bb][tid];
+    for (int idx = tid; idx < g * C; idx += 256) {         // back to the pooled mean
+      const int bb = idx / C, c = idx - bb * C;
       float dm = 0.f;
-      for (int j = 0; j < Cr; ++j) dm += dhid[j] * w1[j * C + c];
-      dpool[(size_t)b * C + c] = dm * inv_hw;
+      for (int j = 0; j < Cr; ++j) dm += dhid[bb][j] * lw1[j * C + c];
+      dpool[(size_t)(b0 + bb) * C + c] = dm * inv_hw;
     }
-    __syncthreads();
   }
-  for (int i = tid; i < C * Cr; i += 256) { dw1[i] += a_w1[i]; dw2[i] += a_w2[i]; }
-  for (int c = tid; c < C; c += 256) db2[c] += a_b2[c];
-  if (tid < Cr) db1[tid] += a_b1[tid];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = tid + 256 * q;
+    if (i < nw) { dw1[i] += aw1[q]; dw2[i] += aw2[q]; }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int c = tid + 256 * q;
+    if (c < C) db2[c] += ab2[q];
+  }
+  if (tid < Cr) db1[tid] += ab1;
 }
 
 // dr = g * gate[b] + dpool[b]                                                   (RCAB: r * gate + x, drn.py:139,156)
