@@ -175,6 +175,8 @@ struct srad_drn {
   std::vector<ConvW> tail;                      // phase + 1
   GraphCache gc;
   TrainState ts;                                // training (second half of this file)
+  hipStream_t side = nullptr;                   // weight gradients of the RCAB chain run here, beside the data-gradient chain
+  std::vector<hipEvent_t> events;
 };
 
 namespace {
@@ -427,6 +429,8 @@ int srad_drn_create(const srad_drn_config* cfg, srad_drn_t** out) {
 void srad_drn_destroy(srad_drn_t* h) {
   if (!h) return;
   h->gc.reset();
+  for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+  if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
 }
 
@@ -747,7 +751,7 @@ struct DrnTrainWs {
   std::vector<float*> cat, dtmp, ups, timg;
   std::vector<std::vector<RcabSave>> rc;
   // backward
-  float *gdeep, *ga, *gb, *dr, *dt, *dups, *dus, *ddtmp, *zup, *dtimg, *dup0, *ppart, *dpool;
+  float *gdeep, *ga, *gb, *dr2[2], *dt2[2], *dups, *dus, *ddtmp, *zup, *dtimg, *dup0, *ppart, *dpool;   // dr / dt double-buffered (two streams)
   std::vector<float*> gcat;
   size_t bytes;
 };
@@ -784,7 +788,8 @@ DrnTrainWs plan_train_ws(const srad_drn* h, int B, int H, int W, void* base, siz
   // backward
   for (int L = 0; L < P; ++L) w.gcat.push_back(bp.take((T0 >> (2 * L)) * 2 * (F << L)));
   w.gdeep = bp.take(TP * top);
-  w.ga = bp.take(rmax); w.gb = bp.take(rmax); w.dr = bp.take(rmax); w.dt = bp.take(rmax);
+  w.ga = bp.take(rmax); w.gb = bp.take(rmax);
+  for (int i = 0; i < 2; ++i) { w.dr2[i] = bp.take(rmax); w.dt2[i] = bp.take(rmax); }
   w.dups = bp.take(umax); w.dus = bp.take(umax);
   w.ddtmp = bp.take((T0 >> 2) * F);
   w.zup = bp.take(T0 * F);
@@ -967,6 +972,35 @@ int srad_drn_backward(srad_drn_t* h, const float* const* dys, int n_out, int B, 
   const size_t T0 = (size_t)B * H0 * W0;
   float* G = flat_grad;
   WgradQueue wq = train_wgrad_queue(h->ts);
+  // Two streams for the RCAB chains (160 of the 170 convolutions): the data-gradient chain stays on the caller's stream, the
+  // two weight gradients of a block and their reduce run on a side stream while the next block's chain proceeds (dr / dt
+  // and the split-K workspace are double-buffered; a block waits for the side work of the block two before it).
+  // SRAD_BWD_ONE_STREAM=1 keeps everything on the caller's stream.
+  static const bool one_stream = getenv("SRAD_BWD_ONE_STREAM") != nullptr;
+  if (!one_stream && !h->side) SRAD_CHECK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  hipStream_t side = one_stream ? s : h->side;
+  size_t ev_next = 0;
+  auto next_event = [&](hipEvent_t* out) -> int {
+    if (ev_next == h->events.size()) {
+      hipEvent_t ev = nullptr;
+      SRAD_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      h->events.push_back(ev);
+    }
+    *out = h->events[ev_next++];
+    return SRAD_OK;
+  };
+  auto a_waits_b = [&](hipStream_t a, hipStream_t b) -> int {
+    if (a == b) return SRAD_OK;
+    hipEvent_t ev = nullptr;
+    SRAD_TRY(next_event(&ev));
+    SRAD_CHECK_HIP(hipEventRecord(ev, b));
+    SRAD_CHECK_HIP(hipStreamWaitEvent(a, ev, 0));
+    return SRAD_OK;
+  };
+  float* const wq_base = wq.ws;
+  const size_t wq_half = wq.ws_floats / 2;
+  hipEvent_t side_done[2] = {nullptr, nullptr};
+  int blk_count = 0;
 
   for (int L = 0; L < P; ++L) SRAD_CHECK_HIP(hipMemsetAsync(w.gcat[L], 0, (T0 >> (2 * L)) * 2 * (F << L) * sizeof(float), s));
   SRAD_CHECK_HIP(hipMemsetAsync(w.gdeep, 0, (T0 >> (2 * P)) * top * sizeof(float), s));
@@ -1017,34 +1051,51 @@ int srad_drn_backward(srad_drn_t* h, const float* const* dys, int n_out, int B, 
     float* gb = w.gb;
     const float* x0 = idx == 0 ? w.deep : w.cat[lvl];       // input of the first RCAB
     const int ld0 = idx == 0 ? top : ch;
+    SRAD_TRY(srad_wgrad_flush(wq, s));                       // the up convs' partials: reduced on the caller's stream
     for (int b = c.n_blocks - 1; b >= 0; --b) {              // RCAB (drn.py:143-158)
       const RcabW& r = h->rcab[idx][b];
       const RcabSave& sv = w.rc[idx][b];
       const float* xin = b == 0 ? x0 : w.rc[idx][b - 1].xo;
       const int ldin = b == 0 ? ld0 : ch;
+      const int set = blk_count & 1;
+      if (side != s && side_done[set]) SRAD_CHECK_HIP(hipStreamWaitEvent(s, side_done[set], 0));   // block n - 2 fully consumed
+      float* dr = w.dr2[set];
+      float* dt = w.dt2[set];
       hipLaunchKernelGGL(pool_dot_kernel, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, ga, sv.r, w.ppart, Hl * Wl, ch, DRN_POOL_CHUNKS);
       hipLaunchKernelGGL(ca_bwd_kernel, dim3(1), dim3(256), 0, s, w.ppart, DRN_POOL_CHUNKS, sv.pool, sv.gate, 1.0f / (float)(Hl * Wl), B,
                          ch, ch / 16, h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), G + h->ts.flat_off[r.w1],
                          G + h->ts.flat_off[r.b1], G + h->ts.flat_off[r.w2], G + h->ts.flat_off[r.b2], w.dpool);
-      hipLaunchKernelGGL(ca_apply_bwd_kernel, dim3(grid1d(T * ch / 4)), dim3(256), 0, s, ga, sv.gate, w.dpool, w.dr, T, ch, Hl * Wl);
+      hipLaunchKernelGGL(ca_apply_bwd_kernel, dim3(grid1d(T * ch / 4)), dim3(256), 0, s, ga, sv.gate, w.dpool, dr, T, ch, Hl * Wl);
       SRAD_CHECK_HIP(hipGetLastError());
       {
-        WgradParams g = drn_wgrad(h, r.c1, G, w.dr, ch, 0, sv.t, ch, B, Hl, Wl, 1);
-        SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
-        GemmParams p = drn_dgrad(h, r.c1, w.dr, ch, B, Hl, Wl, w.dt, ch, 0);
+        GemmParams p = drn_dgrad(h, r.c1, dr, ch, B, Hl, Wl, dt, ch, 0);
         p.R = sv.t; p.ldr = ch; p.rmode = SRAD_RMODE_DLRELU; p.slope = 0.f;           // through the ReLU
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
+      // both weight gradients of the block + their reduce on the side stream (dr and dt exist now)
+      SRAD_TRY(a_waits_b(side, s));
+      wq.ws = wq_base + (size_t)set * wq_half; wq.ws_floats = wq_half;
       {
-        WgradParams g = drn_wgrad(h, r.c0, G, w.dt, ch, 0, xin, ldin, B, Hl, Wl, 1);
-        SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
-        GemmParams p = drn_dgrad(h, r.c0, w.dt, ch, B, Hl, Wl, gb, ch, 0);
+        WgradParams g = drn_wgrad(h, r.c1, G, dr, ch, 0, sv.t, ch, B, Hl, Wl, 1);
+        SRAD_TRY(srad_launch_wgrad(prec, g, wq, side));
+        WgradParams g0 = drn_wgrad(h, r.c0, G, dt, ch, 0, xin, ldin, B, Hl, Wl, 1);
+        SRAD_TRY(srad_launch_wgrad(prec, g0, wq, side));
+        SRAD_TRY(srad_wgrad_flush(wq, side));
+      }
+      if (side != s) {
+        SRAD_TRY(next_event(&side_done[set]));
+        SRAD_CHECK_HIP(hipEventRecord(side_done[set], side));
+      }
+      {
+        GemmParams p = drn_dgrad(h, r.c0, dt, ch, B, Hl, Wl, gb, ch, 0);
         p.R = ga; p.ldr = ch;                                                        // + the skip path
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
-      SRAD_TRY(srad_wgrad_flush(wq, s));
       float* t = ga; ga = gb; gb = t;
+      ++blk_count;
     }
+    SRAD_TRY(a_waits_b(s, side));                           // the chain's weight gradients are final on the caller's stream
+    wq.ws = wq_base; wq.ws_floats = 2 * wq_half;
     // gradient of the chain's input: deep (idx 0) or the concat buffer of this level
     float* GX = idx == 0 ? w.gdeep : w.gcat[lvl];
     hipLaunchKernelGGL(add_cols_kernel, dim3(grid1d(T * ch / 4)), dim3(256), 0, s, ga, ch, GX, ch, T, ch);
