@@ -150,6 +150,67 @@ __global__ void scale_add_kernel(const float* __restrict__ r, const float* __res
   }
 }
 
+// The two kernels above as one launch: every workgroup recomputes its image's gate (C * C/16 MACs from the pooled partial
+// rows - cheaper than a launch boundary, and the lone one-workgroup-per-image gate kernel took 12 us) and then streams
+// its slice of the image: out = r * gate[b] + x.  grid = (slices per image, B); the slice-0 workgroups also write the gate
+// and the pooled sums when the caller keeps them (training).
+__global__ __launch_bounds__(256) void ca_scale_add_kernel(const float* __restrict__ part, int nchunk, float inv_hw, int C, int Cr,
+                                                           const float* __restrict__ w1, const float* __restrict__ b1,
+                                                           const float* __restrict__ w2, const float* __restrict__ b2,
+                                                           float* __restrict__ gate_out, float* __restrict__ pool_out,
+                                                           const float* __restrict__ r, const float* __restrict__ x, int ldx,
+                                                           float* __restrict__ y, int hw) {
+  __shared__ __attribute__((aligned(16))) float gt[512];
+  __shared__ float mean[512], hid[64];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  for (int c = tid; c < C; c += 256) {
+    const float* pp = part + (size_t)b * nchunk * C + c;
+    float sum = 0.f;
+    int k = 0;
+    for (; k + 8 <= nchunk; k += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = pp[(size_t)(k + u) * C];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += t[u];           // same order as ca_gate_kernel: k ascending
+    }
+    for (; k < nchunk; ++k) sum += pp[(size_t)k * C];
+    if (pool_out && blockIdx.x == 0) pool_out[(size_t)b * C + c] = sum;
+    mean[c] = sum * inv_hw;
+  }
+  __syncthreads();
+  for (int j0 = 0; j0 < Cr; j0 += 8) {                     // 8 hidden units per pass, 32 lanes each
+    const int j = j0 + (tid >> 5), l = tid & 31;
+    float acc = 0.f;
+    if (j < Cr) for (int c = l; c < C; c += 32) acc += w1[j * C + c] * mean[c];
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    if (j < Cr && l == 0) hid[j] = fmaxf(acc + b1[j], 0.f);
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float acc = b2[c];
+    for (int j = 0; j < Cr; ++j) acc += w2[c * Cr + j] * hid[j];
+    const float g = 1.0f / (1.0f + expf(-acc));
+    gt[c] = g;
+    if (gate_out && blockIdx.x == 0) gate_out[(size_t)b * C + c] = g;
+  }
+  __syncthreads();
+  const int c4n = C / 4;
+  const int per = (hw + gridDim.x - 1) / gridDim.x;
+  const int p0 = blockIdx.x * per, p1 = min(hw, p0 + per);
+  const size_t base = (size_t)b * hw;
+  for (int i = tid; i < (p1 - p0) * c4n; i += 256) {
+    const int pl = i / c4n, c = (i - pl * c4n) * 4;
+    const size_t pix = base + p0 + pl;
+    const f32x4 rv = *reinterpret_cast<const f32x4*>(r + pix * C + c);
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + pix * ldx + c);
+    *reinterpret_cast<f32x4*>(y + pix * C + c) = rv * *reinterpret_cast<const f32x4*>(gt + c) + xv;
+  }
+}
+
+inline int ca_slices(int hw) { return hw >= 128 * 128 ? 128 : (hw >= 1024 ? 64 : (hw >= 64 ? 8 : 1)); }
+
 inline int grid1d(size_t total) {
   size_t b = (total + 255) / 256;
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -320,13 +381,12 @@ int forward_body(srad_drn* h, const float* x, int B, int H, int W, float* const*
         SradProfScope prof(s, SRAD_K_MISC, 1.0 * T * ch + 4.0 * B * ch * (ch / 16), 4.0 * T * ch);
         hipLaunchKernelGGL(pool_dot_kernel, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, (const float*)nullptr, w.rr, w.pool, Hl * Wl, ch,
                            DRN_POOL_CHUNKS);
-        hipLaunchKernelGGL(ca_gate_kernel, dim3(B), dim3(128), 0, s, w.pool, DRN_POOL_CHUNKS, 1.0f / (float)(Hl * Wl), ch, ch / 16,
-                           h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2), w.gate, (float*)nullptr);
       }
-      {  // res = body(x) * gate + x                             (drn.py:139, 156-157)
+      {  // the gate, and res = body(x) * gate + x               (drn.py:128-139, 156-157)
         SradProfScope prof(s, SRAD_K_MISC, 2.0 * T * ch, 12.0 * T * ch);
-        hipLaunchKernelGGL(scale_add_kernel, dim3(grid1d(T * ch / 4)), dim3(256), 0, s, w.rr, w.gate, xin, ldin, cur, T, ch,
-                           Hl * Wl);
+        hipLaunchKernelGGL(ca_scale_add_kernel, dim3(ca_slices(Hl * Wl), B), dim3(256), 0, s, w.pool, DRN_POOL_CHUNKS,
+                           1.0f / (float)(Hl * Wl), ch, ch / 16, h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2),
+                           (float*)nullptr, (float*)nullptr, w.rr, xin, ldin, cur, Hl * Wl);
       }
       SRAD_CHECK_HIP(hipGetLastError());
       xin = cur; ldin = ch;
@@ -918,7 +978,6 @@ int srad_drn_forward_train(srad_drn_t* h, const float* x, int B, int H, int W, f
   for (int idx = 0; idx < P; ++idx) {
     const int lvl = P - idx, Hl = H0 >> lvl, Wl = W0 >> lvl;
     const int ch = h->rcab[idx][0].ch;
-    const size_t T = (size_t)B * Hl * Wl;
     for (int b = 0; b < c.n_blocks; ++b) {
       const RcabW& r = h->rcab[idx][b];
       const RcabSave& sv = w.rc[idx][b];
@@ -933,9 +992,9 @@ int srad_drn_forward_train(srad_drn_t* h, const float* x, int B, int H, int W, f
       }
       hipLaunchKernelGGL(pool_dot_kernel, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, (const float*)nullptr, sv.r, w.ppart, Hl * Wl, ch,
                          DRN_POOL_CHUNKS);
-      hipLaunchKernelGGL(ca_gate_kernel, dim3(B), dim3(128), 0, s, w.ppart, DRN_POOL_CHUNKS, 1.0f / (float)(Hl * Wl), ch, ch / 16,
-                         h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2), sv.gate, sv.pool);
-      hipLaunchKernelGGL(scale_add_kernel, dim3(grid1d(T * ch / 4)), dim3(256), 0, s, sv.r, sv.gate, xin, ldin, sv.xo, T, ch, Hl * Wl);
+      hipLaunchKernelGGL(ca_scale_add_kernel, dim3(ca_slices(Hl * Wl), B), dim3(256), 0, s, w.ppart, DRN_POOL_CHUNKS,
+                         1.0f / (float)(Hl * Wl), ch, ch / 16, h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2),
+                         sv.gate, sv.pool, sv.r, xin, ldin, sv.xo, Hl * Wl);
       SRAD_CHECK_HIP(hipGetLastError());
       xin = sv.xo; ldin = ch;
     }
