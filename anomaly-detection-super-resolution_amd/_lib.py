@@ -99,6 +99,11 @@ _SIG = {
     "srad_roc_auc": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double)]),
     "srad_l1_workspace_bytes": (C.c_int, [C.POINTER(C.c_size_t)]),
     "srad_l1_loss": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P]),
+    "srad_loss_workspace_bytes": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "srad_loss_forward": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P,
+                                    _P, C.c_size_t, _P]),
+    "srad_loss_backward": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P,
+                                     _P, C.c_float, _P, C.c_int, _P, C.c_size_t, _P]),
     # event profiler
     "srad_prof_enable": (C.c_int, [C.c_int]),
     "srad_prof_num_classes": (C.c_int, []),
@@ -116,6 +121,13 @@ _SIG = {
                                          C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
     "srad_bench_mlp_block": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_size_t, C.c_int, C.c_int,
                                        C.POINTER(C.c_float), _P]),
+    "srad_bench_qkv_attn": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_size_t,
+                                      C.c_int, C.POINTER(C.c_float), _P]),
+    "srad_op_swin_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "srad_op_qkv_attn": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P,
+                                   C.c_size_t, _P]),
+    "srad_op_mlp_block": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P,
+                                    _P, _P, C.c_int, C.c_float, C.c_float, _P, C.c_int, _P, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "srad_op_gemm_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "srad_op_window_attn": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, _P]),

@@ -378,12 +378,9 @@ int launch_mlp_fm(const MlpBlockParams& p, hipStream_t stream) {
 template <int GD, int KGD, int GM, int KGM, int GN, int KCD, int KCM>
 int launch_mlp(const MlpBlockParams& p, hipStream_t stream) {
   // 16-row tiles until there are enough tokens to fill the chip several times with 64-row tiles
-  if (const char* e = getenv("SRAD_MLP_FM")) {                 // tools/: timing experiments
-    const int fm = atoi(e);
-    if (fm == 64 && p.M % 64 == 0) return launch_mlp_fm<64, GD, KGD, GM, KGM, GN, KCD, KCM>(p, stream);
-    if (fm == 32 && p.M % 32 == 0) return launch_mlp_fm<32, GD, KGD, GM, KGM, GN, KCD, KCM>(p, stream);
-    if (fm == 16) return launch_mlp_fm<16, GD, KGD, GM, KGM, GN, KCD, KCM>(p, stream);
-  }
+  if (p.fm == 64 && p.M % 64 == 0) return launch_mlp_fm<64, GD, KGD, GM, KGM, GN, KCD, KCM>(p, stream);
+  if (p.fm == 32 && p.M % 32 == 0) return launch_mlp_fm<32, GD, KGD, GM, KGM, GN, KCD, KCM>(p, stream);
+  if (p.fm == 16) return launch_mlp_fm<16, GD, KGD, GM, KGM, GN, KCD, KCM>(p, stream);
   if (p.M >= 32768 && p.M % 64 == 0) return launch_mlp_fm<64, GD, KGD, GM, KGM, GN, KCD, KCM>(p, stream);
   if (p.M >= 8192 && p.M % 32 == 0) return launch_mlp_fm<32, GD, KGD, GM, KGM, GN, KCD, KCM>(p, stream);
   return launch_mlp_fm<16, GD, KGD, GM, KGM, GN, KCD, KCM>(p, stream);

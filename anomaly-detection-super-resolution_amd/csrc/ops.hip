@@ -135,6 +135,95 @@ int srad_bench_mlp_block(int M, int d, int m, int no, const float* attn, const f
   return SRAD_OK;
 }
 
+// ---- the two fused forward kernels of a Swin block (bf16, window 8), weights in PyTorch layout, packed into scratch ----
+static size_t swin_scratch_parts(int d, int heads, int m, int no, size_t* off) {
+  size_t o = 0;
+  off[0] = o; o += srad_align_up(srad_qkv_frag_bytes(d, heads), 256);
+  off[1] = o; o += srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, d, d, 1), 256);
+  off[2] = o; o += srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, m, d, 1), 256);
+  off[3] = o; o += srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, d, m, 1), 256);
+  off[4] = o; o += srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, no, d, 1), 256);
+  return o;
+}
+
+size_t srad_op_swin_scratch_bytes(int d, int heads, int m, int no) {
+  size_t off[5];
+  return swin_scratch_parts(d, heads > 0 ? heads : 1, m > 0 ? m : 4, no > 0 ? no : 4, off);
+}
+
+// First half of a Swin block: LayerNorm1 -> qkv Linear -> shifted-window attention (src/drct.py:477-504, 271-299).
+//   x [B*H*W][ldx] (columns [0, d)), w_qkv [3d][d], b_qkv [3d], table [225][heads] -> out [B*H*W][d]
+int srad_op_qkv_attn(const float* x, int ldx, int B, int H, int W, int shift, int d, int heads, const float* ln_g,
+                     const float* ln_b, const float* w_qkv, const float* b_qkv, const float* table, float* out, void* scratch,
+                     size_t scratch_bytes, void* stream) {
+  SRAD_REQUIRE(x && ln_g && ln_b && w_qkv && b_qkv && table && out && scratch, "op_qkv_attn: null argument");
+  SRAD_REQUIRE(srad_qkv_attn_supported(SRAD_PREC_BF16, 8, H, W, d, heads), "op_qkv_attn: unsupported shape d=%d heads=%d %dx%d", d, heads, H, W);
+  SRAD_REQUIRE(scratch_bytes >= srad_align_up(srad_qkv_frag_bytes(d, heads), 256) && ((uintptr_t)scratch & 255) == 0,
+               "op_qkv_attn: scratch too small or not 256-byte aligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  SRAD_TRY(srad_launch_pack_qkv_frag(w_qkv, scratch, d, heads, s));
+  QkvAttnParams a{};
+  a.x = x; a.ldx = ldx; a.ln_g = ln_g; a.ln_b = ln_b; a.w_qkv = scratch; a.b_qkv = b_qkv; a.table = table;
+  a.out = out; a.ld_out = d; a.B = B; a.H = H; a.W = W; a.shift = shift; a.d = d; a.heads = heads;
+  return srad_launch_qkv_attn(a, s);
+}
+
+// Diagnostic twin of srad_bench_mlp_block for the first half: microseconds per launch, back-to-back launches.
+int srad_bench_qkv_attn(const float* x, int ldx, int B, int H, int W, int shift, int d, int heads, const float* w_fp32,
+                        float* out, void* scratch, size_t scratch_bytes, int iters, float* us_out, void* stream) {
+  SRAD_REQUIRE(x && w_fp32 && out && scratch && us_out && iters > 0, "bench_qkv_attn: bad argument");
+  SRAD_REQUIRE(srad_qkv_attn_supported(SRAD_PREC_BF16, 8, H, W, d, heads), "bench_qkv_attn: unsupported shape");
+  SRAD_REQUIRE(scratch_bytes >= srad_align_up(srad_qkv_frag_bytes(d, heads), 256), "bench_qkv_attn: scratch too small");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  SRAD_TRY(srad_launch_pack_qkv_frag(w_fp32, scratch, d, heads, s));
+  QkvAttnParams a{};
+  a.x = x; a.ldx = ldx; a.ln_g = w_fp32; a.ln_b = w_fp32; a.w_qkv = scratch; a.b_qkv = w_fp32; a.table = w_fp32;
+  a.out = out; a.ld_out = d; a.B = B; a.H = H; a.W = W; a.shift = shift; a.d = d; a.heads = heads;
+  for (int i = 0; i < 3; ++i) SRAD_TRY(srad_launch_qkv_attn(a, s));
+  hipEvent_t e0, e1;
+  SRAD_CHECK_HIP(hipEventCreate(&e0));
+  SRAD_CHECK_HIP(hipEventCreate(&e1));
+  SRAD_CHECK_HIP(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) SRAD_TRY(srad_launch_qkv_attn(a, s));
+  SRAD_CHECK_HIP(hipEventRecord(e1, s));
+  SRAD_CHECK_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  SRAD_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *us_out = ms * 1e3f / iters;
+  return SRAD_OK;
+}
+
+// Second half of a Swin block + the RDG's adjust conv (src/drct.py:300, 509-510, 184-190, 389-396):
+//   x1 = shortcut + proj(attn); x2 = x1 + fc2(GELU(fc1(LN2(x1)))); Y[:, yoff:yoff+no] = act(adjust(x2)) * alpha (+ R)
+//   fm: token rows per workgroup (16 / 32 / 64; 0 = the engine's choice for M)
+int srad_op_mlp_block(int M, int d, int m, int no, int fm, const float* attn, const float* shortcut, int ld_short,
+                      const float* w_proj, const float* b_proj, const float* ln_g, const float* ln_b, const float* w_fc1,
+                      const float* b_fc1, const float* w_fc2, const float* b_fc2, const float* w_adj, const float* b_adj, int act,
+                      float slope, float alpha, const float* r, int ldr, float* y, int ldy, int yoff, void* scratch,
+                      size_t scratch_bytes, void* stream) {
+  SRAD_REQUIRE(attn && shortcut && w_proj && b_proj && ln_g && ln_b && w_fc1 && b_fc1 && w_fc2 && b_fc2 && w_adj && b_adj && y && scratch,
+               "op_mlp_block: null argument");
+  SRAD_REQUIRE(srad_mlp_block_supported(SRAD_PREC_BF16, M, d, m, no), "op_mlp_block: unsupported shape M=%d d=%d m=%d no=%d", M, d, m, no);
+  SRAD_REQUIRE(fm == 0 || ((fm == 16 || fm == 32 || fm == 64) && M % fm == 0), "op_mlp_block: fm must be 0, 16, 32 or 64 and divide M");
+  size_t off[5];
+  const size_t need = swin_scratch_parts(d, 1, m, no, off);
+  SRAD_REQUIRE(scratch_bytes >= need && ((uintptr_t)scratch & 255) == 0, "op_mlp_block: scratch %zu bytes, %zu needed (256-byte aligned)", scratch_bytes, need);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  char* sc = reinterpret_cast<char*>(scratch);
+  SRAD_TRY(srad_launch_pack_weight_frag(w_proj, sc + off[1], d, d, s));
+  SRAD_TRY(srad_launch_pack_weight_frag(w_fc1, sc + off[2], m, d, s));
+  SRAD_TRY(srad_launch_pack_weight_frag(w_fc2, sc + off[3], d, m, s));
+  SRAD_TRY(srad_launch_pack_weight_frag(w_adj, sc + off[4], no, d, s));
+  MlpBlockParams q{};
+  q.attn = attn; q.ld_attn = d; q.shortcut = shortcut; q.ld_short = ld_short; q.M = M; q.d = d; q.m = m; q.no = no;
+  q.w_proj = sc + off[1]; q.w_fc1 = sc + off[2]; q.w_fc2 = sc + off[3]; q.w_adj = sc + off[4];
+  q.b_proj = b_proj; q.b_fc1 = b_fc1; q.b_fc2 = b_fc2; q.b_adj = b_adj; q.ln_g = ln_g; q.ln_b = ln_b;
+  q.act = act; q.slope = slope; q.alpha = alpha; q.R = r; q.ldr = ldr; q.Y = y; q.ldy = ldy; q.yoff = yoff; q.fm = fm;
+  return srad_launch_mlp_block(q, s);
+}
+
 int srad_op_wgrad(int precision, const float* dy, int ldy, const float* x, int ldx, int B, int Hi, int Wi, int N,
                   int Cin, int ntaps, int stride, const float* row_scale, float alpha, float* dw, float* db,
                   void* workspace, void* stream) {

@@ -71,27 +71,35 @@ def resolve_checkpoint(args) -> str:
     raise FileNotFoundError('Please provide --checkpoint or a valid --run-dir containing model/*.pt')
 
 
-def _load_png(path: str, n_colors: int) -> np.ndarray:
+def iter_split(data_root: str, classe: str, split: str, scale, n_colors: int, rgb_range: float = 255.0
+               ) -> Iterable[Tuple[str, np.ndarray, np.ndarray]]:
+    """(name, LR u8 HWC, HR u8 HWC) of ``{root}/{class}/test/{split}`` read the way the reference's evaluator reads it
+    (src/evaluate.py:140-150,204-217): the MVTec test loader (``data.MVTec(train=False)``: LR_{s} / LR_bicubic/X{s} / LR
+    next to HR, ``set_channel``, HR cropped to LR * scale) and the TRUNCATING u8 conversion of the HR tensor.  The LR image
+    is what the loader feeds the model, kept as u8 when it is integral (PNG input), so the forward sees the same values."""
+    from .data import MVTec
+
+    class _O:
+        pass
+    o = _O()
+    o.scale = list(scale) if isinstance(scale, (list, tuple)) else [scale]
+    o.data_dir = str(Path(data_root) / classe / 'test' / split)
+    o.n_colors, o.rgb_range, o.no_augment, o.patch_size, o.batch_size, o.test_every = n_colors, 255, True, 0, 1, 1
+    ds = MVTec(o, train=False)
+    for i in range(len(ds)):
+        lr, hr, name = ds.sample(i)
+        hr_u8 = hr.clamp(0, 255).to(torch.uint8).permute(1, 2, 0).numpy()          # .byte(): truncation
+        lr0 = lr[0].permute(1, 2, 0).numpy()
+        yield name, (lr0.astype(np.uint8) if np.array_equal(lr0, np.floor(lr0)) and lr0.min() >= 0 and lr0.max() <= 255 else lr0), hr_u8
+
+
+def save_sr_image(sr_u8_hwc: np.ndarray, name: str, split: str, scale_value: int, output_dir: str) -> None:
+    """src/evaluate.py:193-202: ``<output_dir>/<split>/x<scale>/<name>.png`` of the truncated u8 SR image."""
     from PIL import Image
-    im = Image.open(path)
-    im = im.convert('L') if n_colors == 1 else im.convert('RGB')
-    a = np.asarray(im, dtype=np.uint8)
-    return a[:, :, None] if a.ndim == 2 else a
-
-
-def iter_split(data_root: str, classe: str, split: str, scale: int, n_colors: int) -> Iterable[Tuple[str, np.ndarray, np.ndarray]]:
-    """(name, LR u8 HWC, HR u8 HWC) of ``{root}/{class}/test/{split}/{HR,LR_{s}}/*.png`` - the layout
-    scripts/prepare_mvtec_data.py writes and src/data.py:109-147 reads (LR_{s}, LR_bicubic/X{s} or LR)."""
-    base = Path(data_root) / classe / 'test' / split
-    hr_dir = base / 'HR'
-    lr_dir = next((d for d in (base / f'LR_{scale}', base / 'LR_bicubic' / f'X{scale}', base / 'LR') if d.is_dir()), None)
-    if not hr_dir.is_dir() or lr_dir is None:
-        raise FileNotFoundError(f"expected {hr_dir} and an LR folder next to it")
-    for hp in sorted(hr_dir.glob('*.png')):
-        lp = lr_dir / hp.name
-        if not lp.is_file():
-            raise FileNotFoundError(str(lp))
-        yield hp.stem, _load_png(str(lp), n_colors), _load_png(str(hp), n_colors)
+    out_dir = Path(output_dir) / split / f"x{scale_value}"
+    out_dir.mkdir(parents=True, exist_ok=True)
+    img = Image.fromarray(sr_u8_hwc[:, :, 0]) if sr_u8_hwc.shape[2] == 1 else Image.fromarray(np.ascontiguousarray(sr_u8_hwc))
+    img.save(str(out_dir / f"{name}.png"))
 
 
 def shard_indices(n: int, rank: int, world: int) -> List[int]:
@@ -127,7 +135,7 @@ def super_resolve_u8(model, lr_u8: Sequence[np.ndarray], hr_u8: Sequence[np.ndar
     dev = model.device if hasattr(model, 'device') else next(model.parameters()).device
     sr_out: List[torch.Tensor] = []
     for i in range(0, len(lr_u8), batch):
-        lr = torch.from_numpy(np.stack(lr_u8[i:i + batch])).to(dev).permute(0, 3, 1, 2).float() * (rgb_range / 255.0)
+        lr = torch.from_numpy(np.stack(lr_u8[i:i + batch])).to(dev).permute(0, 3, 1, 2).float() * (rgb_range / 255.0)   # np2Tensor
         sr = model(lr)
         if isinstance(sr, list):
             sr = sr[-1]
@@ -138,9 +146,10 @@ def super_resolve_u8(model, lr_u8: Sequence[np.ndarray], hr_u8: Sequence[np.ndar
 
 
 def evaluate_on_test(opt, model, good: Sequence[Tuple[np.ndarray, np.ndarray]], bad: Sequence[Tuple[np.ndarray, np.ndarray]],
-                     rank: int = 0, world: int = 1) -> dict:
+                     rank: int = 0, world: int = 1, names: Sequence[str] = (), output_dir: str = '', save_images: bool = False) -> dict:
     """src/evaluate.py:138-267 for in-memory (LR, HR) u8 pairs.  With world > 1 every rank scores its
-    share r::world; rank 0 gathers the score rows and returns the AUCs (others return {})."""
+    share r::world; rank 0 gathers the score rows and returns the AUCs (others return {}).  ``save_images``: every rank
+    writes the SR images it produced under ``output_dir/{good,bad}/x{scale}`` (src/evaluate.py:190-224)."""
     model.eval()                                              # H1: deterministic scoring
     y_true = [0] * len(good) + [1] * len(bad)
     pairs = list(good) + list(bad)
@@ -149,6 +158,11 @@ def evaluate_on_test(opt, model, good: Sequence[Tuple[np.ndarray, np.ndarray]], 
         return {}
     mine = shard_indices(len(pairs), rank, world)
     sr, hr = super_resolve_u8(model, [pairs[i][0] for i in mine], [pairs[i][1] for i in mine], float(opt.rgb_range))
+    if save_images and output_dir:
+        scale_value = opt.scale[-1] if isinstance(opt.scale, list) else int(opt.scale)
+        sr_host = sr.cpu().numpy()
+        for k, i in enumerate(mine):
+            save_sr_image(sr_host[k], names[i] if i < len(names) else f"{i:05d}", 'good' if y_true[i] == 0 else 'bad', scale_value, output_dir)
     H, W = hr.shape[1:3]
     sizes = M.sweep_window_sizes(min(H, W))
     ssim, mse, psnr = M.score_pairs(sr, hr, sizes)
@@ -169,6 +183,13 @@ def evaluate_on_test(opt, model, good: Sequence[Tuple[np.ndarray, np.ndarray]], 
 
 def main(argv=None):
     args = parse_eval_args(argv)
+    from .launch import spawn
+    if spawn(_run, getattr(args, "gpus", 1), (args,)):      # --gpus N without a launcher: N fresh ranks (image-parallel)
+        return
+    _run(args)
+
+
+def _run(args):
     model_type, class_name, resolution, scale = args.model_type, args.classe, args.resolution, args.scale
     if args.run_dir:
         inf = infer_from_run_dir(args.run_dir)
@@ -188,9 +209,11 @@ def main(argv=None):
                     data_root=args.data_root)
     opt.test_only = True
     model = Model(opt, None, dual_model=(model_type == 'drn-l'))
-    good = [(lr, hr) for _, lr, hr in iter_split(opt.data_root, class_name, 'good', scale, opt.n_colors)]
-    bad = [(lr, hr) for _, lr, hr in iter_split(opt.data_root, class_name, 'bad', scale, opt.n_colors)]
-    evaluate_on_test(opt, model, good, bad, rank, world)
+    g = list(iter_split(opt.data_root, class_name, 'good', opt.scale, opt.n_colors))
+    b = list(iter_split(opt.data_root, class_name, 'bad', opt.scale, opt.n_colors))
+    out_dir = args.output_dir or (os.path.join(args.run_dir, 'eval_results') if args.run_dir else './workspace/eval_results')
+    evaluate_on_test(opt, model, [(lr, hr) for _, lr, hr in g], [(lr, hr) for _, lr, hr in b], rank, world,
+                     names=[n for n, _, _ in g] + [n for n, _, _ in b], output_dir=out_dir, save_images=args.save_images)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

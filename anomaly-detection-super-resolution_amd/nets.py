@@ -140,6 +140,11 @@ class _EngineModule(nn.Module):
         (optimizer steps and load_state_dict bump ``_version``).  The steady-state cost is one pass
         over a cached tensor list (no module-tree walks on the hot path)."""
         self._ensure_handle(device)
+        if getattr(self, "flat_params", None) is not None:
+            # training mode was enabled: the parameters live in the flat buffer and ONE launch re-packs all of them
+            # (forward packs included), whoever changed them - the fused Adam, a torch optimizer or load_state_dict
+            self._sync_flat()
+            return
         if getattr(self, "_param_cache", None) is None:
             self._param_cache = [(name, self.get_parameter(name)) for name, _ in self._engine_params]
             self._tags = [None] * len(self._param_cache)
@@ -225,7 +230,7 @@ class _EngineModule(nn.Module):
         L.check(self._fn("train_param_floats")(h, C.byref(total)), "train_param_floats")
         flat = torch.zeros(total.value, dtype=torch.float32, device=dev)
         grad = torch.zeros(total.value, dtype=torch.float32, device=dev)
-        views = []
+        views, homes = [], []
         off = C.c_int64()
         with torch.no_grad():
             for i, (name, numel) in enumerate(self._engine_params):
@@ -237,12 +242,14 @@ class _EngineModule(nn.Module):
                 g = grad[off.value:off.value + numel].view(p.shape)
                 p.grad = g
                 views.append((p, g))
+                homes.append((p, v.data_ptr(), v))
         nbytes = C.c_size_t()
         L.check(self._fn("train_arena_bytes")(h, C.byref(nbytes)), "train_arena_bytes")
         self._tarena = torch.zeros(nbytes.value + 256, dtype=torch.uint8, device=dev)
         tp, tb = self._aligned(self._tarena)
         L.check(self._fn("train_bind")(h, tp, tb), "train_bind")
         self.flat_params, self.flat_grads, self._grad_views = flat, grad, views
+        self._flat_homes = homes
         self._synced_version = None
         self._train_ws = {}
         self._anchor = torch.zeros(1, device=dev, requires_grad=True)
@@ -251,17 +258,33 @@ class _EngineModule(nn.Module):
 
     def mark_params_dirty(self) -> None:
         """Tell the engine the flat parameters were changed by something that does not bump tensor versions
-        (the fused Adam kernel)."""
+        (the fused Adam kernel, a replayed hipGraph)."""
         self._synced_version = None
+        self._tags = None
+
+    def _flat_state(self):
+        """Everything that can change the packed weights behind the engine's back.  After ``enable_training`` every
+        Parameter is a view into ``flat_params`` but keeps its OWN version counter: ``torch.optim.Adam.step()`` and
+        ``load_state_dict`` bump ``p._version`` and leave ``flat_params._version`` alone.  A parameter whose storage
+        was replaced (``p.data = t``, ``load_state_dict(assign=True)``) is copied back into its slot and re-homed."""
+        ver = self.flat_params._version
+        for p, ptr, home in self._flat_homes:
+            ver += p._version
+            if p.data_ptr() != ptr:
+                with torch.no_grad():
+                    home.copy_(p.data)
+                    p.data = home
+                ver += 1 << 40
+        return ver
 
     def _sync_flat(self) -> None:
         if getattr(self, "flat_params", None) is None:
             raise RuntimeError(f"{type(self).__name__}: call enable_training() before a training-mode forward")
-        ver = self.flat_params._version
+        ver = self._flat_state()
         if self._synced_version != ver:
             L.check(self._fn("sync_params")(self._handle, L.dptr(self.flat_params), L.current_stream_ptr()), "sync_params")
-            self._synced_version = ver
-            self._tags = None               # the eval path re-checks its own tags
+            self._synced_version = self._flat_state()      # re-homing above does not repeat
+            self._tags = None
 
     def _train_workspace(self, B, H, W, dev):
         key = (B, H, W)
@@ -390,7 +413,7 @@ class DRCT(_EngineModule):
 
     # -- training (C ABI srad_drct_forward_train / srad_drct_backward) ------------------------
     def _can_train(self) -> bool:
-        return True
+        return self.window_size == 8        # the attention backward is built for 8 x 8 windows (128 px / x4: C2, C4)
 
     def enable_training(self) -> "DRCT":
         super().enable_training()
@@ -439,15 +462,28 @@ class DRCT(_EngineModule):
             self.zero_grad()
         wp, wb = self._aligned(self._train_ws[(B, H, W)])
         dx = torch.empty(B, self.cfg.in_chans, H, W, dtype=torch.float32, device=dy.device) if need_dx else None
-        cb = L.BUCKET_FN(lambda user, b: self.on_bucket(b)) if self.on_bucket is not None else L.BUCKET_FN(0)
+        failed = []
+
+        def hook(user, b):                  # ctypes swallows exceptions raised inside a callback: keep the first one
+            try:
+                if not failed:
+                    self.on_bucket(b)
+            except BaseException as e:      # noqa: BLE001 - re-raised below, after the C call has returned
+                failed.append(e)
+        cb = L.BUCKET_FN(hook) if self.on_bucket is not None else L.BUCKET_FN(0)
         L.check(L.lib().srad_drct_backward(self._handle, L.dptr(dy), B, H, W, L.dptr(self._keep), L.dptr(dx),
                                            L.dptr(self.flat_grads), wp, wb, L.current_stream_ptr(), cb, None), "drct_backward")
+        if failed:
+            raise RuntimeError(f"gradient bucket hook failed: {failed[0]!r} - gradients of this step are not reduced") from failed[0]
         return dx
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.training and torch.is_grad_enabled():
             if not x.is_cuda:
                 raise RuntimeError("srad_amd runs on the GPU only (HIP engine); got a CPU tensor - there is no CPU fallback")
+            if not self._can_train():
+                raise NotImplementedError(f"DRCT: the HIP backward pass is built for window size 8 (got {self.window_size}); "
+                                          "run other window sizes under torch.no_grad() / .eval()")
             if x.dim() != 4 or x.shape[1] != self.cfg.in_chans:
                 raise ValueError(f"expected a [B, {self.cfg.in_chans}, H, W] tensor")
             if x.shape[2] % self.window_size or x.shape[3] % self.window_size:

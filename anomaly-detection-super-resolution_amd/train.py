@@ -72,6 +72,46 @@ class FusedAdam:
         self.param_groups[0]["lr"] = float(sd["lr"])
 
 
+class TensorAdam:
+    """The same Adam kernel applied tensor by tensor: the optimizer of a dual regression model (two small convolution
+    weights; src/trainer.py:62-73).  ``step(grad_scale)`` divides the (all-reduced) gradients by the world size."""
+
+    def __init__(self, params, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        self.params = [p for p in params]
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), tuple(betas), float(eps), float(weight_decay)
+        self.state = [(torch.zeros_like(p.data), torch.zeros_like(p.data)) for p in self.params]
+        self.step_count = 0
+        self.param_groups = [{"lr": self.lr}]
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        for p in self.params:
+            p.grad = None
+
+    def step(self, grad_scale: float = 1.0) -> None:
+        self.step_count += 1
+        lr = float(self.param_groups[0]["lr"])
+        for p, (m, v) in zip(self.params, self.state):
+            if p.grad is None:
+                continue
+            g = p.grad.detach().float().contiguous()
+            if not p.data.is_contiguous():
+                raise RuntimeError("TensorAdam needs contiguous parameters")
+            L.check(L.lib().srad_adam_step(L.dptr(p.data), L.dptr(g), L.dptr(m), L.dptr(v), p.numel(), lr, self.betas[0],
+                                           self.betas[1], self.eps, self.weight_decay, self.step_count, float(grad_scale),
+                                           L.current_stream_ptr()), "adam_step")
+
+    def state_dict(self):
+        return {"step": self.step_count, "lr": self.param_groups[0]["lr"],
+                "exp_avg": [m for m, _ in self.state], "exp_avg_sq": [v for _, v in self.state]}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.param_groups[0]["lr"] = float(sd["lr"])
+        for (m, v), a, b in zip(self.state, sd["exp_avg"], sd["exp_avg_sq"]):
+            m.copy_(a)
+            v.copy_(b)
+
+
 def cosine_lr(base_lr: float, epoch: int, t_max: float, eta_min: float) -> float:
     """CosineAnnealingLR closed form (src/trainer.py:76-83: T_max = epochs, stepped once per epoch)."""
     return eta_min + (base_lr - eta_min) * (1.0 + math.cos(math.pi * epoch / t_max)) / 2.0
@@ -134,16 +174,22 @@ class GradReducer:
 
 
 def train_step(model, lr_img: torch.Tensor, hr_img: torch.Tensor, optimizer: FusedAdam,
-               reducer: Optional[GradReducer] = None) -> torch.Tensor:
-    """One iteration of Trainer.train for DRCT (src/trainer.py:161-205): zero_grad, forward, L1 loss,
-    backward, (all-reduce,) Adam.  Returns the loss as a 0-d device tensor (no host sync)."""
+               reducer: Optional[GradReducer] = None, loss_fn=None, note=None) -> torch.Tensor:
+    """One iteration of Trainer.train for DRCT (src/trainer.py:161-205): zero_grad, forward, loss, backward,
+    (all-reduce,) Adam.  Returns the loss as a 0-d device tensor (no host sync).  ``loss_fn``: a ``loss.Loss`` whose
+    ``value_and_grad`` replaces the built-in nn.L1Loss; ``note``: a ``loss.Loss`` that only logs the value."""
     from . import metrics as M
     optimizer.zero_grad()
     sr = model._forward_train(lr_img)
-    loss = M.l1_loss(sr, hr_img)
-    dy = torch.empty_like(sr)
-    L.check(L.lib().srad_l1_grad(L.dptr(sr), L.dptr(hr_img), L.dptr(dy), sr.numel(), 1.0 / sr.numel(),
-                                 L.current_stream_ptr()), "l1_grad")
+    if loss_fn is not None:
+        loss, dy = loss_fn.value_and_grad(sr, hr_img)
+    else:
+        loss = M.l1_loss(sr, hr_img)
+        dy = torch.empty_like(sr)
+        L.check(L.lib().srad_l1_grad(L.dptr(sr), L.dptr(hr_img), L.dptr(dy), sr.numel(), 1.0 / sr.numel(),
+                                     L.current_stream_ptr()), "l1_grad")
+        if note is not None:
+            note.note([loss])
     model._backward(dy, need_dx=False)
     if reducer is not None:
         reducer.finish()
@@ -206,22 +252,25 @@ class GraphedTrainStep:
         return loss.clone()                            # the graph's own output buffer is overwritten by the next replay
 
 
-def drn_loss(sr, lr_list, hr, sr2lr, dual_weight: float = 0.1) -> torch.Tensor:
-    """DRN training loss (src/trainer.py:168-185): L1(sr[-1], hr) + sum_j L1(sr[j], lr[j]) over the coarser outputs
-    + dual_weight * sum_i L1(dual_i(sr[i - n]), lr[i]).  ``lr_list`` = [LR_x(max), ..., LR_x2] coarse -> fine, as the
-    reference loader yields it."""
-    l1 = torch.nn.functional.l1_loss
-    loss_primary = l1(sr[-1], hr)
+def drn_loss(sr, lr_list, hr, sr2lr, dual_weight: float = 0.1, loss_fn=None) -> torch.Tensor:
+    """DRN training loss (src/trainer.py:168-185): loss(sr[-1], hr) + sum_j loss(sr[j], lr[j]) over the coarser outputs
+    + dual_weight * sum_i loss(dual_i(sr[i - n]), lr[i]).  ``lr_list`` = [LR_x(max), ..., LR_x2] coarse -> fine, as the
+    reference loader yields it.  ``loss_fn``: a ``loss.Loss`` (default: the engine's nn.L1Loss reduction); either way the
+    values and the gradients into the SR outputs are the engine's reductions, autograd only chains them."""
+    if loss_fn is None:
+        from .loss import L1Loss
+        loss_fn = L1Loss()
+    loss_primary = loss_fn(sr[-1], hr)
     for i in range(1, len(sr)):
-        loss_primary = loss_primary + l1(sr[i - 1 - len(sr)], lr_list[i - len(sr)])
-    loss_dual = l1(sr2lr[0], lr_list[0])
+        loss_primary = loss_primary + loss_fn(sr[i - 1 - len(sr)], lr_list[i - len(sr)])
+    loss_dual = loss_fn(sr2lr[0], lr_list[0])
     for i in range(1, len(sr2lr)):
-        loss_dual = loss_dual + l1(sr2lr[i], lr_list[i])
+        loss_dual = loss_dual + loss_fn(sr2lr[i], lr_list[i])
     return loss_primary + dual_weight * loss_dual
 
 
 def drn_train_step(model, dual_models, lr_list, hr, optimizer, dual_optimizers, dual_weight: float = 0.1,
-                   reducer: Optional["GradReducer"] = None) -> torch.Tensor:
+                   reducer: Optional["GradReducer"] = None, loss_fn=None) -> torch.Tensor:
     """One iteration of Trainer.train for DRN-L with its dual regression models (src/trainer.py:161-205): forward of
     the SR net and of every dual model on the matching SR output, the composite loss, backward through the dual models
     into the SR outputs and through the DRN engine, one Adam step for the SR net and one per dual model."""
@@ -230,15 +279,16 @@ def drn_train_step(model, dual_models, lr_list, hr, optimizer, dual_optimizers, 
         o.zero_grad()
     sr = model(lr_list[0])
     sr2lr = [dual_models[i](sr[i - len(dual_models)]) for i in range(len(dual_models))]
-    loss = drn_loss(sr, lr_list, hr, sr2lr, dual_weight)
+    loss = drn_loss(sr, lr_list, hr, sr2lr, dual_weight, loss_fn)
     loss.backward()
+    scale = 1.0
     if reducer is not None:
         reducer.reduce_all(model.flat_grads, [(0, model.flat_grads.numel())])
         for dm in dual_models:
             for p in dm.parameters():
                 reducer.dist.all_reduce(p.grad, group=reducer.group)
-                p.grad.mul_(reducer.grad_scale)
-    optimizer.step(grad_scale=reducer.grad_scale if reducer is not None else 1.0)
+        scale = reducer.grad_scale
+    optimizer.step(grad_scale=scale)
     for o in dual_optimizers:
-        o.step()
+        o.step(scale) if isinstance(o, TensorAdam) else o.step()
     return loss.detach()

@@ -24,6 +24,32 @@ sys.path.insert(0, ROOT)
 
 PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}      # dense MFMA peaks, MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
+CSRC = os.path.join(ROOT, "anomaly-detection-super-resolution_amd", "csrc")
+
+
+def kernel_source_sha() -> str:
+    """sha256 over the HIP sources: a committed PMC profile is only quoted while it describes THESE kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(CSRC, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_profile(kernel: str):
+    """(counters of `kernel`, file, stale?) from the newest profiles/r*_pmc_counters.json (tools/pmc_summary.py: separate
+    rocprofv3 --pmc passes of `bench.py --no-graph --no-train --no-eval`)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_counters.json")))
+    if not files:
+        return None, None, None
+    try:
+        pmc = json.load(open(files[-1]))
+        return pmc["kernels"].get(kernel), os.path.relpath(files[-1], ROOT), pmc.get("kernel_source_sha") != kernel_source_sha()
+    except Exception:
+        return None, None, None
 
 
 def usable_cores() -> int:
@@ -123,9 +149,10 @@ def train_leg(args, torch, dist, dev, world, rank):
     from srad_amd.train import FusedAdam, GradReducer, train_step
     o = Opt()
     o.precision, o.use_graph = args.dtype, False
-    torch.manual_seed(1)
+    torch.manual_seed(1)                                   # identical replicas ...
     m = DRCT(o).to(dev).train()
     m.enable_training()
+    torch.manual_seed(1 + rank)                            # ... but per-rank DropPath draws (seed + rank)
     opt = FusedAdam(m, lr=1e-4)
     red = GradReducer().attach(m) if world > 1 else None
     B = args.train_batch
@@ -169,8 +196,12 @@ def train_leg(args, torch, dist, dev, world, rank):
            "hr_mpixels_per_s": round(world * B * 128 * 128 * steps / el / 1e6, 3),
            "images_per_s": round(world * B * steps / el, 2),
            "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)],
-           "grad_allreduce": ("RCCL all-reduce of %d per-RDG buckets (%.1f M fp32) overlapped with backward" %
-                              (len(m.grad_buckets), m.flat_grads.numel() / 1e6)) if world > 1 else "none (1 GPU)"}
+           "grad_allreduce": ({"backend": dist.get_backend(), "collective": "all-reduce(SUM) per RDG bucket on a side stream, "
+                               "overlapped with the backward; 1/world folded into Adam", "buckets": len([b for b in m.grad_buckets if b[1] > 0]),
+                               "bytes_per_step": int(4 * sum(n for _, n in m.grad_buckets)),
+                               "largest_bucket_bytes": int(4 * max(n for _, n in m.grad_buckets))}
+                              if world > 1 else "none (1 GPU)"),
+           "droppath_seed": f"1 + rank"}
     if rank == 0:
         L.prof_enable(True)
         train_step(m, lr_img, hr_img, opt, red)
@@ -191,6 +222,37 @@ def train_leg(args, torch, dist, dev, world, rank):
         out["model_tflops"] = round(fl * world / (el / steps) / 1e12, 2)
     del m, opt
     torch.cuda.empty_cache()
+    return out
+
+
+def scorer_leg(torch, dev):
+    """Roofline of the reconstruction-error scorer (HBM-bound, algorithmic bytes = two fp32 luminance
+    planes per pair per window size = 8 H W B).  Two shapes: the MVTec-grid split of the anomaly-eval leg (78 pairs, 128 px,
+    13 window sizes) and one C5 tile pair (1024 px, 102 window sizes); u8 pairs already resident in HBM, timed with
+    events on the launch stream, all window sizes in one call (one SAT build + one evaluation launch per window size)."""
+    from srad_amd import metrics as M
+    out = {}
+    for tag, n, px in (("grid_128px", 78, 128), ("tile_1024px", 2, 1024)):
+        g = torch.Generator(device="cpu").manual_seed(5)
+        hr = torch.randint(0, 256, (n, px, px, 1), generator=g, dtype=torch.uint8).to(dev)
+        sr = (hr.int() + torch.randint(-6, 7, hr.shape, generator=g).to(dev)).clamp(0, 255).to(torch.uint8)
+        sizes = M.sweep_window_sizes(px)
+        M.score_pairs(sr, hr, sizes)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5 if px <= 128 else 2
+        e0.record()
+        for _ in range(reps):
+            M.score_pairs(sr, hr, sizes)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        algo = 8.0 * px * px * n * len(sizes)
+        out[tag] = {"pairs": n, "hr_px": px, "window_sizes": len(sizes), "ms": round(ms, 3),
+                    "pairs_x_windows_per_s": round(n * len(sizes) / (ms * 1e-3), 1),
+                    "roofline": {"bound": "hbm", "achieved": round(algo / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                 "frac": round(algo / (ms * 1e-3) / HBM_PEAK, 4), "traffic": None,
+                                 "algorithmic_bytes": int(algo)}}
     return out
 
 
@@ -298,7 +360,7 @@ def drn_train_leg(args, torch, dev):
     return out
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -313,16 +375,70 @@ def main():
     ap.add_argument("--no-train-graph", action="store_true", help="C4 leg: eager launches instead of one hipGraph per step")
     ap.add_argument("--train-batch", type=int, default=8)
     ap.add_argument("--train-steps", type=int, default=10)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def rank_plan(args, env=None):
+    """Environments of the ranks this process must start: ``--gpus N`` with no launcher around it -> N entries; a rank of
+    ``torch.distributed.run`` (WORLD_SIZE set) or N = 1 -> [] (run in this process)."""
+    from srad_amd.launch import launch_plan
+    return launch_plan(args.gpus, env=env)
+
+
+def parity_mode_leg(model, x, y_bf16, args, torch, dev):
+    """The mode that owns the 1e-3 parity claim: the same C2 forward in fp32 mode (exact-fp32 MFMA v_mfma_f32_16x16x4_f32, the
+    unfused launches), timed like the headline (graph replay), with its own roofline against the 157.3 TFLOP/s fp32 peak."""
+    from srad_amd import _lib as L
+    from srad_amd.nets import DRCT
+    o32 = Opt()
+    o32.precision, o32.use_graph = "fp32", not args.no_graph
+    m32 = DRCT(o32).to(dev).eval()
+    m32.load_state_dict(model.state_dict())
+    steps = max(10, min(args.steps, 50))
+    with torch.no_grad():
+        for _ in range(3):
+            y32 = m32(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            y32 = m32(x)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        m32.use_graph = False
+        L.prof_enable(True)
+        m32(x)
+        torch.cuda.synchronize()
+        L.prof_collect()
+        reps = 5
+        for _ in range(reps):
+            m32(x)
+        torch.cuda.synchronize()
+        prof = L.prof_collect()
+        L.prof_enable(False)
+    B, _, H, W = x.shape
+    flops = m32.flops(B, H, W)
+    dom = max(prof, key=lambda k: prof[k]["ms"])
+    d = prof[dom]
+    ach = d["flops"] / (d["ms"] * 1e-3)
+    out = {"dtype": "fp32", "what": "C2 forward in the fp32 parity mode (exact-fp32 MFMA, six launches per Swin block)",
+           "ms_per_step": round(dt * 1e3, 4), "hr_mpixels_per_s": round(B * H * 4 * W * 4 / dt / 1e6, 3),
+           "model_tflops": round(flops / dt / 1e12, 2),
+           "roofline": {"kernel": dom, "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": PEAK["fp32"] / 1e12,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK["fp32"], 4), "traffic": None,
+                        "launches_per_step": d["launches"] // reps, "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 3)},
+           "bf16_vs_fp32_mode_max_rel": float(f"{float((y_bf16 - y32).abs().max() / y32.abs().max()):.3e}")}
+    return out, y32, m32
+
+
+def run_rank(args):
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
+    if args.gpus != world:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; the launcher's WORLD_SIZE wins", file=sys.stderr)
     n_gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
@@ -330,7 +446,7 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm (xGMI between the GPUs of a node)
 
     from srad_amd import _lib as L
     from srad_amd.nets import DRCT
@@ -338,7 +454,7 @@ def main():
     opt = Opt()
     opt.precision = args.dtype
     opt.use_graph = not args.no_graph
-    torch.manual_seed(1)                                   # reference seed (src/main.py:41,89)
+    torch.manual_seed(1)                                   # reference seed (src/main.py:41,89): identical replicas
     model = DRCT(opt).to(dev).eval()
     B, H, W, s = args.batch, 32, 32, 4
     g = torch.Generator(device="cpu").manual_seed(1 + rank)
@@ -384,11 +500,13 @@ def main():
         "config": {"workload": "C2: DRCT-L x4 forward, MVTec-grid shape, 128px HR, batch 4 per GPU "
                                "(LR [4,1,32,32] fp32 -> HR [4,1,128,128]), window 8, 12 RDG x 5 Swin blocks",
                    "per_gpu_batch": B, "parallelism": f"image-parallel x{n_gpus} (no collective)",
-                   "hipgraph": bool(opt.use_graph)},
+                   "hipgraph": bool(opt.use_graph),
+                   "ranks": f"{world} process(es), one per GPU" + (f", backend {dist.get_backend()} (RCCL)" if world > 1 else "")},
     }
 
     if not args.no_train:
         try:
+            torch.manual_seed(1)                           # the replica's weights: same seed on every rank ...
             result["train"] = train_leg(args, torch, dist, dev, world, rank)
         except Exception as e:          # the headline line must survive a failure of this extra leg
             result["train"] = {"error": f"{type(e).__name__}: {e}"}
@@ -415,23 +533,27 @@ def main():
         dom = max(prof, key=lambda k: prof[k]["ms"])
         d = prof[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3)
-        traffic, traffic_src = None, None
-        try:                                   # PMC bytes per launch of the same workload (tools/pmc_summary.py)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r01_pmc_traffic.json: " + pmc["source"]
-        except Exception:
-            pass
-        result["roofline"] = {
+        pmc, pmc_file, stale = pmc_profile(dom)
+        roof = {
             "kernel": dom, "bound": "mfma", "achieved": round(achieved / 1e12, 2), "peak": PEAK[args.dtype] / 1e12,
-            "unit": "TFLOP/s", "frac": round(achieved / PEAK[args.dtype], 4), "traffic": traffic,
-            "traffic_source": traffic_src,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK[args.dtype], 4),
+            "traffic": None if (pmc is None or stale) else pmc.get("hbm_bytes_per_launch"),
             "launches_per_step": d["launches"] // reps,
             "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 3),
             "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 4),
             "algorithmic_mbytes_per_launch": round(d["bytes"] / d["launches"] / 1e6, 3),
             "share_of_kernel_time": round(d["ms"] / total_ms, 3),
         }
+        if pmc is not None:
+            # counters come from separate rocprofv3 --pmc passes of this same workload (a PMC pass cannot run inside this
+            # process); they are quoted only while the profile's source hash equals the kernels that just ran
+            roof["pmc_source"] = pmc_file
+            roof["pmc_stale"] = bool(stale)
+            if not stale:
+                for k in ("mfma_busy", "mfma_busy_note", "valu_busy", "wait_frac", "lds_bank_conflict_frac", "dispatch_us"):
+                    if k in pmc:
+                        roof[k] = pmc[k]
+        result["roofline"] = roof
         result["kernels"] = {k: {"launches_per_step": v["launches"] // reps,
                                  "avg_us": round(v["ms"] * 1e3 / v["launches"], 3),
                                  "ms_per_step": round(v["ms"] / reps, 4),
@@ -439,6 +561,13 @@ def main():
                                  "gbytes_per_s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
                              for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
 
+        y32 = None
+        if n_gpus == 1:
+            try:
+                result["parity_mode"], y32, m32 = parity_mode_leg(model, x, y, args, torch, dev)
+                del m32
+            except Exception as e:
+                result["parity_mode"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and n_gpus == 1:
             # the reference's --device cpu path, restated (oracle), same weights, same batch, fp32
             from oracle import sr_ref as R
@@ -463,8 +592,16 @@ def main():
                                                 f"the cores this job may use, host has {os.cpu_count()} logical cores"}
             result["speedup_vs_cpu"] = round(value / (hr_px / cpu_t / 1e6), 1)
             result["max_rel_err_vs_cpu_fp32"] = float(f"{err:.3e}")
+            if y32 is not None and isinstance(result.get("parity_mode"), dict) and "error" not in result["parity_mode"]:
+                e32 = float((y32.cpu() - ref).abs().max() / ref.abs().max())
+                result["parity_mode"]["max_rel_err_vs_cpu_fp32"] = float(f"{e32:.3e}")
+                result["parity_mode"]["speedup_vs_cpu"] = round(result["parity_mode"]["hr_mpixels_per_s"] / (hr_px / cpu_t / 1e6), 1)
         if n_gpus == 1 and not args.no_eval:
             result["anomaly_eval"] = anomaly_eval_leg(model, args, torch)
+            try:
+                result["scorer"] = scorer_leg(torch, dev)
+            except Exception as e:
+                result["scorer"] = {"error": f"{type(e).__name__}: {e}"}
             result["eval_1024px_tile"] = c5_leg(args, torch, dev)
             result["drn_forward"] = c3_leg(args, torch, dev)
             if not args.no_train:
@@ -472,10 +609,22 @@ def main():
                     result["drn_train"] = drn_train_leg(args, torch, dev)
                 except Exception as e:                    # a secondary leg never takes the headline line down
                     result["drn_train"] = {"error": f"{type(e).__name__}: {e}"}
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    plan = rank_plan(args)
+    if plan:
+        # --gpus N without a launcher: start N ranks from THIS process, which has not touched the GPU (no torch.cuda call
+        # above); rank 0 prints the JSON line, a failing rank makes the parent exit non-zero
+        from srad_amd.launch import spawn
+        spawn(run_rank, args.gpus, (args,))
+        return
+    run_rank(args)
 
 
 if __name__ == "__main__":

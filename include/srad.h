@@ -190,6 +190,26 @@ int srad_roc_auc(const int32_t* labels, const double* scores, int n, double* auc
 int srad_l1_workspace_bytes(size_t* bytes);
 int srad_l1_loss(const float* a, const float* b, int64_t n, double* out, void* workspace, void* stream);
 
+/* The loss types of the reference's loss factory `Loss(opt, ckp)` (src/loss.py:72-121; the CLI only ever builds '1*L1'):
+ *   SRAD_LOSS_L1   nn.L1Loss(reduction='mean')                     (src/loss.py:84)
+ *   SRAD_LOSS_MSE  nn.MSELoss()                                    (src/loss.py:82)
+ *   SRAD_LOSS_PSNR PSNRLoss: -10 log10(255^2 / (mse + 1e-8))       (src/loss.py:63-70)
+ *   SRAD_LOSS_SSIM SSIMLoss / calc_ssim: sum(1 - ssim_map) / batch_size with the 10-px shave, zero-padded 11x11 mean
+ *                  filter and the 255^2-scaled constants           (src/loss.py:9-61)
+ * sr [B,C,sH,sW] and hr [B,C,H,W] fp32 NCHW (sH, sW may exceed H, W only for SSIM, which crops sr like the reference).
+ * forward: out2[0] = loss, out2[1] = state for the backward (device doubles).  backward: dsr (+)= weight * gscale_dev[0]
+ * * dLoss/dsr (gscale_dev may be NULL = 1); SSIM's backward reads the workspace its forward filled. */
+#define SRAD_LOSS_L1 0
+#define SRAD_LOSS_MSE 1
+#define SRAD_LOSS_PSNR 2
+#define SRAD_LOSS_SSIM 3
+int srad_loss_workspace_bytes(int kind, int B, int C, int H, int W, size_t* bytes);
+int srad_loss_forward(int kind, const float* sr, const float* hr, int B, int C, int sH, int sW, int H, int W, float rgb_range,
+                      int batch_size, double* out2, void* workspace, size_t workspace_bytes, void* stream);
+int srad_loss_backward(int kind, const float* sr, const float* hr, int B, int C, int sH, int sW, int H, int W, float rgb_range,
+                       int batch_size, const double* fwd_out2, const float* gscale_dev, float weight, float* dsr, int accumulate,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------ single operators
  * NHWC / token-major fp32 activations [rows][ld]; channel counts and row strides multiples of 4 floats. */
 /* Linear / 1x1 conv / 3x3 conv (pad 1, stride 1|2) with fused prologue + epilogue:
@@ -208,6 +228,25 @@ int srad_op_window_attn(int precision, const float* qkv, float* out, const float
 /* nn.LayerNorm over the last dimension, eps 1e-5 (src/drct.py:798,833) */
 int srad_op_layernorm(const float* x, int ldx, float* y, int ldy, int rows, int C, const float* g, const float* b,
                       void* stream);
+
+/* The two fused launches a Swin block becomes in bf16 mode with 8 x 8 windows (BASELINE configs C2 / C4; what bench.py
+ * times).  Weights in PyTorch layout (device fp32), packed into `scratch` (>= srad_op_swin_scratch_bytes, 256-byte aligned).
+ *   srad_op_qkv_attn : norm1 -> attn.qkv -> cyclic shift + window partition -> softmax(q k^T * scale + relative position
+ *                      bias + 0/-100 shift mask) v -> window reverse + shift back
+ *                      (SwinTransformerBlock.forward src/drct.py:477-504 up to attn.proj; WindowAttention.forward 271-299)
+ *                      x [B*H*W][ldx] (columns [0,d)) , w_qkv [3d][d], b_qkv [3d], table [225][heads] -> out [B*H*W][d]
+ *   srad_op_mlp_block: x1 = shortcut + attn.proj(attn); x2 = x1 + mlp(norm2(x1)) (src/drct.py:300, 509-510, 184-190), then
+ *                      the RDG's 1x1 adjust conv: y[:, yoff:yoff+no] = act(adjust(x2) + b) * alpha (+ r) (src/drct.py:389-396)
+ *                      fm = token rows per workgroup (16 | 32 | 64, 0 = the engine's choice for M) */
+size_t srad_op_swin_scratch_bytes(int d, int heads, int m, int no);
+int srad_op_qkv_attn(const float* x, int ldx, int B, int H, int W, int shift, int d, int heads, const float* ln_g,
+                     const float* ln_b, const float* w_qkv, const float* b_qkv, const float* table, float* out, void* scratch,
+                     size_t scratch_bytes, void* stream);
+int srad_op_mlp_block(int M, int d, int m, int no, int fm, const float* attn, const float* shortcut, int ld_short,
+                      const float* w_proj, const float* b_proj, const float* ln_g, const float* ln_b, const float* w_fc1,
+                      const float* b_fc1, const float* w_fc2, const float* b_fc2, const float* w_adj, const float* b_adj, int act,
+                      float slope, float alpha, const float* r, int ldr, float* y, int ldy, int yoff, void* scratch,
+                      size_t scratch_bytes, void* stream);
 
 /* Backward operators (autograd of the rows above).
  * Weight/bias gradient of Linear / conv: dw[N][Cin][taps] += alpha * dy^T A(x), db[N] += alpha * colsum(dy);
@@ -267,6 +306,8 @@ int srad_bench_mlp_block(int M, int d, int m, int no, const float* attn, const f
                          void* stream);
 int srad_bench_window_attn(int precision, const float* qkv, float* out, const float* table, int B, int H, int W, int ws,
                            int shift, int d, int heads, int hdp, int iters, float* us_out, void* stream);
+int srad_bench_qkv_attn(const float* x, int ldx, int B, int H, int W, int shift, int d, int heads, const float* w_fp32,
+                        float* out, void* scratch, size_t scratch_bytes, int iters, float* us_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -68,13 +68,17 @@ def rel_pos_index(ws: int) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------ DRCT
-def window_attention(sd, p: str, x: torch.Tensor, ws: int, heads: int, mask) -> torch.Tensor:
-    """src/drct.py:271-302.  x: [B_, N, C]"""
+def attention_core(sd, p: str, x: torch.Tensor, ws: int, heads: int, mask, rnd=None) -> torch.Tensor:
+    """src/drct.py:271-299 (everything of WindowAttention.forward before ``proj``).  x: [B_, N, C] -> [B_, N, C].
+    ``rnd`` (tests of the bf16 kernels only): the rounding the engine's bf16 mode applies to MFMA operands - q (after the
+    scale), k, v and the un-normalised probabilities exp(s - max); the row sum stays fp32 and un-rounded, as in the kernels."""
     B_, N, C = x.shape
     qkv = F.linear(x, _t(sd, p + "qkv.weight"), _t(sd, p + "qkv.bias"))
     qkv = qkv.reshape(B_, N, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
     q = q * ((C // heads) ** -0.5)
+    if rnd is not None:
+        q, k, v = rnd(q), rnd(k), rnd(v)
     attn = q @ k.transpose(-2, -1)
     table = _t(sd, p + "relative_position_bias_table")
     idx = rel_pos_index(ws)
@@ -84,27 +88,50 @@ def window_attention(sd, p: str, x: torch.Tensor, ws: int, heads: int, mask) -> 
         nW = mask.shape[0]
         attn = attn.view(B_ // nW, nW, heads, N, N) + mask.unsqueeze(1).unsqueeze(0)
         attn = attn.view(-1, heads, N, N)
-    attn = torch.softmax(attn, dim=-1)
-    x = (attn @ v).transpose(1, 2).reshape(B_, N, C)
+    if rnd is None:
+        attn = torch.softmax(attn, dim=-1)
+        out = attn @ v
+    else:
+        e = torch.exp(attn - attn.amax(-1, keepdim=True))
+        out = (rnd(e) @ v) / e.sum(-1, keepdim=True)
+    return out.transpose(1, 2).reshape(B_, N, C)
+
+
+def window_attention(sd, p: str, x: torch.Tensor, ws: int, heads: int, mask, rnd=None, taps=None) -> torch.Tensor:
+    """src/drct.py:271-302.  x: [B_, N, C]"""
+    x = attention_core(sd, p, x, ws, heads, mask, rnd)
+    if taps is not None:
+        taps["attn_windows"] = x
+    if rnd is not None:
+        x = rnd(x)
     return F.linear(x, _t(sd, p + "proj.weight"), _t(sd, p + "proj.bias"))
 
 
 def swin_block(sd, p: str, x: torch.Tensor, H: int, W: int, ws: int, heads: int,
-               shift: int, keep=None) -> torch.Tensor:
+               shift: int, keep=None, rnd=None, taps=None) -> torch.Tensor:
     """src/drct.py:472-512.  x: [B, H*W, C].  ``keep`` (optional [B] tensor of 0/1 divided
     by keep_prob, or a pair of them: the module's drop_path is CALLED twice per block, drct.py:509-510,
     so the attention and MLP branches draw independent masks) restates DropPath in training mode
-    (drct.py:107-119); None = eval."""
+    (drct.py:107-119); None = eval.  ``rnd``: operand rounding of the engine's bf16 mode (see ``attention_core``), also
+    applied to LayerNorm1/2 outputs, the attention output and GELU(fc1) - the A operands of the following GEMMs.
+    ``taps`` receives 'attn' (attention output before proj, token order) and 'x1' (after the first residual)."""
     B, L, C = x.shape
     keep_a, keep_m = keep if isinstance(keep, (tuple, list)) else (keep, keep)
+    r = (lambda t: t) if rnd is None else rnd
     shortcut = x
-    x = F.layer_norm(x, (C,), _t(sd, p + "norm1.weight"), _t(sd, p + "norm1.bias"), 1e-5)
+    x = r(F.layer_norm(x, (C,), _t(sd, p + "norm1.weight"), _t(sd, p + "norm1.bias"), 1e-5))
     x = x.view(B, H, W, C)
     if shift > 0:
         x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))
     xw = window_partition(x, ws).view(-1, ws * ws, C)
     mask = calculate_mask(H, W, ws, shift) if shift > 0 else None
-    aw = window_attention(sd, p + "attn.", xw, ws, heads, mask)
+    wt = {} if taps is not None else None
+    aw = window_attention(sd, p + "attn.", xw, ws, heads, mask, rnd, wt)
+    if taps is not None:
+        a = window_reverse(wt["attn_windows"].view(-1, ws, ws, C), ws, H, W)
+        if shift > 0:
+            a = torch.roll(a, shifts=(shift, shift), dims=(1, 2))
+        taps["attn"] = a.reshape(B, H * W, C)
     x = window_reverse(aw.view(-1, ws, ws, C), ws, H, W)
     if shift > 0:
         x = torch.roll(x, shifts=(shift, shift), dims=(1, 2))
@@ -112,9 +139,11 @@ def swin_block(sd, p: str, x: torch.Tensor, H: int, W: int, ws: int, heads: int,
     if keep_a is not None:
         x = x * keep_a.view(B, 1, 1)
     x = shortcut + x
-    y = F.layer_norm(x, (C,), _t(sd, p + "norm2.weight"), _t(sd, p + "norm2.bias"), 1e-5)
+    if taps is not None:
+        taps["x1"] = x
+    y = r(F.layer_norm(x, (C,), _t(sd, p + "norm2.weight"), _t(sd, p + "norm2.bias"), 1e-5))
     y = F.linear(y, _t(sd, p + "mlp.fc1.weight"), _t(sd, p + "mlp.fc1.bias"))
-    y = F.gelu(y)                                   # exact erf GELU (drct.py:175,184-190)
+    y = r(F.gelu(y))                                # exact erf GELU (drct.py:175,184-190)
     y = F.linear(y, _t(sd, p + "mlp.fc2.weight"), _t(sd, p + "mlp.fc2.bias"))
     if keep_m is not None:
         y = y * keep_m.view(B, 1, 1)

@@ -23,3 +23,9 @@ def sr_golden():
 def scorer_golden():
     import numpy as np
     return np.load(os.path.join(GOLDEN, "scorer_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def host_golden():
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, "host_golden.npz"))

@@ -94,39 +94,41 @@ def test_drn_x8_preset_training_is_refused():
         m(torch.zeros(1, 1, 4, 4, device="cuda"))
 
 
-def test_drn_trainer_mirror_runs_an_epoch_on_png_folders(tmp_path):
-    """src/trainer.py's DRN loop on the folder layout src/data.py reads (HR + LR_2 + LR_4): dual models, their Adam
-    optimizers and cosine schedules, checkpoints incl. dual_model_latest.pt."""
+def test_cli_train_drn_writes_run_dir_with_dual_models(tmp_path):
+    """src/main.py train_drn on the folder layout src/data.py reads (HR + LR_2 + LR_4): dual models, their Adam optimizers
+    (the engine's kernel, tensor by tensor) and cosine schedules, run-dir files incl. dual_model_*.pt and dual_optimizers.pt;
+    the composite loss falls over two virtual epochs."""
+    import os
     from PIL import Image
+    from srad_amd import main as Mn
     from srad_amd import options as Opt
-    from srad_amd.model import Model
-    from srad_amd.trainer import FolderPairs, Trainer
     rng = np.random.default_rng(0)
-    d = tmp_path / "grid" / "train" / "good"
-    for sub in ("HR", "LR_2", "LR_4"):
-        (d / sub).mkdir(parents=True)
     yy, xx = np.mgrid[0:64, 0:64]
-    for i in range(4):
-        hr = (127 + 90 * np.sin(xx / (3.0 + i)) * np.cos(yy / 4.0) + rng.normal(0, 4, (64, 64))).clip(0, 255).astype(np.uint8)
-        Image.fromarray(hr).save(d / "HR" / f"{i}.png")
-        Image.fromarray(hr.reshape(32, 2, 32, 2).mean((1, 3)).round().astype(np.uint8)).save(d / "LR_2" / f"{i}.png")
-        Image.fromarray(hr.reshape(16, 4, 16, 4).mean((1, 3)).round().astype(np.uint8)).save(d / "LR_4" / f"{i}.png")
-    opt = Opt.build_opt('drn-l', 'grid', 64, 4, batch_size=2, dtype='fp32', data_root=str(tmp_path), save=str(tmp_path / "run"), epochs=2)
-    opt.n_blocks, opt.print_every = 2, 1
-    assert opt.scale == [2, 4] and opt.weight_decay == 1e-8
-    torch.manual_seed(1)
-    model = Model(opt, None, dual_model=True)
-    ds = FolderPairs(opt.data_dir, list(opt.scale), 1)
-    assert ds.multi and [a.shape for a in ds.items[0][1]] == [(16, 16, 1), (32, 32, 1)]
-    t = Trainer(opt, ds, model, dual_model=True, val_set=ds)
-    while not t.terminate():
-        t.train()
-        model.save(opt.save, is_best=True)
-    assert len(t.loss_log) == 2 and t.loss_log[1] < t.loss_log[0]
-    duals = torch.load(tmp_path / "run" / "model" / "dual_model_latest.pt", weights_only=True)
+    for split, n in (("train", 4), ("val", 1)):
+        d = tmp_path / "data" / "grid" / split / "good"
+        for sub in ("HR", "LR_2", "LR_4"):
+            (d / sub).mkdir(parents=True)
+        for i in range(n):
+            hr = (127 + 90 * np.sin(xx / (3.0 + i)) * np.cos(yy / 4.0) + rng.normal(0, 4, (64, 64))).clip(0, 255).astype(np.uint8)
+            Image.fromarray(hr).save(d / "HR" / f"{i}.png")
+            Image.fromarray(hr.reshape(32, 2, 32, 2).mean((1, 3)).round().astype(np.uint8)).save(d / "LR_2" / f"{i}.png")
+            Image.fromarray(hr.reshape(16, 4, 16, 4).mean((1, 3)).round().astype(np.uint8)).save(d / "LR_4" / f"{i}.png")
+    args = Opt.parse_train_args(["--model-type", "drn-l", "--classe", "grid", "--resolution", "64", "--scale", "4", "--epochs", "2",
+                                 "--batch-size", "2", "--data-root", str(tmp_path / "data"), "--save-dir", str(tmp_path / "exp")])
+    opt = Mn.build_train_opt(args)
+    assert opt.scale == [2, 4] and opt.weight_decay == 1e-8 and (opt.n_blocks, opt.n_feats) == (40, 20) and opt.test_every == 128
+    opt.n_blocks, opt.test_every, opt.print_every = 2, 4, 2
+    Mn.train_drn(opt)
+    run = opt.save
+    assert {"config.txt", "log.txt", "loss_log.pt", "optimizer.pt", "dual_optimizers.pt", "psnr_ssim_log.pt"} <= set(os.listdir(run))
+    assert sorted(os.listdir(os.path.join(run, "model"))) == ["dual_model_best.pt", "dual_model_latest.pt", "model_best.pt", "model_latest.pt"]
+    duals = torch.load(os.path.join(run, "model", "dual_model_latest.pt"), weights_only=True)
     assert isinstance(duals, list) and len(duals) == 2 and set(duals[0]) == {"dual_module.0.0.weight", "dual_module.1.weight"}
-    psnr, ssim = t.test()
-    assert np.isfinite(psnr)
+    dopt = torch.load(os.path.join(run, "dual_optimizers.pt"))
+    assert sorted(dopt) == [0, 1] and dopt[0]["step"] == 8
+    loss_log = torch.load(os.path.join(run, "loss_log.pt"))
+    assert tuple(loss_log.shape) == (2, 1) and float(loss_log[1, 0]) < float(loss_log[0, 0])
+    assert "scale: [2, 4]" in open(os.path.join(run, "config.txt")).read()
 
 
 def test_drn_bf16_gradients_close_to_fp32_mode():

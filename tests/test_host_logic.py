@@ -166,34 +166,53 @@ def test_cosine_schedule_matches_torch():
         sch.step()
 
 
-def test_folder_pairs_and_rank_sharded_batches(tmp_path):
-    """The training data reader (layout of src/data.py:109-147) and the minibatch sharding of the data-parallel trainer:
-    every rank draws the same permutation and takes rank::world of each global batch, so the union over the ranks is
-    the reference's batch and no image is seen twice in an epoch."""
-    from PIL import Image
-    from srad_amd.trainer import FolderPairs, batches
-    d = tmp_path / "good"
-    for sub in ("HR", "LR_2", "LR_4"):
-        (d / sub).mkdir(parents=True)
-    for i in range(10):
-        hr = np.full((16, 16), 10 * i, dtype=np.uint8)
-        Image.fromarray(hr).save(d / "HR" / f"{i:02d}.png")
-        Image.fromarray(hr[::2, ::2]).save(d / "LR_2" / f"{i:02d}.png")
-        Image.fromarray(hr[::4, ::4]).save(d / "LR_4" / f"{i:02d}.png")
-    single = FolderPairs(str(d), 4, 1)
-    assert len(single) == 10 and not single.multi and single.items[3][1].shape == (4, 4, 1)
-    multi = FolderPairs(str(d), [2, 4], 1)
-    assert multi.multi and [a.shape for a in multi.items[0][1]] == [(4, 4, 1), (8, 8, 1)]       # coarsest first
-    seen = []
-    for rank in range(2):
-        for lr, hr, names in batches(single, 4, epoch=3, rank=rank, world=2):
-            assert lr.shape == (2, 1, 4, 4) and hr.shape == (2, 1, 16, 16) and lr.dtype == torch.float32
-            assert torch.equal(lr[:, 0, 0, 0], hr[:, 0, 0, 0])                                   # pairs stay together
-            seen += list(names)
-    assert len(seen) == 8 and len(set(seen)) == 8                  # 2 full global batches of 4; the ragged tail is dropped
-    one = [n for _, _, names in batches(single, 4, epoch=3) for n in names]
-    assert sorted(one) == sorted(seen)                             # same permutation on every rank
-    lr_list, hr, _ = next(iter(batches(multi, 2, epoch=0, shuffle=False, augment=True)))
-    assert isinstance(lr_list, list) and lr_list[0].shape == (2, 1, 4, 4) and lr_list[1].shape == (2, 1, 8, 8)
-    with pytest.raises(FileNotFoundError):
-        FolderPairs(str(d), 8, 1)
+def test_launch_plan_for_gpus_n():
+    """``--gpus N`` without a launcher starts N ranks (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* on 127.0.0.1); under
+    torch.distributed.run (WORLD_SIZE set) or with one GPU nothing is spawned."""
+    from srad_amd.launch import launch_plan
+    plan = launch_plan(2, port=29555, env={})
+    assert [p["RANK"] for p in plan] == ["0", "1"] and [p["LOCAL_RANK"] for p in plan] == ["0", "1"]
+    assert all(p["WORLD_SIZE"] == "2" and p["MASTER_ADDR"] == "127.0.0.1" and p["MASTER_PORT"] == "29555" for p in plan)
+    assert all(p["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for p in plan)
+    assert launch_plan(1, env={}) == [] and launch_plan(8, env={"WORLD_SIZE": "8"}) == []
+    assert len(launch_plan(8, env={})) == 8 and len({p["MASTER_PORT"] for p in launch_plan(8, env={})}) == 1
+
+
+def test_bench_gpus_flag_builds_a_two_rank_launch():
+    """bench.py --gpus 2 plans two child ranks (the round-1 script silently benchmarked one GPU)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    args = bench.parse_args(["--gpus", "2", "--steps", "3", "--warmup", "1"])
+    plan = bench.rank_plan(args, env={})
+    assert len(plan) == 2 and plan[1]["RANK"] == "1" and plan[0]["WORLD_SIZE"] == "2"
+    assert bench.rank_plan(bench.parse_args(["--gpus", "1"]), env={}) == []
+    assert bench.rank_plan(args, env={"WORLD_SIZE": "2", "RANK": "0"}) == []          # already a rank of torch.distributed.run
+
+
+def test_checkpoint_writes_what_the_evaluator_parses(tmp_path):
+    """Checkpoint (src/checkpoint.py:10-28,53-58): config.txt as 'key: value' lines after a timestamp, log.txt appended
+    by write_log; evaluate.infer_from_run_dir (src/evaluate.py:84-118) reads model / class / resolution / scale back."""
+    from srad_amd import main as Mn
+    from srad_amd.checkpoint import Checkpoint
+    args = Opt.parse_train_args(["--model-type", "drn-l", "--classe", "carpet", "--resolution", "256", "--scale", "4",
+                                 "--save-dir", str(tmp_path), "--batch-size", "8"])
+    o = Mn.build_train_opt(args)
+    assert o.test_every == 32 and o.n_colors == 3 and o.data_dir == "data/mvtec_256/carpet/train/good"
+    assert o.save.startswith(str(tmp_path) + "/drn-l/mvtec_carpet_256_X4") and o.save.endswith("/")
+    o.save = str(tmp_path / "renamed")
+    ck = Checkpoint(o)
+    ck.write_log("hello")
+    ck.write_log("again", refresh=True)
+    ck.done()
+    lines = (tmp_path / "renamed" / "config.txt").read_text().splitlines()
+    assert lines[1] == "" and "model_name: drn-l" in lines and "scale: [2, 4]" in lines and "patch_size: 256" in lines
+    assert (tmp_path / "renamed" / "log.txt").read_text() == "hello\nagain\n"
+    assert (tmp_path / "renamed" / "model").is_dir() and (tmp_path / "renamed" / "results").is_dir()
+    inf = E.infer_from_run_dir(str(tmp_path / "renamed"))
+    assert (inf["model_type"], inf["classe"], inf["resolution"], inf["scale"]) == ("drn-l", "carpet", 256, 4)
+    ck2 = Checkpoint(o)                                                  # an existing run dir is appended to
+    ck2.done()
+    assert (tmp_path / "renamed" / "config.txt").read_text().count("model_name: drn-l") == 2
