@@ -1,6 +1,8 @@
 """GPU: DRCT forward through the C ABI against (a) the golden fixtures the reference produced and
 (b) the oracle, in both precisions.  Bars: fp32 mode <= 1e-3 relative (north_star), measured
-~1e-5; bf16 mode: max error <= 3% of the output range, PSNR vs the fp32 result >= 35 dB."""
+~1e-5; bf16 mode (whole model; the two fused kernels have their own oracle tests at 2e-3 in test_gpu_fused_ops.py): max
+error <= 1% of the output range, PSNR vs the reference's fp32 result >= 50 dB - about 2x the measured 0.4% / 61 dB of the
+full 12-RDG model."""
 import numpy as np
 import pytest
 import torch
@@ -47,8 +49,8 @@ def test_drct_bf16_close_to_reference(sr_golden, name):
     err = np.abs(out - y)
     psnr = 10 * np.log10(rng ** 2 / np.mean(err.astype(np.float64) ** 2))
     print(name, "bf16 max err / range", err.max() / rng, "psnr", psnr)
-    assert err.max() / rng < 3e-2
-    assert psnr > 35.0
+    assert err.max() / rng < 1e-2
+    assert psnr > 50.0
 
 
 def test_drct_graph_replay_and_weight_update(sr_golden):
@@ -107,8 +109,8 @@ def test_fused_mlp_block_matches_unfused_path(sr_golden, monkeypatch):
     rng = float(y.max() - y.min())
     print("fused vs unfused max/range", np.abs(fused - unfused).max() / rng, "fused vs ref", np.abs(fused - y).max() / rng)
     assert np.abs(fused - unfused).max() / rng < 1e-2
-    assert np.abs(fused - y).max() / rng < 3e-2
-    assert 10 * np.log10(rng ** 2 / np.mean((fused - y).astype(np.float64) ** 2)) > 35.0
+    assert np.abs(fused - y).max() / rng < 1e-2
+    assert 10 * np.log10(rng ** 2 / np.mean((fused - y).astype(np.float64) ** 2)) > 50.0
 
 
 def test_c5_window64_attention_geometry_matches_oracle():
