@@ -35,6 +35,9 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+#ifndef SRAD_MLP_NSETS16
+#define SRAD_MLP_NSETS16 3
+#endif
 constexpr int F_LDA = 392;         // LDS row stride of the <=384-wide bf16 activation tile
 constexpr int F_LDH = 520;         // LDS row stride of the <=512-wide hidden tile
 constexpr int F_SC = 128;          // output columns per weight stage
@@ -56,7 +59,7 @@ __device__ __forceinline__ float gelu_fast(float x) {
 // matrices, so at 65536 tokens 16-row tiles move 4096 x 0.5 MB per launch through L2).
 // KCD / KCM = 32-wide k chunks of the block dim / hidden (exact: a stage loads and multiplies only its real chunks; a
 // run-time chunk count meant duplicate loads of chunk 0 or branches around the loads, both measured slower).
-template <int FM, int GD, int KGD, int GM, int KGM, int GN, int KCD, int KCM>
+template <int FM, int GD, int KGD, int GM, int KGM, int GN, int KCD, int KCM, bool STAMP = false>
 __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) {
   static_assert(KGD == (KCD + 7) / 8 && KGM == (KCM + 7) / 8, "k groups are 8 chunks wide");
   constexpr int NRT = FM / 16;       // 16-row MFMA tiles per workgroup
@@ -70,6 +73,18 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
   const int fr = lane & 15, fq = lane >> 4;
   const int m0 = blockIdx.x * FM;
   const int d = p.d, m = p.m, no = p.no;
+  const int dbg = STAMP ? p.dbg : 0;                               // the switch-off experiments exist in the diagnostic build only
+  // diagnostic build only (tools/stamp_bench.py): shader-clock stamps of every wave at the phase boundaries
+  auto stamp = [&](int idx) {
+    if constexpr (STAMP) {
+      unsigned long long t;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (lane == 0) p.stamps[((size_t)blockIdx.x * 8 + wave) * 16 + idx] = t;
+    }
+  };
+  stamp(0);
   constexpr int Kd = KCD * 32, Km = KCM * 32;                    // packed K of the weights
   constexpr int n_proj = GD * KGD, n_fc1 = GM * KGD, n_fc2 = GD * KGM, n_adj = GN * KGD;
   constexpr int n_stages = n_proj + n_fc1 + n_fc2 + n_adj;
@@ -97,7 +112,7 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
   // 8 waves (two per SIMD), each owns 16 output columns of a 128-column stage, i.e. 16 rows of the packed weight that
   // NOBODY else reads: the weights go straight from global memory into MFMA fragment registers, three stages ahead (no
   // LDS stage, no barrier per stage), from the fragment-major pack (one contiguous kilobyte per wave load).
-  constexpr int NSETS = 3;
+  constexpr int NSETS = FM == 16 ? SRAD_MLP_NSETS16 : 3;   // 16-row tiles leave ~100 VGPRs free at 2 waves per SIMD: deeper weight stream
   u32x4 w_reg[NSETS][8];
   auto load_w = [&](auto S, u32x4 (&reg)[8]) {
     constexpr StageGeo sg = geo(decltype(S)::value);
@@ -105,11 +120,15 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     const int nreal = sg.ph == 0 ? d : (sg.ph == 1 ? m : (sg.ph == 2 ? d : no));
     // fragment-major pack: 1 KB tiles (16 rows x 32 k), tile (n / 16, k / 32); this wave's row tile is g * 8 + wave;
     // lane: row fr, k 8 fq .. of the tile - the 64 lanes cover its 1 KB
-    const char* base = w + ((size_t)(sg.g * 8 + wave) * sg.kc + sg.kg * 8) * 1024 + fr * 64 + fq * 16;
-    if ((sg.g * 8 + wave_s) * 16 < nreal) {
+    // A wave whose 16 columns are all padding loads nothing useful - but a load inside a branch makes hipcc's wait-count
+    // pass assume the branch was NOT taken at the join (vmcnt of every older load drops to ~0: the vectors and the activation
+    // tile were waited for together with three whole weight stages).  So the loads are unconditional and such a wave reads one
+    // 16-byte word per load instead (all lanes the same address: one request).
+    const bool live = (sg.g * 8 + wave_s) * 16 < nreal;
+    const char* base = live ? w + ((size_t)(sg.g * 8 + wave) * sg.kc + sg.kg * 8) * 1024 + fr * 64 + fq * 16 : w;
+    const int step = live ? 1024 : 0;
 #pragma unroll
-      for (int cc = 0; cc < sg.nch; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + cc * 1024);
-    }
+    for (int cc = 0; cc < sg.nch; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + cc * step);
   };
   // c[rt] += (A[16 rows][k0 .. k0 + nch*32) . W[16 columns of this wave][..]^T)^T
   auto mma_stage = [&](const __bf16* A, int lda, int k0, int nch, const u32x4 (&reg)[8], f32x4 (&c)[NRT]) {
@@ -130,7 +149,10 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     }
   };
 
-  // ---- issue the independent loads: attn tile, first weight stages, vectors, shortcut in C layout ----
+  // ---- issue the independent loads, in the order their data is needed: the attn tile and the shortcut rows (first GEMM /
+  //      its epilogue), the staged vectors, then the weight stages.  vmcnt retires in issue order, so whatever is issued
+  //      before a load is waited for with it: with the weights first (as it was) the prologue took three dependent round
+  //      trips (stamp build: 6000 of the kernel's 22000 cycles before the first MFMA). ----
   constexpr int NAQ = 32 * GD;                                    // float4 per row of the attn tile actually needed
   constexpr int NAJ = FM * NAQ / 512;                             // float4 per thread
   static_assert(FM * NAQ % 512 == 0, "attn tile must divide over the workgroup");
@@ -141,32 +163,6 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     a_reg[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.attn) + (size_t)(m0 + row) * p.ld_attn * 4 +
                                                (unsigned)min(c, d - 4) * 4u);
   }
-  static_for<0, NSETS>([&](auto Q) { load_w(Q, w_reg[decltype(Q)::value]); });
-  float vq[5];
-  {
-    // staged vectors: [0,384) b_proj, [384,896) b_fc1, [896,1280) b_fc2, [1280,1664) b_adj, [1664,2048) gamma,
-    // [2048,2432) beta (clamped reads; entries past a vector's length are never used)
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      const int i = tid + 512 * q;
-      const float* src; int n, o;
-      if (i < 384) { src = p.b_proj; n = d; o = i; }
-      else if (i < 896) { src = p.b_fc1; n = m; o = i - 384; }
-      else if (i < 1280) { src = p.b_fc2; n = d; o = i - 896; }
-      else if (i < 1664) { src = p.b_adj; n = no; o = i - 1280; }
-      else if (i < 2048) { src = p.ln_g; n = d; o = i - 1664; }
-      else { src = p.ln_b; n = d; o = i - 2048; }
-      vq[q] = src[min(o, n - 1)];
-    }
-  }
-  // DropPath factors of this lane's token rows (training; 1 otherwise)
-  float rs1v[NRT], rs2v[NRT];
-#pragma unroll
-  for (int rt = 0; rt < NRT; ++rt) {
-    const int smp = p.rps > 0 ? (m0 + rt * 16 + fr) / p.rps : 0;
-    rs1v[rt] = p.rs1 ? p.rs1[smp] : 1.f;
-    rs2v[rt] = p.rs2 ? p.rs2[smp] : 1.f;
-  }
   // accumulator layout of this lane: token row 16*rt + fr, columns 128*g + 16*wave + 4*fq + (0..3)
   f32x4 x1[GD][NRT];
 #pragma unroll
@@ -174,11 +170,45 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     const int c4 = min(F_SC * g + 16 * wave + 4 * fq, d - 4);
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt)
-      x1[g][rt] = (p.dbg & 32) ? f32x4{0.f, 0.f, 0.f, 0.f}
+      x1[g][rt] = (dbg & 32) ? f32x4{0.f, 0.f, 0.f, 0.f}
                                : *reinterpret_cast<const f32x4*>(p.shortcut + (size_t)(m0 + rt * 16 + fr) * p.ld_short + c4);
   }
+  // staged vectors: [0,384) b_proj, [384,896) b_fc1, [896,1280) b_fc2, [1280,1664) b_adj, [1664,2048) gamma, [2048,2432) beta.
+  // Wave w < 6 stages vector w: a wave-uniform base pointer (scalar select, no per-lane pointer table in memory) and two
+  // clamped float4 per lane; entries past a vector's length are never used.
+  f32x4 vq[2];
+  int v_off = 0, v_len = 0;
+  {
+    const float* src = p.b_proj; int n = d;
+    if (wave_s == 1) { src = p.b_fc1; n = m; v_off = 384; }
+    else if (wave_s == 2) { src = p.b_fc2; n = d; v_off = 896; }
+    else if (wave_s == 3) { src = p.b_adj; n = no; v_off = 1280; }
+    else if (wave_s == 4) { src = p.ln_g; n = d; v_off = 1664; }
+    else if (wave_s == 5) { src = p.ln_b; n = d; v_off = 2048; }
+    v_len = wave_s == 1 ? 512 : 384;
+    vq[0] = *reinterpret_cast<const f32x4*>(src + min(4 * lane, n - 4));
+    vq[1] = *reinterpret_cast<const f32x4*>(src + min(256 + 4 * lane, n - 4));
+  }
+  // DropPath factors of this lane's token rows (training; 1 otherwise)
+  float rs1v[NRT], rs2v[NRT];
 #pragma unroll
-  for (int q = 0; q < 5; ++q) vec[tid + 512 * q] = vq[q];
+  for (int rt = 0; rt < NRT; ++rt) {
+    const int smp = p.rps > 0 ? (m0 + rt * 16 + fr) / p.rps : 0;
+    // unconditional loads from a global pointer either way (see load_w; a pointer to a __device__ constant would make
+    // these flat loads, which count out of order: hipcc then waits vmcnt(0) for everything)
+    typedef const float __attribute__((address_space(1)))* gfloat_p;   // a select of two kernel-argument pointers is a generic pointer to hipcc
+    const float r1 = ((gfloat_p)(p.rs1 ? p.rs1 : p.b_proj))[p.rs1 ? smp : 0], r2 = ((gfloat_p)(p.rs2 ? p.rs2 : p.b_proj))[p.rs2 ? smp : 0];
+    rs1v[rt] = p.rs1 ? r1 : 1.f;
+    rs2v[rt] = p.rs2 ? r2 : 1.f;
+  }
+  load_w(std::integral_constant<int, 0>{}, w_reg[0]);             // only what the first stage needs rides with the activations:
+  stamp(1);                                                        // the CU's load queue is first-in first-out and ~200 KB of
+                                                                   // weight requests ahead of them cost 3000 cycles (stamp build)
+  if (wave_s < 6) {
+    *reinterpret_cast<f32x4*>(vec + v_off + 4 * lane) = vq[0];
+    if (256 + 4 * lane < v_len) *reinterpret_cast<f32x4*>(vec + v_off + 256 + 4 * lane) = vq[1];
+  }
+  stamp(2);                                                        // the vectors have arrived
   {  // attn tile -> bf16 -> A1 (zero beyond d)
 #pragma unroll
     for (int j = 0; j < NAJ; ++j) {
@@ -189,6 +219,7 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
       *reinterpret_cast<bf16x4*>(A1 + row * F_LDA + c) = h;
     }
   }
+  static_for<1, NSETS>([&](auto Q) { load_w(Q, w_reg[decltype(Q)::value]); });   // the rest of the look-ahead, behind the tile
 
   // ---- phase epilogues (run when the last k-group of a 128-column group is done) ----
   auto col4_of = [&](int g) { return F_SC * g + 16 * wave + 4 * fq; };
@@ -269,7 +300,7 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     for (int rt = 0; rt < NRT; ++rt) {
       f32x4 v = c[rt] + b1;
       if (p.save_hpre && c4 < m) *reinterpret_cast<f32x4*>(p.save_hpre + (size_t)(m0 + rt * 16 + fr) * m + c4) = v;
-      if (!(p.dbg & 4)) {
+      if (!(dbg & 4)) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
       }
@@ -336,22 +367,32 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     u32x4 (&reg)[8] = w_reg[s % NSETS];
     constexpr int Kp = ph == 2 ? Km : Kd;
     constexpr int nch = (Kp >> 5) - kg * 8 < 8 ? (Kp >> 5) - kg * 8 : 8;
-    if constexpr (ls == 0) __syncthreads();            // first stage of a phase: the activation tile (A1 / Hs) and,
+    if constexpr (ls == 0) {
+      stamp(3 + 3 * ph);                               // this wave's previous phase (its epilogue included) is done
+      __syncthreads();                                 // first stage of a phase: the activation tile (A1 / Hs) and,
                                                        // at s == 0, the staged vectors written before are visible
+      stamp(4 + 3 * ph);
+    }
     if constexpr (kg == 0) {
 #pragma unroll
       for (int rt = 0; rt < NRT; ++rt) c[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const bool live = (g * 8 + wave_s) * 16 < (ph == 0 ? d : (ph == 1 ? m : (ph == 2 ? d : no)));
-    if (!(p.dbg & 2) && live) mma_stage(ph == 2 ? Hs : A1, ph == 2 ? F_LDH : F_LDA, kg * 256, nch, reg, c);
-    if (!(p.dbg & 1)) load_w(std::integral_constant<int, s + NSETS>{}, reg);          // refill this set, NSETS stages ahead
-    if (!(p.dbg & 16)) if constexpr (kg == kgs - 1) {
+    if (!(dbg & 2) && live) mma_stage(ph == 2 ? Hs : A1, ph == 2 ? F_LDH : F_LDA, kg * 256, nch, reg, c);
+    // refill this set, NSETS stages ahead.  Issuing a load can block (the queue is full while the weights stream), so where
+    // an epilogue follows that other waves wait for (LayerNorm2, the tile hand-overs) the refill goes behind it
+    constexpr bool epi_first = kg == kgs - 1;
+    if constexpr (!epi_first) { if (!(dbg & 1)) load_w(std::integral_constant<int, s + NSETS>{}, reg); }
+    if constexpr (kg == kgs - 1 && g == (ph == 0 ? GD : (ph == 1 ? GM : (ph == 2 ? GD : GN))) - 1) stamp(5 + 3 * ph);   // last MFMAs of the phase issued
+    if (!(dbg & 16)) if constexpr (kg == kgs - 1) {
       if constexpr (ph == 0) epi_proj(std::integral_constant<int, g>{}, c);
       else if constexpr (ph == 1) epi_fc1(g, c);
       else if constexpr (ph == 2) epi_fc2(std::integral_constant<int, g>{}, c);
       else epi_adj(g, c);
     }
+    if constexpr (epi_first) { if (!(dbg & 1)) load_w(std::integral_constant<int, s + NSETS>{}, reg); }
   });
+  stamp(15);
 }
 
 struct FusedCfg { int gd, kgd, gm, kgm, gn, kcd, kcm; };
@@ -359,10 +400,10 @@ inline FusedCfg fused_cfg(int d, int m, int no) {
   const int Kd = srad_cp(d), Km = srad_cp(m);
   return FusedCfg{(d + F_SC - 1) / F_SC, (Kd + 255) / 256, (m + F_SC - 1) / F_SC, (Km + 255) / 256, (no + F_SC - 1) / F_SC, Kd / 32, Km / 32};
 }
-template <int FM, int GD, int KGD, int GM, int KGM, int GN, int KCD, int KCM>
+template <int FM, int GD, int KGD, int GM, int KGM, int GN, int KCD, int KCM, bool STAMP = false>
 int launch_mlp_fm(const MlpBlockParams& p, hipStream_t stream) {
   constexpr size_t lds = (size_t)(FM * F_LDA + FM * F_LDH) * 2 + (F_NV + FM * 16) * sizeof(float);
-  auto kern = mlp_block_kernel<FM, GD, KGD, GM, KGM, GN, KCD, KCM>;
+  auto kern = mlp_block_kernel<FM, GD, KGD, GM, KGM, GN, KCD, KCM, STAMP>;
   static bool configured = false;
   if (!configured) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -380,6 +421,7 @@ int launch_mlp(const MlpBlockParams& p, hipStream_t stream) {
   // 16-row tiles until there are enough tokens to fill the chip several times with 64-row tiles
   if (p.fm == 64 && p.M % 64 == 0) return launch_mlp_fm<64, GD, KGD, GM, KGM, GN, KCD, KCM>(p, stream);
   if (p.fm == 32 && p.M % 32 == 0) return launch_mlp_fm<32, GD, KGD, GM, KGM, GN, KCD, KCM>(p, stream);
+  if (p.stamps && p.M % 16 == 0) return launch_mlp_fm<16, GD, KGD, GM, KGM, GN, KCD, KCM, true>(p, stream);   // diagnostic build
   if (p.fm == 16) return launch_mlp_fm<16, GD, KGD, GM, KGM, GN, KCD, KCM>(p, stream);
   if (p.M >= 32768 && p.M % 64 == 0) return launch_mlp_fm<64, GD, KGD, GM, KGM, GN, KCD, KCM>(p, stream);
   if (p.M >= 8192 && p.M % 32 == 0) return launch_mlp_fm<32, GD, KGD, GM, KGM, GN, KCD, KCM>(p, stream);
@@ -407,6 +449,8 @@ int srad_launch_mlp_block(const MlpBlockParams& p, hipStream_t stream) {
   SRAD_REQUIRE((p.ld_short & 3) == 0 && ((uintptr_t)p.shortcut & 15) == 0 && (p.ldy & 3) == 0 && (p.yoff & 3) == 0 &&
                    ((uintptr_t)p.Y & 15) == 0 && (!p.R || ((p.ldr & 3) == 0 && ((uintptr_t)p.R & 15) == 0)),
                "mlp_block: shortcut / output / residual rows must be float4-addressable");
+  SRAD_REQUIRE((((uintptr_t)p.b_proj | (uintptr_t)p.b_fc1 | (uintptr_t)p.b_fc2 | (uintptr_t)p.b_adj | (uintptr_t)p.ln_g | (uintptr_t)p.ln_b) & 15) == 0,
+               "mlp_block: bias / LayerNorm vectors must be 16-byte aligned");
   const FusedCfg c = fused_cfg(p.d, p.m, p.no);
 #define X(a, b, cc, dd, e, f, g) if (c.gd == a && c.kgd == b && c.gm == cc && c.kgm == dd && c.gn == e && c.kcd == f && c.kcm == g) return launch_mlp<a, b, cc, dd, e, f, g>(p, stream);
   SRAD_FUSED_CFGS(X)

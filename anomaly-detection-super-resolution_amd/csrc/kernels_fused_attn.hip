@@ -62,22 +62,31 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
   const int wy = widx / nWx, wx = widx - wy * nWx;
   const float scale = rsqrtf((float)hd);
 
-  if (tid < 64) {
-    const int py = tid >> 3, px = tid & 7;
-    const int r = wy * ws + py, c = wx * ws + px;               // coordinates in the shifted image
+  // token of window position t (cyclic shift + window partition as index arithmetic, drct.py:482-504)
+  auto token_of = [&](int t, int& info) {
+    const int py = t >> 3, px = t & 7;
+    const int r = wy * ws + py, c = wx * ws + px;                 // coordinates in the shifted image
     int orr = r + p.shift; if (orr >= p.H) orr -= p.H;
     int occ = c + p.shift; if (occ >= p.W) occ -= p.W;
-    tok[tid] = (b * p.H + orr) * p.W + occ;
     const int rh = r < p.H - ws ? 0 : (r < p.H - p.shift ? 1 : 2);
     const int rw = c < p.W - ws ? 0 : (c < p.W - p.shift ? 1 : 2);
-    inf[tid] = ((rh * 3 + rw) << 16) | (py << 8) | px;
+    info = ((rh * 3 + rw) << 16) | (py << 8) | px;
+    return (b * p.H + orr) * p.W + occ;
+  };
+  const int xrow = tid >> 3, col4 = tid & 7;
+  int my_info;
+  const int my_tok = token_of(xrow, my_info);                     // every thread knows its own row: no barrier before the loads
+  if (tid < 64) {
+    int info;
+    tok[tid] = token_of(tid, info);
+    inf[tid] = info;
   }
-  __syncthreads();
 
   // ---- weights: the head's 3 * HDP virtual rows [q_h | k_h | v_h] as fragments (srad_launch_pack_qkv_frag).  A wave owns 16
   //      virtual columns of a 128-column stage for all 64 tokens and NOBODY else reads their weights, so they go straight
-  //      from global memory into MFMA operand registers, three stages ahead, issued before the window is even gathered:
-  //      no LDS weight stage, no barrier per stage (as in mlp_block_kernel). ----
+  //      from global memory into MFMA operand registers, three stages ahead: no LDS weight stage, no barrier per stage (as in
+  //      mlp_block_kernel).  The loads are unconditional - a load inside a branch makes hipcc's wait-count pass drain every
+  //      older load at the join; a wave without columns in a stage reads one 16-byte word per load instead. ----
   constexpr int NSETS = 3;
   u32x4 w_reg[NSETS][8];
   const char* const Wh = reinterpret_cast<const char*>(p.w_qkv) + (size_t)h * (NV / 16) * KC * 1024;
@@ -85,45 +94,40 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
     constexpr int sc = decltype(S)::value < n_stages - 1 ? decltype(S)::value : n_stages - 1;
     constexpr int st = sc / KG, kg = sc - st * KG;
     constexpr int nch = KC - kg * 8 < 8 ? KC - kg * 8 : 8;
-    const char* base = Wh + ((size_t)(st * 8 + wave) * KC + kg * 8) * 1024 + fr * 64 + fq * 16;
-    if ((st * 8 + wave_s) * 16 < NV) {
+    const bool live = (st * 8 + wave_s) * 16 < NV;
+    const char* base = live ? Wh + ((size_t)(st * 8 + wave) * KC + kg * 8) * 1024 + fr * 64 + fq * 16 : Wh;
+    const int step = live ? 1024 : 0;
 #pragma unroll
-      for (int cc = 0; cc < nch; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + cc * 1024);
-    }
+    for (int cc = 0; cc < nch; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + cc * step);
   };
 
-  // ---- issue the loads: window rows of x (gathered), first weight stages, vectors ----
+  // ---- issue the loads in the order their data is needed (vmcnt retires in issue order): the window's rows of x
+  //      (gathered), the staged vectors, the first weight stage; the rest of the weight look-ahead follows the LayerNorm ----
   f32x4 a_reg[KC];
-  const int xrow = tid >> 3, col4 = tid & 7;
   {
-    const char* src = reinterpret_cast<const char*>(p.x) + (size_t)tok[xrow] * p.ldx * 4;
+    const char* src = reinterpret_cast<const char*>(p.x) + (size_t)my_tok * p.ldx * 4;
 #pragma unroll
     for (int j = 0; j < KC; ++j) a_reg[j] = *reinterpret_cast<const f32x4*>(src + (unsigned)min(j * 32 + col4 * 4, d - 4) * 4u);
   }
-  static_for<0, NSETS>([&](auto Q) { load_w(Q, w_reg[decltype(Q)::value]); });
+  // gamma | beta (320 each) | bias (3 * HDP) | table (225) are contiguous in LDS.  One role per wave, wave-uniform base /
+  // stride / count (scalar selects), five clamped 4-byte loads per lane: no per-lane branch, no pointer table in memory.
+  typedef const float __attribute__((address_space(1)))* gfloat_p;
+  float vq[5];
+  int v_dst, v_cnt, v_n;
   {
-    // gamma | beta (320 each), bias (3*HDP), table (225): <= 640 + 384 + 225 = 1249 values, 3 per thread
-    float vq[3];
+    gfloat_p src; int stride = 1;
+    if (wave_s == 0) { src = (gfloat_p)p.ln_g; v_n = d; v_cnt = 320; v_dst = 0; }
+    else if (wave_s == 1) { src = (gfloat_p)p.ln_b; v_n = d; v_cnt = 320; v_dst = 320; }
+    else if (wave_s < 5) { src = (gfloat_p)p.b_qkv + (wave_s - 2) * d + h * hd; v_n = hd; v_cnt = HDP; v_dst = 640 + (wave_s - 2) * HDP; }
+    else { src = (gfloat_p)p.table + (size_t)(wave_s - 5) * 75 * heads + h; stride = heads; v_n = 75; v_cnt = 75; v_dst = 640 + 3 * HDP + (wave_s - 5) * 75; }
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const int i = tid + 512 * q;
-      float v;
-      if (i < 320) v = p.ln_g[min(i, d - 1)];
-      else if (i < 640) v = p.ln_b[min(i - 320, d - 1)];
-      else if (i < 640 + 3 * HDP) {
-        const int o = i - 640, which = o / HDP, c = o - which * HDP;
-        v = p.b_qkv[which * d + h * hd + min(c, hd - 1)];
-        v = c < hd ? v : 0.f;
-      } else {
-        v = p.table[(size_t)min(i - 640 - 3 * HDP, 224) * heads + h];
-      }
-      vq[q] = v;
-    }
+    for (int q = 0; q < 5; ++q) vq[q] = src[(size_t)min(lane + 64 * q, v_n - 1) * stride];
+  }
+  load_w(std::integral_constant<int, 0>{}, w_reg[0]);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const int i = tid + 512 * q;
-      if (i < 640 + 3 * HDP + 225) v_g[i] = vq[q];                // gamma | beta | bias | table are contiguous
-    }
+  for (int q = 0; q < 5; ++q) {
+    const int e = lane + 64 * q;
+    if (e < v_cnt) v_g[v_dst + e] = e < v_n ? vq[q] : 0.f;        // bias entries of the padded head columns are 0
   }
   if constexpr (HDP32 != HDP) {
     // head dims padded to 48 / 80: the last 32-wide k step of q.k^T also covers 16 columns no epilogue writes
@@ -151,12 +155,13 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
       const f32x4 g4 = *reinterpret_cast<const f32x4*>(v_g + c);
       const f32x4 b4 = *reinterpret_cast<const f32x4*>(v_b + c);
       const f32x4 v = c < d ? (a_reg[j] - mu) * rstd * g4 + b4 : f32x4{0.f, 0.f, 0.f, 0.f};
-      if (p.save_xn && h == 0 && c < d) *reinterpret_cast<f32x4*>(p.save_xn + (size_t)tok[xrow] * d + c) = v;
+      if (p.save_xn && h == 0 && c < d) *reinterpret_cast<f32x4*>(p.save_xn + (size_t)my_tok * d + c) = v;
       bf16x4 hh;
       hh[0] = (__bf16)v[0]; hh[1] = (__bf16)v[1]; hh[2] = (__bf16)v[2]; hh[3] = (__bf16)v[3];
       *reinterpret_cast<bf16x4*>(XN + xrow * QA_LDX + c) = hh;
     }
   }
+  static_for<1, NSETS>([&](auto Q) { load_w(Q, w_reg[decltype(Q)::value]); });   // the rest of the weight look-ahead
   __syncthreads();                                                // the normalised window is in LDS
 
   // ---- q|k|v = xn . W^T : 128 virtual columns per stage, transposed result (lane: token fr of row tile t, 4 columns) ----

@@ -118,7 +118,12 @@ int srad_bench_mlp_block(int M, int d, int m, int no, const float* attn, const f
   q.attn = attn; q.ld_attn = 320; q.shortcut = shortcut; q.ld_short = 320; q.M = M; q.d = d; q.m = m; q.no = no;
   q.w_proj = sc; q.w_fc1 = sc + b1; q.w_fc2 = sc + b1 + b2; q.w_adj = sc + b1 + b2 + b3;
   q.b_proj = q.b_fc1 = q.b_fc2 = q.b_adj = q.ln_g = q.ln_b = w_fp32;
-  q.act = SRAD_ACT_LRELU; q.slope = 0.2f; q.alpha = 1.f; q.R = nullptr; q.ldr = 0; q.Y = y; q.ldy = 320; q.yoff = 0; q.dbg = dbg;
+  q.act = SRAD_ACT_LRELU; q.slope = 0.2f; q.alpha = 1.f; q.R = nullptr; q.ldr = 0; q.Y = y; q.ldy = 320; q.yoff = 0; q.dbg = dbg & 0xff;
+  q.fm = (dbg >> 8) & 0xff;                         // bits 8..15: rows per workgroup (0 = auto)
+  if (dbg & 0x100ff) {                              // bit 16 or any switch-off bit: the diagnostic build; its stamps go behind the packed weights
+    SRAD_REQUIRE(scratch_bytes >= b1 + b2 + b3 + b4 + (size_t)(M / 16) * 8 * 16 * 8, "bench_mlp_block: scratch too small for the stamps");
+    q.stamps = reinterpret_cast<unsigned long long*>(sc + b1 + b2 + b3 + b4);
+  }
   for (int i = 0; i < 3; ++i) SRAD_TRY(srad_launch_mlp_block(q, s));
   hipEvent_t a, b;
   SRAD_CHECK_HIP(hipEventCreate(&a));

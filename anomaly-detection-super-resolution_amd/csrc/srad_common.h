@@ -181,6 +181,7 @@ struct MlpBlockParams {
   float* Y; int ldy, yoff;
   int dbg;                               // timing experiments only (tools/): 1 skip W loads, 2 skip MFMA, 4 skip GELU
   int fm;                                // token rows per workgroup: 0 = chosen from M, else 16 / 32 / 64
+  unsigned long long* stamps;            // diagnostic build (16-row tiles): [workgroup][8 waves][16] s_memtime stamps, else null
   // ---- training (all optional): DropPath factors of the two residual branches and the tensors the backward needs ----
   const float *rs1, *rs2; int rps;       // per-sample factors (row m belongs to sample m / rps), null = 1
   float *save_x1, *save_xn2, *save_hpre, *save_hact, *save_x2;   // [M][d] x + attn branch, [M][d] LayerNorm2, [M][m] fc1 pre-activation, [M][m] GELU, [M][d] block output

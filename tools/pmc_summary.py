@@ -1,62 +1,132 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 PMC passes (one per counter, as MI355X_MICROARCH.md prescribes) into a small
-JSON that bench.py reports as roofline.traffic.
+"""Summarise rocprofv3 PMC passes of the C2 forward into profiles/rNN_pmc_counters.json, which bench.py quotes as
+roofline.traffic / roofline.mfma_busy while its `kernel_source_sha` matches the kernels being benched.
 
-    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -- python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-graph
-    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_write -- python3 bench.py ...
-    python tools/pmc_summary.py gpurun_out/prof_fetch gpurun_out/prof_write profiles/r01_pmc_traffic.json
+Passes (tools/pmc_passes.sh runs them; each its own process, counters only with --kernel-trace, as the pool requires):
+  traffic : FETCH_SIZE | WRITE_SIZE            (TCC: cannot share a pass, MI355X_MICROARCH.md "rocprofv3 PMC slots")
+  sq      : SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES
+            SQ_INSTS_VALU_MFMA_MOPS_BF16 (or the names `rocprofv3 -L` lists), SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+            SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU, GRBM_GUI_ACTIVE
+Every <dir> given on the command line is scanned for *counter_collection.csv (Counter_Name / Counter_Value per dispatch)
+and *kernel_trace.csv (durations); counters are averaged per launch and per kernel class (and per template instance).
 
-gfx950 corrections: FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE counts 128-B requests as 64 B for
-wide coalesced reads, so it is doubled (MI355X_MICROARCH.md "HBM").
+    python tools/pmc_summary.py profiles/r02_pmc_counters.json gpurun_out/pmc_*/
+
+gfx950 corrections (MI355X_MICROARCH.md): FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE tallies the 128-B requests of wide
+(16 B / lane) coalesced reads at 64 B, so it is doubled - every global load of qkv_attn / mlp_block is a 16-byte-per-lane
+load of whole 64-byte row pieces or 1 KB weight fragments, the pattern the guide's factor was measured on; narrower accesses
+are uncalibrated.  SQ_*_CYCLES count quad-cycles (x4 = shader cycles) except SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over
+the SIMDs that were busy); SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE are summed over the 8 XCDs (per shader engine for SQ).
+
+Derived per kernel class:
+  mfma_busy            = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8
+                         (share of all matrix pipes' time spent in MFMA while the kernel runs: the north_star's "MFMA-busy")
+  wait_frac            = SQ_WAIT_ANY / SQ_WAVE_CYCLES          (waves parked at s_waitcnt / s_barrier)
+  issue_stall_frac     = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES
+  active_frac          = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES
+  lds_bank_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
 """
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "anomaly-detection-super-resolution_amd", "csrc")
+
+
+def kernel_source_sha() -> str:
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(CSRC, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def classify(name: str) -> str:
     if "gemm_kernel" in name:
         args = name.split("gemm_kernel<")[1].split(">")[0].replace(" ", "").split(",")
-        return {"64": "gemm_bn64", "32": "gemm_bn32", "16": "gemm_bn16"}[args[2]]
-    if "mlp_block_kernel" in name:
-        return "mlp_block"
-    if "qkv_attn_kernel" in name:
-        return "qkv_attn"
-    if "window_attn_kernel" in name:
-        return "window_attn"
-    if "layernorm_kernel" in name:
-        return "layernorm"
-    for key, cls in (("wgrad_multi_kernel", "wgrad"), ("wgrad_kernel", "wgrad"), ("wgrad_reduce_kernel", "wgrad_reduce"),
-                     ("ln_bwd_kernel", "layernorm_bwd"), ("window_attn_bwd", "window_attn_bwd")):
+        return {"64": "gemm_bn64", "32": "gemm_bn32", "16": "gemm_bn16"}.get(args[2], "gemm")
+    for key, cls in (("mlp_block_kernel", "mlp_block"), ("qkv_attn_kernel", "qkv_attn"), ("swin_block_kernel", "swin_block"),
+                     ("window_attn_bwd", "window_attn_bwd"), ("window_attn_kernel", "window_attn"), ("layernorm_kernel", "layernorm"),
+                     ("wgrad_multi_kernel", "wgrad"), ("wgrad_kernel", "wgrad"), ("wgrad_reduce_kernel", "wgrad_reduce"),
+                     ("ln_bwd_kernel", "layernorm_bwd"), ("mlp_bwd_kernel", "mlp_bwd"), ("lin_ln_bwd_kernel", "lin_ln_bwd"),
+                     ("sat_", "scorer"), ("ssim_eval", "scorer")):
         if key in name:
             return cls
     return "other"
 
 
-def load(folder):
-    out = collections.defaultdict(lambda: [0, 0.0])
-    for f in glob.glob(folder + "/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            k = classify(r["Kernel_Name"])
-            out[k][0] += 1
-            out[k][1] += float(r["Counter_Value"])
-    return out
+def instance(name: str) -> str:
+    n = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+    return n.split("(")[0][:80]
 
 
 def main():
-    fetch, write, dst = load(sys.argv[1]), load(sys.argv[2]), sys.argv[3]
-    res = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --no-graph C2 workload",
-           "corrections": "KiB -> bytes; FETCH_SIZE x2 on gfx950 (128-B requests tallied at 64 B)", "kernels": {}}
-    for k in fetch:
-        n = fetch[k][0]
-        f = fetch[k][1] / n * 1024 * 2
-        w = write[k][1] / max(1, write[k][0]) * 1024 if k in write else 0.0
-        res["kernels"][k] = {"launches": n, "fetch_bytes_per_launch": round(f), "write_bytes_per_launch": round(w),
-                             "hbm_bytes_per_launch": round(f + w)}
+    dst, dirs = sys.argv[1], sys.argv[2:]
+    cls_sum = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))     # class -> counter -> [n, sum]
+    inst_sum = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    dur = collections.defaultdict(lambda: [0, 0.0])
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                for table, key in ((cls_sum, classify(r["Kernel_Name"])), (inst_sum, instance(r["Kernel_Name"]))):
+                    e = table[key][r["Counter_Name"]]
+                    e[0] += 1
+                    e[1] += float(r["Counter_Value"])
+        for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                e = dur[classify(r["Kernel_Name"])]
+                e[0] += 1
+                e[1] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+
+    def summarise(ctrs):
+        avg = {k: v[1] / v[0] for k, v in ctrs.items() if v[0]}
+        out = {"launches": max(v[0] for v in ctrs.values())}
+        out["counters_per_launch"] = {k: round(v, 1) for k, v in sorted(avg.items())}
+        if "FETCH_SIZE" in avg:
+            out["fetch_bytes_per_launch"] = round(avg["FETCH_SIZE"] * 1024 * 2)
+        if "WRITE_SIZE" in avg:
+            out["write_bytes_per_launch"] = round(avg["WRITE_SIZE"] * 1024)
+        if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
+            out["hbm_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
+        wave = avg.get("SQ_WAVE_CYCLES")
+        if wave:
+            for name, key in (("wait_frac", "SQ_WAIT_ANY"), ("issue_stall_frac", "SQ_WAIT_INST_ANY"), ("active_frac", "SQ_ACTIVE_INST_ANY"),
+                              ("valu_active_frac", "SQ_ACTIVE_INST_VALU"), ("lds_active_frac", "SQ_ACTIVE_INST_LDS")):
+                if key in avg:
+                    out[name] = round(avg[key] / wave, 4)
+        if avg.get("SQ_LDS_IDX_ACTIVE"):
+            out["lds_bank_conflict_frac"] = round(avg.get("SQ_LDS_BANK_CONFLICT", 0.0) / avg["SQ_LDS_IDX_ACTIVE"], 4)
+        if "GRBM_GUI_ACTIVE" in avg and avg["GRBM_GUI_ACTIVE"] > 0:
+            kcycles = avg["GRBM_GUI_ACTIVE"] / 8.0
+            out["kernel_cycles"] = round(kcycles)
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in avg:
+                out["mfma_busy"] = round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * 256 * kcycles), 4)
+                out["mfma_busy_note"] = "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): share of the chip's matrix-pipe time"
+            if "SQ_BUSY_CYCLES" in avg:
+                out["sq_busy_frac"] = round(avg["SQ_BUSY_CYCLES"] / (avg["GRBM_GUI_ACTIVE"] * 4), 4)      # 32 shader engines / 8 XCDs
+        return out
+
+    res = {"source": "rocprofv3 --pmc passes (one counter group per process) of `bench.py --no-graph --no-train --no-eval "
+                     "--no-cpu-baseline`: the C2 forward, eager launches",
+           "corrections": "FETCH_SIZE/WRITE_SIZE KiB -> bytes; FETCH_SIZE x2 (16 B/lane coalesced loads: 128-B requests tallied at 64 B)",
+           "kernel_source_sha": kernel_source_sha(), "kernels": {}, "instances": {}}
+    for k, ctrs in cls_sum.items():
+        res["kernels"][k] = summarise(ctrs)
+        if dur[k][0]:
+            res["kernels"][k]["dispatch_us"] = round(dur[k][1] / dur[k][0] / 1e3, 3)
+    for k, ctrs in inst_sum.items():
+        if any(s in k for s in ("qkv_attn", "mlp_block", "swin_block", "window_attn")):
+            res["instances"][k] = summarise(ctrs)
+    os.makedirs(os.path.dirname(os.path.abspath(dst)), exist_ok=True)
     json.dump(res, open(dst, "w"), indent=1)
-    print(json.dumps(res["kernels"], indent=1))
+    keep = {k: {kk: vv for kk, vv in v.items() if kk != "counters_per_launch"} for k, v in res["kernels"].items()}
+    print(json.dumps(keep, indent=1))
 
 
 if __name__ == "__main__":
