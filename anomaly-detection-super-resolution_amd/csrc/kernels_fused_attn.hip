@@ -25,9 +25,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 constexpr int QA_LDP = 72;     // probability tile row stride
+constexpr int QA_LDB = 68;     // bias table row stride (floats): the 16 keys a float4 read group touches fall on 16 different bank quads
 
 // HDT = ceil(head_dim / 16) (2, 3, 4, 5 or 8), KC = ceil(d / 32) 32-wide k chunks (<= 10)
-template <int HDT, int KC>
+template <int HDT, int KC, bool STAMP = false>
 __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
   constexpr int KG = (KC + 7) / 8;         // 256-wide k groups per weight stage
   constexpr int QA_LDX = KC * 32 + 8;      // LDS row stride of the normalised window tile
@@ -45,8 +46,10 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
   float* v_b = v_g + 320;                                       // [320] beta
   float* v_bias = v_b + 320;                                    // [3][HDP] q|k|v bias of this head (0 in padding)
   float* tbl = v_bias + 3 * HDP;                                // [225] relative position bias of this head
-  float* lsum = tbl + 232;                                      // [64] softmax denominators
-  int* tok = reinterpret_cast<int*>(lsum + 64);                 // [64] token index
+  float* lsum = tbl + 232;                                      // [2][64] softmax denominators of the two key halves
+  float* mxs = lsum + 128;                                      // [2][64] row maxima of the two key halves
+  float* BM = mxs + 128;                                        // [64 keys][QA_LDB] bias + shift mask, query-contiguous
+  int* tok = reinterpret_cast<int*>(BM + 64 * QA_LDB);          // [64] token index
   int* inf = tok + 64;                                          // [64] (region << 16) | (py << 8) | px
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -54,6 +57,17 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
   const int rt = wave & 3, chh = wave >> 2;                     // P.V: row tile, column-tile parity
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const int d = p.d, heads = p.heads, hd = d / heads;
+  // diagnostic build only (tools/stamp_bench.py): shader-clock stamps of every wave at the phase boundaries
+  auto stamp = [&](int idx) {
+    if constexpr (STAMP) {
+      unsigned long long t;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (lane == 0) p.stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 16 + idx] = t;
+    }
+  };
+  stamp(0);
   // grid = (windows, heads): linear ids of one window's heads differ by a multiple of 8 when the window
   // count is, so they share an XCD and the window's x rows are fetched into one L2 only
   const int h = blockIdx.y, win = blockIdx.x;
@@ -124,6 +138,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
     for (int q = 0; q < 5; ++q) vq[q] = src[(size_t)min(lane + 64 * q, v_n - 1) * stride];
   }
   load_w(std::integral_constant<int, 0>{}, w_reg[0]);
+  stamp(1);                                                       // prologue loads issued
 #pragma unroll
   for (int q = 0; q < 5; ++q) {
     const int e = lane + 64 * q;
@@ -135,6 +150,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
     *reinterpret_cast<bf16x4*>(QKV + row * HS + HDP + 4 * part) = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
   }
 
+  stamp(2);                                                       // vectors staged
   // ---- LayerNorm1 from the registers (the 8 lanes of a row hold all its columns) -> bf16 -> XN ----
   {
     float s = 0.f, ss = 0.f;
@@ -148,7 +164,25 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
     { s = srad_row8_sum(s); ss = srad_row8_sum(ss); }
     const float mu = s / (float)d;
     const float rstd = rsqrtf(fmaxf(ss / (float)d - mu * mu, 0.f) + 1e-5f);
-    __syncthreads();                                              // gamma / beta staged
+    stamp(3);                                                     // x rows arrived, statistics done
+    __syncthreads();                                              // gamma / beta / table / window geometry staged
+    stamp(4);
+    {
+      // relative position bias + 0 / -100 shift mask (drct.py:284-292, 449-470) of this head for every (key, query) pair,
+      // once per workgroup: the softmax then adds one float4 per 4 scores instead of unpacking coordinates per score
+      const int k = tid >> 3, q0 = (tid & 7) * 8;
+      const int ki = inf[k], ky = (ki >> 8) & 0xff, kx = ki & 0xff, kr = ki >> 16;
+      float bm[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int qi = inf[q0 + i], qy = (qi >> 8) & 0xff, qx = qi & 0xff, qr = qi >> 16;
+        float v = tbl[(qy - ky + 7) * 15 + (qx - kx + 7)];
+        if (p.shift > 0 && qr != kr) v += -100.0f;
+        bm[i] = v;
+      }
+      *reinterpret_cast<f32x4*>(BM + k * QA_LDB + q0) = f32x4{bm[0], bm[1], bm[2], bm[3]};
+      *reinterpret_cast<f32x4*>(BM + k * QA_LDB + q0 + 4) = f32x4{bm[4], bm[5], bm[6], bm[7]};
+    }
 #pragma unroll
     for (int j = 0; j < KC; ++j) {
       const int c = j * 32 + col4 * 4;
@@ -161,8 +195,11 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
       *reinterpret_cast<bf16x4*>(XN + xrow * QA_LDX + c) = hh;
     }
   }
+  stamp(5);                                                       // normalised rows written
   static_for<1, NSETS>([&](auto Q) { load_w(Q, w_reg[decltype(Q)::value]); });   // the rest of the weight look-ahead
+  stamp(6);
   __syncthreads();                                                // the normalised window is in LDS
+  stamp(7);
 
   // ---- q|k|v = xn . W^T : 128 virtual columns per stage, transposed result (lane: token fr of row tile t, 4 columns) ----
   f32x4 acc[4];
@@ -208,54 +245,54 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
       }
     }
   });
+  stamp(8);                                                       // this wave's q | k | v columns done
   __syncthreads();                                                // q, k, v complete
+  stamp(9);
 
   const __bf16* Qs = QKV;
   const __bf16* Ks = QKV + 64 * HS;
   const __bf16* Vs = QKV + 2 * 64 * HS;
 
-  // ---- S = q k^T, bias, mask, softmax: waves 0..3, 16 query rows x 64 keys each ----
-  if (wave < 4) {
-    f32x4 sc[4];
+  // ---- S = q k^T, bias, mask, softmax on all 8 waves: wave = (query row tile rt, key half kh), 16 queries x 32 keys each;
+  //      the two halves of a row exchange their maxima through LDS, so the probabilities are exp(s - row max) as before ----
+  {
+    const int kh = chh;
+    f32x4 sc[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 2; ++j) sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < HDP32; kk += 32) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Qs + (wave * 16 + fr) * HS + kk + 8 * fq);
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Qs + (rt * 16 + fr) * HS + kk + 8 * fq);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bf16x8 bb = *reinterpret_cast<const bf16x8*>(Ks + (j * 16 + fr) * HS + kk + 8 * fq);
+      for (int j = 0; j < 2; ++j) {
+        const bf16x8 bb = *reinterpret_cast<const bf16x8*>(Ks + ((2 * kh + j) * 16 + fr) * HS + kk + 8 * fq);
         sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, sc[j], 0, 0, 0);
       }
     }
-    int qinf[4], kinf[4];
+    // lane: queries rt*16 + 4 fq + e (e = 0..3), keys (2 kh + j) * 16 + fr
+    float mx[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) qinf[e] = inf[wave * 16 + fq * 4 + e];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) kinf[j] = inf[j * 16 + fr];
+    for (int j = 0; j < 2; ++j) sc[j] += *reinterpret_cast<const f32x4*>(BM + ((2 * kh + j) * 16 + fr) * QA_LDB + rt * 16 + 4 * fq);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int qy = (qinf[e] >> 8) & 0xff, qx = qinf[e] & 0xff, qr = qinf[e] >> 16;
-      float mx = -1e30f;
+      mx[e] = srad_row16_max(fmaxf(sc[0][e], sc[1][e]));
+      if (fr == 0) mxs[kh * 64 + rt * 16 + fq * 4 + e] = mx[e];
+    }
+    __syncthreads();
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int ky = (kinf[j] >> 8) & 0xff, kx = kinf[j] & 0xff, kr = kinf[j] >> 16;
-        float v = sc[j][e] + tbl[(qy - ky + 7) * 15 + (qx - kx + 7)];
-        if (p.shift > 0 && qr != kr) v += -100.0f;
-        sc[j][e] = v;
-        mx = fmaxf(mx, v);
-      }
-      mx = srad_row16_max(mx);
-      float rs = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { const float pv = __expf(sc[j][e] - mx); sc[j][e] = pv; rs += pv; }
-      rs = srad_row16_sum(rs);
-      if (fr == 0) lsum[wave * 16 + fq * 4 + e] = rs;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) Ps[(wave * 16 + fq * 4 + e) * QA_LDP + j * 16 + fr] = (__bf16)sc[j][e];
+    for (int e = 0; e < 4; ++e) {
+      const int row = rt * 16 + fq * 4 + e;
+      const float m = fmaxf(mx[e], mxs[(kh ^ 1) * 64 + row]);
+      const float p0 = __expf(sc[0][e] - m), p1 = __expf(sc[1][e] - m);
+      const float rs = srad_row16_sum(p0 + p1);
+      if (fr == 0) lsum[kh * 64 + row] = rs;
+      Ps[row * QA_LDP + (2 * kh) * 16 + fr] = (__bf16)p0;
+      Ps[row * QA_LDP + (2 * kh + 1) * 16 + fr] = (__bf16)p1;
     }
   }
+  stamp(10);                                                      // scores + softmax
   __syncthreads();
+  stamp(11);
 
   // ---- O = P V (transposed result: lane owns token fr of row tile rt, 4 consecutive output columns) ----
   {
@@ -277,7 +314,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
         o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb, pa, o, 0, 0, 0);
       }
       const int row = rt * 16 + fr;
-      const float inv = 1.0f / lsum[row];
+      const float inv = 1.0f / (lsum[row] + lsum[64 + row]);
       float* dst = p.out + (size_t)tok[row] * p.ld_out + h * hd;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -286,14 +323,15 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
       }
     }
   }
+  stamp(15);
 }
 
-template <int HDT, int KC>
+template <int HDT, int KC, bool STAMP = false>
 int launch_qa(const QkvAttnParams& p, hipStream_t stream) {
   constexpr int HDP = 16 * HDT, HS = ((HDP + 31) & ~31) + 8;
   constexpr size_t lds = (size_t)(64 * (KC * 32 + 8) + 3 * 64 * HS + 64 * QA_LDP) * 2 +
-                         (size_t)(640 + 3 * HDP + 232 + 64) * sizeof(float) + 128 * sizeof(int);
-  auto kern = qkv_attn_kernel<HDT, KC>;
+                         (size_t)(640 + 3 * HDP + 232 + 256 + 64 * QA_LDB) * sizeof(float) + 128 * sizeof(int);
+  auto kern = qkv_attn_kernel<HDT, KC, STAMP>;
   static bool configured = false;
   if (!configured) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -327,6 +365,11 @@ int srad_launch_qkv_attn(const QkvAttnParams& p, hipStream_t stream) {
   SRAD_REQUIRE((p.ldx & 3) == 0 && ((uintptr_t)p.x & 15) == 0, "qkv_attn: x rows must be float4-addressable");
   SRAD_REQUIRE(p.shift >= 0 && p.shift < 8, "qkv_attn: shift %d must be in [0, 8)", p.shift);
   const int hdt = (p.d / p.heads + 15) / 16, kc = (p.d + 31) / 32;
+  if (p.stamps) {                                                 // diagnostic build
+#define X(a, b) if (hdt == a && kc == b) return launch_qa<a, b, true>(p, stream);
+    SRAD_QA_CFGS(X)
+#undef X
+  }
 #define X(a, b) if (hdt == a && kc == b) return launch_qa<a, b>(p, stream);
   SRAD_QA_CFGS(X)
 #undef X

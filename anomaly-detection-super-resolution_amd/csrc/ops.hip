@@ -183,7 +183,12 @@ int srad_bench_qkv_attn(const float* x, int ldx, int B, int H, int W, int shift,
   SRAD_TRY(srad_launch_pack_qkv_frag(w_fp32, scratch, d, heads, s));
   QkvAttnParams a{};
   a.x = x; a.ldx = ldx; a.ln_g = w_fp32; a.ln_b = w_fp32; a.w_qkv = scratch; a.b_qkv = w_fp32; a.table = w_fp32;
-  a.out = out; a.ld_out = d; a.B = B; a.H = H; a.W = W; a.shift = shift; a.d = d; a.heads = heads;
+  a.out = out; a.ld_out = d; a.B = B; a.H = H; a.W = W; a.shift = shift & 0xff; a.d = d; a.heads = heads;
+  if (shift & 0x10000) {                            // bit 16 of `shift`: the stamp build; stamps go behind the weight pack in scratch
+    const size_t wb = srad_align_up(srad_qkv_frag_bytes(d, heads), 256);
+    SRAD_REQUIRE(scratch_bytes >= wb + (size_t)B * (H / 8) * (W / 8) * heads * 8 * 16 * 8, "bench_qkv_attn: scratch too small for the stamps");
+    a.stamps = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(scratch) + wb);
+  }
   for (int i = 0; i < 3; ++i) SRAD_TRY(srad_launch_qkv_attn(a, s));
   hipEvent_t e0, e1;
   SRAD_CHECK_HIP(hipEventCreate(&e0));

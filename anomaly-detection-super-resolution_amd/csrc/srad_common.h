@@ -203,6 +203,7 @@ struct QkvAttnParams {
   // ---- training (optional): what the backward needs ----
   float* save_xn;                          // [T][d] LayerNorm1(x) (written by the head-0 workgroups)
   float* save_qkv; int hdp;                // [T][3][heads][hdp] head-padded q | k | v (q unscaled), as the QKV GEMM writes it
+  unsigned long long* stamps;              // diagnostic build: [workgroup][8 waves][16] s_memtime stamps, else null
 };
 bool srad_qkv_attn_supported(int prec, int ws, int H, int W, int d, int heads);
 int srad_launch_qkv_attn(const QkvAttnParams& p, hipStream_t stream);
