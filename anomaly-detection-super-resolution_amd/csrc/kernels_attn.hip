@@ -18,6 +18,7 @@
 // epilogue writes this layout directly (GemmParams::hsplit_*); pad columns are never read as data and need no
 // initialisation.
 #include "srad_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -41,7 +42,13 @@ __device__ __forceinline__ void store4(typename AT<PREC>::type* dst, f32x4 v) {
 // NW = waves per workgroup = 16-query slabs per workgroup: 4 for windows of up to 64 tokens, 8 above (the K / V
 // chunk and the bias table in LDS are then shared by 128 queries and two waves per SIMD hide each other's latency).
 // FULL: the window's token count is a multiple of 64, no key of a chunk needs masking out.
-template <int PREC, int NT_O, bool TBL_LDS, int NW, bool FULL>
+// ROW64 (bf16, 64 x 64 windows = BASELINE config C5, 4096-token windows): a 64-key chunk is exactly one ROW of the window,
+// so the key's y and its shift-mask row region are chunk constants and its column region depends only on the 16-key
+// tile: the relative-position bias of a lane's 16 keys is 16 loads at constant offsets from one per-chunk address and
+// the 0 / -100 mask is one per-tile addend - no per-score index arithmetic.  Scores live in the log2 domain (q pre-scaled
+// by log2 e, table staged x log2 e), so the probabilities are bare v_exp_f32.  The softmax was the bound of this kernel
+// (~14 VALU instructions per score against 0.5 - 2 MFMA issue slots); this path needs ~6.
+template <int PREC, int NT_O, bool TBL_LDS, int NW, bool FULL, bool ROW64 = false>
 __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p) {
   using T = typename AT<PREC>::type;
   constexpr int PAD = AT<PREC>::PAD;
@@ -73,7 +80,8 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
   const int b = win / nW, widx = win - b * nW;
   const int wy = widx / nWx, wx = widx - wy * nWx;
   const int q0 = blockIdx.x * BQ;
-  const float scale = rsqrtf((float)hd);
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float scale = rsqrtf((float)hd) * (ROW64 ? LOG2E : 1.0f);
   const int tw = 2 * ws - 1;
 
   auto fexp = [](float x) -> float {     // bf16 mode: v_exp_f32 (2 ulp); fp32 (parity) mode: libm expf
@@ -99,7 +107,7 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
     else { tokk[tid - BQ] = tok; infk[tid - BQ] = inf; }
   }
   if constexpr (TBL_LDS)
-    for (int i = tid; i < tw * tw; i += NT) tbl[i] = p.table[(size_t)i * heads + h];
+    for (int i = tid; i < tw * tw; i += NT) tbl[i] = p.table[(size_t)i * heads + h] * (ROW64 ? LOG2E : 1.0f);
   __syncthreads();
 
   // All global loads are unconditional on clamped addresses and masked by selects afterwards:
@@ -146,6 +154,11 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
   const int qinf = infq[wave * 16 + fr];
   // bias index (qy - ky + ws - 1) * tw + (qx - kx + ws - 1) = lin_q - lin_k + (ws - 1) * (tw + 1)
   const int aq = (qinf & 0xffffff) + (ws - 1) * (tw + 1), qr = qinf >> 24;
+  // ROW64: the query's window coordinates and shift-mask regions (rh = row region, rw = column region; qr = 3 rh + rw)
+  const int r64_lin = qinf & 0xffffff, r64_qy = r64_lin / tw, r64_qx = r64_lin - r64_qy * tw;
+  const int r64_rhq = qr / 3, r64_rwq = qr - 3 * r64_rhq;
+  auto r64_rw = [&](int c) { return c < p.W - 64 ? 0 : (c < p.W - p.shift ? 1 : 2); };
+  const bool r64_cdiff[2] = {r64_rwq != r64_rw(wx * 64), r64_rwq != r64_rw(wx * 64 + 32)};    // key columns 0..31 / 32..63
 
   // Key chunks are software-pipelined: while chunk kc is being multiplied, the K / V rows of chunk kc + 1 are in
   // flight in registers and the token list of chunk kc + 2 is being written (three-slot ring in LDS).
@@ -197,6 +210,22 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
 
     // ---- bias + mask + online softmax of this lane's query over its 16 keys, then across the four lane groups ----
     float mx = -1e30f;
+    if constexpr (ROW64) {
+      // key position k0 + i = (row kc, column i): bias index (qy - kc + 63) * 127 + (qx - kx + 63), kx = 16 j + 4 fq + e
+      const float* const bp = tbl + (r64_qy - kc + 63) * 127 + r64_qx - 4 * fq;        // + 63 - kx folded into constant offsets
+      const bool rowdiff = r64_rhq != (wy * 64 + kc < p.H - 64 ? 0 : (wy * 64 + kc < p.H - p.shift ? 1 : 2));
+      const float madd[2] = {(p.shift > 0 && (rowdiff || r64_cdiff[0])) ? -100.0f * LOG2E : 0.f,
+                             (p.shift > 0 && (rowdiff || r64_cdiff[1])) ? -100.0f * LOG2E : 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = (s[j][e] + bp[63 - 16 * j - e]) + madd[j >> 1];
+          s[j][e] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int4 ki = *reinterpret_cast<const int4*>(infk_c + j * 16 + 4 * fq);
@@ -213,16 +242,19 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
         mx = fmaxf(mx, v);
       }
     }
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float mnew = fmaxf(mrow, mx);
-    const float alpha = fexp(mrow - mnew);
+    const float alpha = ROW64 ? __builtin_amdgcn_exp2f(mrow - mnew) : fexp(mrow - mnew);
     float rs = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float pv = (FULL || k0 + j * 16 + 4 * fq + e < N) ? fexp(s[j][e] - mnew) : 0.f;
+        float pv;
+        if constexpr (ROW64) pv = __builtin_amdgcn_exp2f(s[j][e] - mnew);
+        else pv = (FULL || k0 + j * 16 + 4 * fq + e < N) ? fexp(s[j][e] - mnew) : 0.f;
         s[j][e] = pv;
         rs += pv;
       }
@@ -304,10 +336,17 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
   const int full = N % 64 == 0 ? 1 : 0;
   auto kern = tbl_in_lds ? (full ? window_attn_kernel<PREC, NT_O, true, NW, true> : window_attn_kernel<PREC, NT_O, true, NW, false>)
                          : (full ? window_attn_kernel<PREC, NT_O, false, NW, true> : window_attn_kernel<PREC, NT_O, false, NW, false>);
-  static size_t configured[4] = {0, 0, 0, 0};
-  if (lds > configured[tbl_in_lds * 2 + full]) {
+  // 64 x 64 windows with a shift of 0 or 32 (what DRCT builds: window_size // 2): the one-row-per-chunk path
+  const bool row64 = PREC == SRAD_PREC_BF16 && NW == 8 && p.ws == 64 && tbl_in_lds && (p.shift == 0 || p.shift == 32) &&
+                     getenv("SRAD_NO_ROW64") == nullptr;
+  if constexpr (PREC == SRAD_PREC_BF16 && NW == 8) {
+    if (row64) kern = window_attn_kernel<PREC, NT_O, true, NW, true, true>;
+  }
+  static size_t configured[5] = {0, 0, 0, 0, 0};
+  const int slot = row64 ? 4 : tbl_in_lds * 2 + full;
+  if (lds > configured[slot]) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured[tbl_in_lds * 2 + full] = lds;
+    configured[slot] = lds;
   }
   const int nW = (p.H / p.ws) * (p.W / p.ws);
   dim3 grid((N + BQ - 1) / BQ, p.heads, p.B * nW);
