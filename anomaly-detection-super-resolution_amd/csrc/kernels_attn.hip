@@ -106,8 +106,25 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
     if (tid < BQ) { tokq[tid] = tok; infq[tid] = inf; }
     else { tokk[tid - BQ] = tok; infk[tid - BQ] = inf; }
   }
-  if constexpr (TBL_LDS)
-    for (int i = tid; i < tw * tw; i += NT) tbl[i] = p.table[(size_t)i * heads + h] * (ROW64 ? LOG2E : 1.0f);
+  // ROW64: the 128 queries of a workgroup are two rows of the window (qy0, qy0 + 1) and chunk kc is key row kc, so a chunk
+  // indexes exactly two rows of the 127 x 127 bias table, R0(kc) = qy0 - kc + 63 and R0(kc) + 1 = R0(kc - 1): ONE new row
+  // per chunk.  The rows slide through a four-slot ring in LDS (slot = R & 3, 128 floats each) instead of the whole table
+  // (64.5 KB) being resident: 2 - 3 workgroups fit a CU, which is what hides this kernel's per-chunk latency chain.
+  const int r64_qy0 = q0 / 64;
+  auto r64_row_load = [&](int R) -> float {                       // threads 0 .. 126: column tid of table row R (clamped)
+    const int Rc = min(max(R, 0), 126), cc = min(tid, 126);
+    return p.table[(size_t)(Rc * 127 + cc) * heads + h] * LOG2E;
+  };
+  float r64_next = 0.f;                                           // row of the NEXT chunk, in flight
+  if constexpr (ROW64) {
+    if (tid < 128) {
+      tbl[((r64_qy0 + 64) & 3) * 128 + tid] = r64_row_load(r64_qy0 + 64);      // R0(0) + 1
+      tbl[((r64_qy0 + 63) & 3) * 128 + tid] = r64_row_load(r64_qy0 + 63);      // R0(0)
+      r64_next = r64_row_load(r64_qy0 + 62);                                   // R0(1)
+    }
+  } else if constexpr (TBL_LDS) {
+    for (int i = tid; i < tw * tw; i += NT) tbl[i] = p.table[(size_t)i * heads + h];
+  }
   __syncthreads();
 
   // All global loads are unconditional on clamped addresses and masked by selects afterwards:
@@ -122,7 +139,7 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
       dst[i] = *reinterpret_cast<const f32x4*>(p.qkv + (size_t)toks[row] * ldq + (which * heads + h) * hdp + min(c, hdp - 4));
     }
   };
-  auto store_tile = [&](T* base, int first, float mul, const auto& src) {
+  auto store_tile = [&](T* base, int first, float mul, const auto& src, bool ones_col = false) {
     constexpr int NL = sizeof(src) / sizeof(f32x4);
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
@@ -133,7 +150,7 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
       const bool rok = first + row < N;
       f32x4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (rok && c + e < hd) ? src[i][e] * mul : 0.f;
+      for (int e = 0; e < 4; ++e) v[e] = (rok && c + e < hd) ? src[i][e] * mul : ((ones_col && c + e == hd) ? 1.0f : 0.f);
       store4<PREC>(base + row * HS + c, v);
     }
   };
@@ -168,7 +185,12 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
     const int* const infk_c = infk + (kc % 3) * 64;
     if (kc > 0) __syncthreads();           // previous chunk fully consumed (K / V / token slot (kc + 2) % 3 free)
     store_tile(Ks, k0, 1.f, kv);
-    store_tile(Vs, k0, 1.f, vv);
+    store_tile(Vs, k0, 1.f, vv, ROW64);          // ROW64: column hd of V is 1, so P.V also accumulates the softmax denominator
+    if constexpr (ROW64) {
+      // the table row chunk kc + 1 adds (its slot was last read four chunks ago), and the load of the one after it
+      if (tid < 128 && kc + 1 < nchunk) tbl[((r64_qy0 + 62 - kc) & 3) * 128 + tid] = r64_next;
+      if (tid < 128) r64_next = r64_row_load(r64_qy0 + 61 - kc);
+    }
     __syncthreads();
     if (kc + 1 < nchunk) {
       const int* tk = tokk + ((kc + 1) % 3) * 64;
@@ -183,8 +205,21 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
 
     // ---- S^T = K (Q * scale)^T: s[j][e] = score(key 16 j + 4 fq + e, query wave * 16 + fr) ----
     f32x4 s[4];
+    if constexpr (ROW64) {
+      // the accumulators START as bias + mask: key position k0 + i = (row kc, column i), bias index
+      // (qy - kc + 63) * 127 + (qx - kx + 63) with kx = 16 j + 4 fq + e -> sixteen loads at constant offsets
+      const float* const bp = tbl + ((r64_qy - kc + 63) & 3) * 128 + r64_qx - 4 * fq;
+      const bool rowdiff = r64_rhq != (wy * 64 + kc < p.H - 64 ? 0 : (wy * 64 + kc < p.H - p.shift ? 1 : 2));
+      const float madd[2] = {(p.shift > 0 && (rowdiff || r64_cdiff[0])) ? -100.0f * LOG2E : 0.f,
+                             (p.shift > 0 && (rowdiff || r64_cdiff[1])) ? -100.0f * LOG2E : 0.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[j][e] = bp[63 - 16 * j - e] + madd[j >> 1];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     if constexpr (PREC == SRAD_PREC_BF16) {
 #pragma unroll
       for (int kk = 0; kk < HDP; kk += 32) {
@@ -211,20 +246,8 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
     // ---- bias + mask + online softmax of this lane's query over its 16 keys, then across the four lane groups ----
     float mx = -1e30f;
     if constexpr (ROW64) {
-      // key position k0 + i = (row kc, column i): bias index (qy - kc + 63) * 127 + (qx - kx + 63), kx = 16 j + 4 fq + e
-      const float* const bp = tbl + (r64_qy - kc + 63) * 127 + r64_qx - 4 * fq;        // + 63 - kx folded into constant offsets
-      const bool rowdiff = r64_rhq != (wy * 64 + kc < p.H - 64 ? 0 : (wy * 64 + kc < p.H - p.shift ? 1 : 2));
-      const float madd[2] = {(p.shift > 0 && (rowdiff || r64_cdiff[0])) ? -100.0f * LOG2E : 0.f,
-                             (p.shift > 0 && (rowdiff || r64_cdiff[1])) ? -100.0f * LOG2E : 0.f};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = (s[j][e] + bp[63 - 16 * j - e]) + madd[j >> 1];
-          s[j][e] = v;
-          mx = fmaxf(mx, v);
-        }
-      }
+      for (int j = 0; j < 4; ++j) mx = fmaxf(mx, fmaxf(fmaxf(s[j][0], s[j][1]), fmaxf(s[j][2], s[j][3])));
     } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -247,20 +270,25 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float mnew = fmaxf(mrow, mx);
     const float alpha = ROW64 ? __builtin_amdgcn_exp2f(mrow - mnew) : fexp(mrow - mnew);
-    float rs = 0.f;
+    if constexpr (ROW64) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float pv;
-        if constexpr (ROW64) pv = __builtin_amdgcn_exp2f(s[j][e] - mnew);
-        else pv = (FULL || k0 + j * 16 + 4 * fq + e < N) ? fexp(s[j][e] - mnew) : 0.f;
-        s[j][e] = pv;
-        rs += pv;
-      }
-    rs += __shfl_xor(rs, 16);
-    rs += __shfl_xor(rs, 32);
-    lrow = lrow * alpha + rs;
+        for (int e = 0; e < 4; ++e) s[j][e] = __builtin_amdgcn_exp2f(s[j][e] - mnew);   // the denominator comes out of P.V (ones column)
+    } else {
+      float rs = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pv = (FULL || k0 + j * 16 + 4 * fq + e < N) ? fexp(s[j][e] - mnew) : 0.f;
+          s[j][e] = pv;
+          rs += pv;
+        }
+      rs += __shfl_xor(rs, 16);
+      rs += __shfl_xor(rs, 32);
+      lrow = lrow * alpha + rs;
+    }
     mrow = mnew;
 #pragma unroll
     for (int j = 0; j < NT_O; ++j) o[j] *= alpha;
@@ -308,6 +336,16 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
   // ---- normalise and scatter back to raster order ([T][d], plain head-major columns) ----
   {
     const int row = wave * 16 + fr;
+    if constexpr (ROW64) {
+      // channel hd of O^T holds the denominator: lane group fq = (hd % 16) / 4, register hd % 4 of column tile hd / 16
+      float l = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT_O; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (j == hd / 16 && e == (hd & 3)) l = o[j][e];
+      lrow = __shfl(l, (((hd & 15) >> 2) << 4) | fr);
+    }
     if (q0 + row < N) {
       const float inv = 1.0f / lrow;
       float* dst = p.out + (size_t)tokq[row] * d + h * hd;
@@ -332,7 +370,7 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
   size_t base = (size_t)((BQ + 128) * HS) * sizeof(T) + (2 * BQ + 6 * 64) * sizeof(int);
   base = srad_align_up(base, 16);
   const int tbl_in_lds = (base + (size_t)tw * tw * 4) <= 150 * 1024 ? 1 : 0;
-  const size_t lds = base + (tbl_in_lds ? (size_t)tw * tw * 4 : 0);
+  size_t lds = base + (tbl_in_lds ? (size_t)tw * tw * 4 : 0);
   const int full = N % 64 == 0 ? 1 : 0;
   auto kern = tbl_in_lds ? (full ? window_attn_kernel<PREC, NT_O, true, NW, true> : window_attn_kernel<PREC, NT_O, true, NW, false>)
                          : (full ? window_attn_kernel<PREC, NT_O, false, NW, true> : window_attn_kernel<PREC, NT_O, false, NW, false>);
@@ -340,7 +378,10 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
   const bool row64 = PREC == SRAD_PREC_BF16 && NW == 8 && p.ws == 64 && tbl_in_lds && (p.shift == 0 || p.shift == 32) &&
                      getenv("SRAD_NO_ROW64") == nullptr;
   if constexpr (PREC == SRAD_PREC_BF16 && NW == 8) {
-    if (row64) kern = window_attn_kernel<PREC, NT_O, true, NW, true, true>;
+    if (row64) {
+      kern = window_attn_kernel<PREC, NT_O, true, NW, true, true>;
+      lds = base + (size_t)4 * 128 * 4;            // a four-row ring of the bias table
+    }
   }
   static size_t configured[5] = {0, 0, 0, 0, 0};
   const int slot = row64 ? 4 : tbl_in_lds * 2 + full;
