@@ -193,11 +193,13 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
     constexpr StageGeo sg = geo(decltype(S)::value);
     const char* w = (const char*)(sg.ph == -1 ? p.w_adjt : (sg.ph == 0 ? p.w_fc2t : p.w_fc1t));
     const int nreal = sg.ph == 0 ? m : d;
-    const char* base = w + ((size_t)(sg.g * 8 + wave) * sg.kc + sg.kg * 8) * 1024 + fr * 64 + fq * 16;
-    if ((sg.g * 8 + wave_s) * 16 < nreal) {
+    // unconditional (a load inside a branch makes hipcc's wait-count pass drain every older load at the join, see
+    // mlp_block_kernel): a wave without real columns in the stage reads one 16-byte word per load instead
+    const bool live = (sg.g * 8 + wave_s) * 16 < nreal;
+    const char* base = live ? w + ((size_t)(sg.g * 8 + wave) * sg.kc + sg.kg * 8) * 1024 + fr * 64 + fq * 16 : w;
+    const int step = live ? 1024 : 0;
 #pragma unroll
-      for (int cc = 0; cc < sg.nch; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + cc * 1024);
-    }
+    for (int cc = 0; cc < sg.nch; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + cc * step);
   };
   auto mma_stage = [&](const __bf16* A, int lda, int k0, int nch, const u32x4 (&reg)[8], f32x4 (&c)[NRT]) {
     const __bf16* ar = A + fr * lda + k0 + 8 * fq;
@@ -231,16 +233,23 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
     const int idx = min(tid + 512 * j, FM * NAQ - 1), row = idx / NAQ, c = (idx - row * NAQ) * 4;
     if constexpr (KCA > 0) {
       a_reg[j] = *reinterpret_cast<const f32x4*>(p.dA + (size_t)(m0 + row) * p.ld_dA + min(c, p.KA - 4));
-      y_reg[j] = p.y_act ? *reinterpret_cast<const f32x4*>(p.y_act + (size_t)(m0 + row) * p.ld_y + min(c, p.KA - 4)) : z4;
+      // unconditional load (from dA itself when there is no activation: the values are not used then)
+      typedef const f32x4 __attribute__((address_space(1)))* gf4_p;     // (C-style cast: a pointer select is generic to hipcc)
+      y_reg[j] = *(gf4_p)((p.y_act ? p.y_act + (size_t)(m0 + row) * p.ld_y : p.dA + (size_t)(m0 + row) * p.ld_dA) + min(c, p.KA - 4));
     } else {
       a_reg[j] = *reinterpret_cast<const f32x4*>(p.dx2 + (size_t)(m0 + row) * d + min(c, d - 4));
     }
   }
-  static_for<0, NSETS>([&](auto Q) { load_w(Q, w_reg[decltype(Q)::value]); });
-  const float gq = tid < 384 ? p.ln_g[min(tid, d - 1)] : 0.f;
+  // (the weight stages are issued BEHIND the activations: vmcnt retires in issue order and the CU's load queue is
+  //  first-in first-out, see mlp_block_kernel)
+  const float gq = p.ln_g[min(tid, d - 1)];
   float rs2v[NRT];
 #pragma unroll
-  for (int rt = 0; rt < NRT; ++rt) rs2v[rt] = p.rs2 ? p.rs2[(m0 + rt * 16 + fr) / p.rps] : 1.f;
+  for (int rt = 0; rt < NRT; ++rt) {
+    typedef const float __attribute__((address_space(1)))* gfloat_p;   // a select of two kernel-argument pointers is a generic pointer to hipcc: flat loads, vmcnt(0) everywhere
+    const float r = ((gfloat_p)(p.rs2 ? p.rs2 : p.ln_g))[p.rs2 ? (m0 + rt * 16 + fr) / p.rps : 0];
+    rs2v[rt] = p.rs2 ? r : 1.f;
+  }
   f32x4 r2[GD][NRT], xv[GD][NRT];
 #pragma unroll
   for (int g = 0; g < GD; ++g) {
@@ -260,6 +269,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt) hp[g][rt] = *reinterpret_cast<const f32x4*>(p.hpre + (size_t)(m0 + rt * 16 + fr) * m + c4);
   }
+  load_w(std::integral_constant<int, 0>{}, w_reg[0]);
   if (tid < 384) v_g[tid] = gq;
 #pragma unroll
   for (int j = 0; j < NAJ; ++j) {
@@ -283,6 +293,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
       }
     }
   }
+  static_for<1, NSETS>([&](auto Q) { load_w(Q, w_reg[decltype(Q)::value]); });   // the rest of the weight look-ahead
 
   f32x4 dxn[GD][NRT];
   f32x4 c[NRT];
@@ -338,17 +349,21 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
     constexpr int sc = decltype(S)::value < n_proj - 1 ? decltype(S)::value : n_proj - 1;
     constexpr int g = sc / KGD, kg = sc - g * KGD;
     constexpr int nch = KCD - kg * 8 < 8 ? KCD - kg * 8 : 8;
-    const char* base = (const char*)p.w_projt + ((size_t)(g * 8 + wave) * KCD + kg * 8) * 1024 + fr * 64 + fq * 16;
-    if ((g * 8 + wave_s) * 16 < d) {
+    const bool live = (g * 8 + wave_s) * 16 < d;
+    const char* base = live ? (const char*)p.w_projt + ((size_t)(g * 8 + wave) * KCD + kg * 8) * 1024 + fr * 64 + fq * 16 : (const char*)p.w_projt;
+    const int step = live ? 1024 : 0;
 #pragma unroll
-      for (int cc = 0; cc < nch; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + cc * 1024);
-    }
+    for (int cc = 0; cc < nch; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + cc * step);
   };
   float rs1v[NRT];
   if (p.w_projt) {
     static_for<0, NSETS>([&](auto Q) { load_wp(Q, w_reg[decltype(Q)::value]); });
 #pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) rs1v[rt] = p.rs1 ? p.rs1[(m0 + rt * 16 + fr) / p.rps] : 1.f;
+    for (int rt = 0; rt < NRT; ++rt) {
+      typedef const float __attribute__((address_space(1)))* gfloat_p;
+      const float r = ((gfloat_p)(p.rs1 ? p.rs1 : p.ln_g))[p.rs1 ? (m0 + rt * 16 + fr) / p.rps : 0];
+      rs1v[rt] = p.rs1 ? r : 1.f;
+    }
   }
   ln_bwd_tail<NRT, GD>(dxn, xv, r2, v_g, red, d, wave, fr, fq, p.dx1 + (size_t)m0 * d, d, part + (size_t)blockIdx.x * (2 * SRAD_LNB_CP),
                        p.w_projt ? A1 : nullptr, FB_LDA);
@@ -405,15 +420,16 @@ __global__ __launch_bounds__(512) void lin_ln_bwd_kernel(const LinLnBwdParams p,
     constexpr int sc = decltype(S)::value < n_stages - 1 ? decltype(S)::value : n_stages - 1;
     constexpr int g = sc / KG, kg = sc - g * KG;
     constexpr int nch = KC - kg * 8 < 8 ? KC - kg * 8 : 8;
-    const char* base = (const char*)p.w_t + ((size_t)(g * 8 + wave) * KC + kg * 8) * 1024 + fr * 64 + fq * 16;
-    if ((g * 8 + wave_s) * 16 < d) {                 // all-padding column tiles: no loads, no MFMAs (see mlp_block_kernel)
+    const bool live = (g * 8 + wave_s) * 16 < d;      // all-padding column tiles: one 16-byte word per load, no MFMAs (see mlp_block_kernel)
+    const char* base = live ? (const char*)p.w_t + ((size_t)(g * 8 + wave) * KC + kg * 8) * 1024 + fr * 64 + fq * 16 : (const char*)p.w_t;
+    const int step = live ? 1024 : 0;
 #pragma unroll
-      for (int cc = 0; cc < nch; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + cc * 1024);
-    }
+    for (int cc = 0; cc < nch; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + cc * step);
   };
   auto col4_of = [&](int g) { return FB_SC * g + 16 * wave + 4 * fq; };
-  static_for<0, NSETS>([&](auto Q) { load_w(Q, w_reg[decltype(Q)::value]); });
-  const float gq = tid < 384 ? p.ln_g[min(tid, d - 1)] : 0.f;
+  // loads in the order their data is needed, all unconditional (see mlp_block_kernel): residual / input rows, gamma, the dY
+  // tile, then the weight stages
+  const float gq = p.ln_g[min(tid, d - 1)];
   f32x4 r2[GD][NRT], xv[GD][NRT];
 #pragma unroll
   for (int g = 0; g < GD; ++g) {
@@ -421,8 +437,10 @@ __global__ __launch_bounds__(512) void lin_ln_bwd_kernel(const LinLnBwdParams p,
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt) {
       const size_t row = (size_t)(m0 + rt * 16 + fr);
-      r2[g][rt] = p.dres ? *reinterpret_cast<const f32x4*>(p.dres + row * p.ld_dres + c4) : z4;
-      if (p.accumulate) r2[g][rt] += *reinterpret_cast<const f32x4*>(p.out + row * p.ld_out + c4);
+      typedef const f32x4 __attribute__((address_space(1)))* gf4_p;
+      const f32x4 rd = *(gf4_p)(p.dres ? p.dres + row * p.ld_dres + c4 : p.x + row * p.ldx + c4);
+      const f32x4 ro = *(gf4_p)(p.accumulate ? p.out + row * p.ld_out + c4 : p.x + row * p.ldx + c4);
+      r2[g][rt] = (p.dres ? rd : z4) + (p.accumulate ? ro : z4);
       xv[g][rt] = *reinterpret_cast<const f32x4*>(p.x + row * p.ldx + c4);
     }
   }
@@ -451,6 +469,7 @@ __global__ __launch_bounds__(512) void lin_ln_bwd_kernel(const LinLnBwdParams p,
     }
   }
   if (tid < 384) v_g[tid] = gq;
+  static_for<0, NSETS>([&](auto Q) { load_w(Q, w_reg[decltype(Q)::value]); });
   __syncthreads();
 
   f32x4 dxn[GD][NRT];
