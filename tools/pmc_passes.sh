@@ -20,5 +20,6 @@ run write WRITE_SIZE
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
 run sq2 SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE
 python3 tools/pmc_summary.py "profiles/${TAG}_pmc_counters.json" "$OUT"/fetch "$OUT"/write "$OUT"/sq1 "$OUT"/sq2 > "$OUT.summary.txt"
-cp "profiles/${TAG}_pmc_counters.json" "$OUT/"
+cp "profiles/${TAG}_pmc_counters.json" "$OUT.counters.json"
+rm -rf "$OUT"   # the raw per-dispatch CSVs are tens of MB: only the summaries travel back
 echo "summary written"

@@ -19,7 +19,7 @@ are uncalibrated.  SQ_*_CYCLES count quad-cycles (x4 = shader cycles) except SQ_
 the SIMDs that were busy); SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE are summed over the 8 XCDs (per shader engine for SQ).
 
 Derived per kernel class:
-  mfma_busy            = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8
+  mfma_busy            = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x kernel cycles), kernel cycles = SQ_BUSY_CYCLES / 32
                          (share of all matrix pipes' time spent in MFMA while the kernel runs: the north_star's "MFMA-busy")
   wait_frac            = SQ_WAIT_ANY / SQ_WAVE_CYCLES          (waves parked at s_waitcnt / s_barrier)
   issue_stall_frac     = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES
@@ -102,14 +102,21 @@ def main():
                     out[name] = round(avg[key] / wave, 4)
         if avg.get("SQ_LDS_IDX_ACTIVE"):
             out["lds_bank_conflict_frac"] = round(avg.get("SQ_LDS_BANK_CONFLICT", 0.0) / avg["SQ_LDS_IDX_ACTIVE"], 4)
-        if "GRBM_GUI_ACTIVE" in avg and avg["GRBM_GUI_ACTIVE"] > 0:
+        # kernel length in shader cycles: SQ_BUSY_CYCLES is summed over the 32 shader engines and counts only while waves are
+        # resident (15.7 us dispatches read ~32 k cycles = 2.1 GHz); GRBM_GUI_ACTIVE / 8 also counts the dispatch ramp of the
+        # profiled launch and reads ~60 % high on kernels this short (MI355X_MICROARCH.md "DVFS give-back"), so it is the fallback
+        kcycles = None
+        if avg.get("SQ_BUSY_CYCLES", 0) > 0:
+            kcycles = avg["SQ_BUSY_CYCLES"] / 32.0
+        elif avg.get("GRBM_GUI_ACTIVE", 0) > 0:
             kcycles = avg["GRBM_GUI_ACTIVE"] / 8.0
+        if kcycles:
             out["kernel_cycles"] = round(kcycles)
             if "SQ_VALU_MFMA_BUSY_CYCLES" in avg:
                 out["mfma_busy"] = round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * 256 * kcycles), 4)
-                out["mfma_busy_note"] = "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): share of the chip's matrix-pipe time"
-            if "SQ_BUSY_CYCLES" in avg:
-                out["sq_busy_frac"] = round(avg["SQ_BUSY_CYCLES"] / (avg["GRBM_GUI_ACTIVE"] * 4), 4)      # 32 shader engines / 8 XCDs
+                out["mfma_busy_note"] = "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x SQ_BUSY_CYCLES / 32): share of the chip's matrix-pipe time while the kernel is resident"
+            if "GRBM_GUI_ACTIVE" in avg and avg["GRBM_GUI_ACTIVE"] > 0:
+                out["grbm_cycles"] = round(avg["GRBM_GUI_ACTIVE"] / 8.0)
         return out
 
     res = {"source": "rocprofv3 --pmc passes (one counter group per process) of `bench.py --no-graph --no-train --no-eval "
