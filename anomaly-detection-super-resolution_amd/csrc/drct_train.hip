@@ -219,7 +219,9 @@ int srad_drct_forward_train(srad_drct_t* h, const float* x, int B, int H, int W,
         a.x = cur; a.ldx = D; a.ln_g = h->pt.fptr(sw.n1g); a.ln_b = h->pt.fptr(sw.n1b);
         a.w_qkv = h->pt.frag_ptr(sw.qkv.w); a.b_qkv = h->pt.fptr(sw.qkv.b); a.table = h->pt.fptr(sw.table);
         a.out = sv.attn; a.ld_out = d; a.B = B; a.H = H; a.W = W; a.shift = sw.shift; a.d = d; a.heads = sw.heads;
-        a.save_xn = sv.xn1; a.save_qkv = sv.qkv; a.hdp = hdp;
+        // the tensors only the weight gradients read (LN1(x), LN2(.), GELU(.), the block output) are left as bf16, which is
+        // what the MFMA would round them to anyway: half the bytes written here and read (3 - 9 times each) by wgrad
+        a.save_xn_h = reinterpret_cast<__bf16*>(sv.xn1); a.save_qkv = sv.qkv; a.hdp = hdp;
         SRAD_TRY(srad_launch_qkv_attn(a, s));
         MlpBlockParams q{};
         q.attn = sv.attn; q.ld_attn = d; q.shortcut = cur; q.ld_short = D;
@@ -229,7 +231,8 @@ int srad_drct_forward_train(srad_drct_t* h, const float* x, int B, int H, int W,
         q.b_proj = h->pt.fptr(sw.proj.b); q.b_fc1 = h->pt.fptr(sw.fc1.b); q.b_fc2 = h->pt.fptr(sw.fc2.b); q.b_adj = h->pt.fptr(sw.adjust.b);
         q.ln_g = h->pt.fptr(sw.n2g); q.ln_b = h->pt.fptr(sw.n2b);
         q.rs1 = ks1; q.rs2 = ks2; q.rps = HW;
-        q.save_x1 = sv.x1; q.save_xn2 = sv.xn2; q.save_hpre = sv.hpre; q.save_hact = sv.hact; q.save_x2 = sv.x2;
+        q.save_x1 = sv.x1; q.save_hpre = sv.hpre;
+        q.save_xn2_h = reinterpret_cast<__bf16*>(sv.xn2); q.save_hact_h = reinterpret_cast<__bf16*>(sv.hact); q.save_x2_h = reinterpret_cast<__bf16*>(sv.x2);
         if (k < 4) { q.act = SRAD_ACT_LRELU; q.slope = 0.2f; q.alpha = 1.f; q.Y = cur; q.ldy = D; q.yoff = d; }
         else { q.act = SRAD_ACT_NONE; q.alpha = 0.2f; q.R = cur; q.ldr = D; q.Y = nxt; q.ldy = D; q.yoff = 0; }
         SRAD_TRY(srad_launch_mlp_block(q, s));
@@ -426,6 +429,9 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       const int d = sw.d, hdp = hdp_of(d, sw.heads);
       const float* ks1 = keep_scale ? keep_scale + (size_t)(2 * bi) * B : nullptr;
       const float* ks2 = keep_scale ? keep_scale + (size_t)(2 * bi + 1) * B : nullptr;
+      // the fused training forward left this block's wgrad-only activations as bf16 (see srad_drct_forward_train)
+      const bool xh = h->fuse_mlp && srad_qkv_attn_supported(prec, c.window_size, H, W, d, sw.heads) &&
+                      srad_mlp_block_supported(prec, T, d, sw.hidden, k < 4 ? c.gc : E);
       const int set = blk_count & 1;                       // temporaries + partial workspace of this block
       if (side != s && side_done[set]) SRAD_CHECK_HIP(hipStreamWaitEvent(s, side_done[set], 0));   // block n - 2 fully consumed
       wq.ws = wq_base + (size_t)set * wq_half; wq.ws_floats = wq_half;
@@ -446,7 +452,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       }
       {
         WgradParams g = wgrad_of(h, sw.adjust, G, dA, ldA, 0, sv.x2, d, T);
-        g.alpha = aalpha;
+        g.alpha = aalpha; g.x_bf16 = xh;
         SRAD_TRY(srad_launch_wgrad_deferred(prec, g, wq, side));
         if (!fuse_adj) {
           GemmParams p = dgrad_gemm(h, sw.adjust, dA, ldA, T, dx2, d);
@@ -456,9 +462,10 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       }
       {
         WgradParams g = wgrad_of(h, sw.fc2, G, dx2, d, 0, sv.hact, sw.hidden, T);
-        g.row_scale = ks2; g.rps = HW;
+        g.row_scale = ks2; g.rps = HW; g.x_bf16 = xh;
         SRAD_TRY(srad_launch_wgrad_deferred(prec, g, wq, side));
         WgradParams g1 = wgrad_of(h, sw.fc1, G, dh, sw.hidden, 0, sv.xn2, d, T);
+        g1.x_bf16 = xh;
         SRAD_TRY(srad_launch_wgrad_deferred(prec, g1, wq, side));
       }
       if (fuse_mlp) {   // both data gradients and the LayerNorm2 backward in one launch (kernels_fused_bwd.hip)
@@ -511,6 +518,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       }
       {
         WgradParams g = wgrad_of(h, sw.qkv, G, dqkv, 3 * d, 0, sv.xn1, d, T);
+        g.x_bf16 = xh;
         SRAD_TRY(srad_launch_wgrad_deferred(prec, g, wq, side));
       }
       if (fused_bwd && h->ts.tf_off[sw.qkv.w] >= 0 && srad_lin_ln_bwd_supported(prec, T, 3 * d, d)) {

@@ -49,9 +49,13 @@ constexpr int LNB_CP = SRAD_LNB_CP;                  // columns of a dgamma | db
 // wave step - no row / column / padding masks at all (columns past N / Cin read clamped real data into tile rows the
 // final store drops), the factor is one value per wave step: fewer registers (two waves per SIMD) and ~200 fewer
 // VALU instructions per step.
-template <int PREC, bool CONV, bool FULL = false>
+// XH / YH (FULL only): X / dY are stored as bf16 - half the operand bytes and prefetch registers; the 8 rows x 4 columns a
+// lane holds are transposed into the four 8-row MFMA operands with v_perm_b32 instead of being converted.  A bf16 dY is
+// already multiplied by its DropPath factor (its producer did that), so no per-step factor either.
+template <int PREC, bool CONV, bool FULL = false, bool XH = false, bool YH = false>
 __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int ksplit, const int tn, const int tc,
                                            float* __restrict__ part, const int L) {
+  static_assert(!(XH || YH) || (!CONV && PREC == SRAD_PREC_BF16), "bf16 operand storage: Linear layers, bf16 MFMA path");
   extern __shared__ __attribute__((aligned(16))) float wsm[];     // [4 waves][64][68] + [4][64] bias + flag
   constexpr int TST = 68;
   float* const dbs = wsm + 4 * 64 * TST;
@@ -88,7 +92,8 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int kspli
 
   // every load is unconditional on a clamped address; masking happens on the registers afterwards.
   // The next step's loads are issued before this step's MFMAs (two register sets).
-  f32x4 av[1 + SRAD_WGRAD_PREFETCH][RL], bv[1 + SRAD_WGRAD_PREFETCH][RL];
+  f32x4 av[1 + SRAD_WGRAD_PREFETCH][YH ? 1 : RL], bv[1 + SRAD_WGRAD_PREFETCH][XH ? 1 : RL];
+  u32x2 avh[1 + SRAD_WGRAD_PREFETCH][YH ? RL : 1], bvh[1 + SRAD_WGRAD_PREFETCH][XH ? RL : 1];   // bf16 storage: 4 values = 8 bytes per row
   unsigned okm[2];                    // bit t: a row valid, bit 8 + t: b row valid
   float rs[1 + SRAD_WGRAD_PREFETCH][FULL ? 1 : RL];
   auto load_step = [&](int m0, auto set_c) {
@@ -97,10 +102,12 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int kspli
 #pragma unroll
       for (int t = 0; t < RL; ++t) {
         const size_t mr = (size_t)(m0 + RL * fq + t);
-        av[set][t] = *reinterpret_cast<const f32x4*>(p.dY + mr * p.ldy + noff);
-        bv[set][t] = *reinterpret_cast<const f32x4*>(p.X + mr * p.ldx + coff);
+        if constexpr (YH) avh[set][t] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(p.dY) + mr * p.ldy + noff);
+        else av[set][t] = *reinterpret_cast<const f32x4*>(p.dY + mr * p.ldy + noff);
+        if constexpr (XH) bvh[set][t] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(p.X) + mr * p.ldx + coff);
+        else bv[set][t] = *reinterpret_cast<const f32x4*>(p.X + mr * p.ldx + coff);
       }
-      rs[set][0] = p.row_scale ? p.row_scale[m0 / p.rps] : 1.f;
+      if constexpr (!YH) rs[set][0] = p.row_scale ? p.row_scale[m0 / p.rps] : 1.f;
       return;
     }
     unsigned ok = 0u;
@@ -116,7 +123,8 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int kspli
     for (int t = 0; t < RL; ++t) {
       const int m = m0 + RL * fq + t;
       const int mc = min(m, p.M - 1);
-      av[set][t] = *reinterpret_cast<const f32x4*>(p.dY + (size_t)mc * p.ldy + noff);
+      if constexpr (YH) avh[set][t] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(p.dY) + (size_t)mc * p.ldy + noff);
+      else av[set][t] = *reinterpret_cast<const f32x4*>(p.dY + (size_t)mc * p.ldy + noff);
       size_t xr = (size_t)mc;
       bool in = true;
       if constexpr (CONV) {
@@ -128,8 +136,9 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int kspli
         in = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
         xr = (size_t)((bb * p.Hi + min(max(iy, 0), p.Hi - 1)) * p.Wi + min(max(ix, 0), p.Wi - 1));
       }
-      bv[set][t] = *reinterpret_cast<const f32x4*>(p.X + xr * p.ldx + coff);
-      rs[set][t] = p.row_scale ? p.row_scale[mc / p.rps] : 1.f;
+      if constexpr (XH) bvh[set][t] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(p.X) + xr * p.ldx + coff);
+      else bv[set][t] = *reinterpret_cast<const f32x4*>(p.X + xr * p.ldx + coff);
+      rs[set][t] = (!YH && p.row_scale) ? p.row_scale[mc / p.rps] : 1.f;
       ok |= ((m < me && n_ok) ? 1u : 0u) << t;
       ok |= ((m < me && c_ok && in) ? 1u : 0u) << (8 + t);
     }
@@ -138,23 +147,68 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int kspli
   auto compute_step = [&](auto set_c) {
     constexpr int set = decltype(set_c)::value;
     f32x4 a[RL], b[RL];
+    // 8 rows x (2 dwords = 4 bf16 columns) -> operand e = column e of the 8 rows: dword t/2 of operand 2 w + half takes the
+    // low (half 0) or high (half 1) 16 bits of dword w of rows t and t + 1
+    auto transpose_h = [&](const u32x2 (&src)[RL], bf16x8 (&dst)[4]) {
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        u32x4 lo, hi;
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) {
+          lo[t2] = __builtin_amdgcn_perm(src[2 * t2 + 1][w], src[2 * t2][w], 0x05040100u);
+          hi[t2] = __builtin_amdgcn_perm(src[2 * t2 + 1][w], src[2 * t2][w], 0x07060302u);
+        }
+        dst[2 * w] = __builtin_bit_cast(bf16x8, lo);
+        dst[2 * w + 1] = __builtin_bit_cast(bf16x8, hi);
+      }
+    };
 #pragma unroll
     for (int t = 0; t < RL; ++t) {
       if constexpr (FULL) {
-        a[t] = av[set][t] * rs[set][0];
-        b[t] = bv[set][t];
+        if constexpr (YH) {                                 // fp32 view of the row for the bias sums only
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            a[t][2 * w] = __builtin_bit_cast(float, avh[set][t][w] << 16);
+            a[t][2 * w + 1] = __builtin_bit_cast(float, avh[set][t][w] & 0xffff0000u);
+          }
+        } else {
+          a[t] = av[set][t] * rs[set][0];
+        }
+        if constexpr (!XH) b[t] = bv[set][t];
       } else {
-        a[t] = ((okm[set] >> t) & 1u) ? av[set][t] * rs[set][t] : zero4;
-        b[t] = ((okm[set] >> (8 + t)) & 1u) ? bv[set][t] : zero4;
+        if constexpr (YH) {
+          if (!((okm[set] >> t) & 1u)) avh[set][t] = u32x2{0u, 0u};
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            a[t][2 * w] = __builtin_bit_cast(float, avh[set][t][w] << 16);
+            a[t][2 * w + 1] = __builtin_bit_cast(float, avh[set][t][w] & 0xffff0000u);
+          }
+        } else {
+          a[t] = ((okm[set] >> t) & 1u) ? av[set][t] * rs[set][t] : zero4;
+        }
+        if constexpr (XH) { if (!((okm[set] >> (8 + t)) & 1u)) bvh[set][t] = u32x2{0u, 0u}; }
+        else b[t] = ((okm[set] >> (8 + t)) & 1u) ? bv[set][t] : zero4;
       }
       bsum += a[t];
     }
     if constexpr (PREC == SRAD_PREC_BF16) {
       bf16x8 ah[4], bh[4];
+      if constexpr (YH) {
+        transpose_h(avh[set], ah);
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { ah[e][t] = (__bf16)a[t][e]; bh[e][t] = (__bf16)b[t][e]; }
+          for (int t = 0; t < 8; ++t) ah[e][t] = (__bf16)a[t][e];
+      }
+      if constexpr (XH) {
+        transpose_h(bvh[set], bh);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int t = 0; t < 8; ++t) bh[e][t] = (__bf16)b[t][e];
+      }
 #pragma unroll
       for (int en = 0; en < 4; ++en)
 #pragma unroll
@@ -413,6 +467,11 @@ __global__ __launch_bounds__(256, FULL ? 2 : 1) void wgrad_multi_kernel(const Wg
     if (k < mp.count && (int)blockIdx.x >= mp.blk0[k]) i = k;
   const int L = blockIdx.x - mp.blk0[i];
   if (L >= mp.nblk[i]) return;                       // padding blocks between layers
+  if constexpr (PREC == SRAD_PREC_BF16) {
+    // operand storage is per layer (the adjust conv's gradient operands stay fp32): workgroup-uniform branch
+    if (mp.p[i].x_bf16 && mp.p[i].dy_bf16) { wgrad_body<PREC, false, FULL, true, true>(mp.p[i], mp.ksplit[i], mp.tn[i], mp.tc[i], mp.part[i], L); return; }
+    if (mp.p[i].x_bf16) { wgrad_body<PREC, false, FULL, true, false>(mp.p[i], mp.ksplit[i], mp.tn[i], mp.tc[i], mp.part[i], L); return; }
+  }
   wgrad_body<PREC, false, FULL>(mp.p[i], mp.ksplit[i], mp.tn[i], mp.tc[i], mp.part[i], L);
 }
 
@@ -1268,6 +1327,9 @@ int srad_wgrad_launch_deferred(int prec, WgradQueue& q, hipStream_t stream) {
       const long rows_per = ((m.p[i].M + m.ksplit[i] - 1) / m.ksplit[i] + 127) / 128 * 128;
       full = rows_per * m.ksplit[i] == m.p[i].M && (!m.p[i].row_scale || m.p[i].rps % 32 == 0);
     }
+    for (int i = 0; i < m.count; ++i)
+      SRAD_REQUIRE(!(m.p[i].x_bf16 || m.p[i].dy_bf16) || (prec == SRAD_PREC_BF16 && (!m.p[i].dy_bf16 || m.p[i].x_bf16)),
+                   "wgrad: bf16 operand storage needs the bf16 MFMA path, dY only together with X");
     const int rc = prec != SRAD_PREC_BF16 ? launch(wgrad_multi_kernel<SRAD_PREC_F32, false>)
                    : full                 ? launch(wgrad_multi_kernel<SRAD_PREC_BF16, true>)
                                           : launch(wgrad_multi_kernel<SRAD_PREC_BF16, false>);
@@ -1293,6 +1355,7 @@ static int check_wgrad(const WgradParams& p) {
 
 int srad_launch_wgrad(int prec, const WgradParams& p, WgradQueue& q, hipStream_t stream) {
   SRAD_TRY(check_wgrad(p));
+  SRAD_REQUIRE(!p.x_bf16 && !p.dy_bf16, "wgrad: bf16 operand storage is for deferred Linear layers only");
   return prec == SRAD_PREC_BF16 ? launch_wgrad<SRAD_PREC_BF16>(p, q, stream) : launch_wgrad<SRAD_PREC_F32>(p, q, stream);
 }
 

@@ -223,10 +223,13 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
 
   // ---- phase epilogues (run when the last k-group of a 128-column group is done) ----
   auto col4_of = [&](int g) { return F_SC * g + 16 * wave + 4 * fq; };
-  auto store_bf4 = [&](__bf16* base, int ld, int rt, int c4, f32x4 v) {
+  // bf16 quad into the LDS tile and, when `gsave` is set and the quad holds real columns, into the global bf16 copy the
+  // weight gradient reads ([M][gld])
+  auto store_bf4 = [&](__bf16* base, int ld, int rt, int c4, f32x4 v, __bf16* gsave = nullptr, int gld = 0, bool real = false) {
     bf16x4 h;
     h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
     *reinterpret_cast<bf16x4*>(base + (rt * 16 + fr) * ld + c4) = h;
+    if (gsave && real) *reinterpret_cast<bf16x4*>(gsave + (size_t)(m0 + rt * 16 + fr) * gld + c4) = h;
   };
   auto epi_proj = [&](auto G, const f32x4 (&c)[NRT]) {
     constexpr int g = decltype(G)::value;
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
       for (int rt = 0; rt < NRT; ++rt) {
         const f32x4 v = in ? (x1[gg][rt] - mu[rt]) * rstd[rt] * gam + bet : f32x4{0.f, 0.f, 0.f, 0.f};
         if (p.save_xn2 && in) *reinterpret_cast<f32x4*>(p.save_xn2 + (size_t)(m0 + rt * 16 + fr) * d + c4) = v;
-        store_bf4(A1, F_LDA, rt, c4, v);
+        store_bf4(A1, F_LDA, rt, c4, v, p.save_xn2_h, d, in);
       }
     }
   };
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
         for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
       }
       if (p.save_hact && c4 < m) *reinterpret_cast<f32x4*>(p.save_hact + (size_t)(m0 + rt * 16 + fr) * m + c4) = v;
-      store_bf4(Hs, F_LDH, rt, c4, c4 < m ? v : f32x4{0.f, 0.f, 0.f, 0.f});      // m % 4 == 0
+      store_bf4(Hs, F_LDH, rt, c4, c4 < m ? v : f32x4{0.f, 0.f, 0.f, 0.f}, p.save_hact_h, m, c4 < m);      // m % 4 == 0
     }
   };
   auto epi_fc2 = [&](auto G, const f32x4 (&c)[NRT]) {
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     for (int gg = 0; gg < GD; ++gg) {
       const int c4 = col4_of(gg);
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) store_bf4(A1, F_LDA, rt, c4, c4 < d ? x1[gg][rt] : f32x4{0.f, 0.f, 0.f, 0.f});
+      for (int rt = 0; rt < NRT; ++rt) store_bf4(A1, F_LDA, rt, c4, c4 < d ? x1[gg][rt] : f32x4{0.f, 0.f, 0.f, 0.f}, p.save_x2_h, d, c4 < d);
     }
   };
   auto epi_adj = [&](int g, const f32x4 (&c)[NRT]) {

@@ -192,6 +192,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
       if (p.save_xn && h == 0 && c < d) *reinterpret_cast<f32x4*>(p.save_xn + (size_t)my_tok * d + c) = v;
       bf16x4 hh;
       hh[0] = (__bf16)v[0]; hh[1] = (__bf16)v[1]; hh[2] = (__bf16)v[2]; hh[3] = (__bf16)v[3];
+      if (p.save_xn_h && h == 0 && c < d) *reinterpret_cast<bf16x4*>(p.save_xn_h + (size_t)my_tok * d + c) = hh;
       *reinterpret_cast<bf16x4*>(XN + xrow * QA_LDX + c) = hh;
     }
   }

@@ -18,6 +18,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 int srad_set_error(int code, const char* fmt, ...);
 
@@ -185,6 +186,7 @@ struct MlpBlockParams {
   // ---- training (all optional): DropPath factors of the two residual branches and the tensors the backward needs ----
   const float *rs1, *rs2; int rps;       // per-sample factors (row m belongs to sample m / rps), null = 1
   float *save_x1, *save_xn2, *save_hpre, *save_hact, *save_x2;   // [M][d] x + attn branch, [M][d] LayerNorm2, [M][m] fc1 pre-activation, [M][m] GELU, [M][d] block output
+  __bf16 *save_xn2_h, *save_hact_h, *save_x2_h;                  // bf16 forms of the three only the weight gradients read (used instead of the fp32 ones when set)
 };
 bool srad_mlp_block_supported(int prec, int M, int d, int m, int no);
 int srad_launch_mlp_block(const MlpBlockParams& p, hipStream_t stream);
@@ -202,6 +204,7 @@ struct QkvAttnParams {
   int B, H, W, shift, d, heads;
   // ---- training (optional): what the backward needs ----
   float* save_xn;                          // [T][d] LayerNorm1(x) (written by the head-0 workgroups)
+  __bf16* save_xn_h;                       // the same as bf16 (only the weight gradient reads it: half the bytes), or null
   float* save_qkv; int hdp;                // [T][3][heads][hdp] head-padded q | k | v (q unscaled), as the QKV GEMM writes it
   unsigned long long* stamps;              // diagnostic build: [workgroup][8 waves][16] s_memtime stamps, else null
 };
@@ -224,6 +227,8 @@ struct WgradParams {
   float alpha;
   float* dW;                   // [n_real][cin_real][ntaps]
   float* db;                   // [n_real] or null
+  int x_bf16, dy_bf16;         // operand storage: 1 = the pointer is a __bf16 array (ld in elements); Linear layers on the
+                               // mask-free (FULL) bf16 path only.  A bf16 dY is already multiplied by its DropPath factor.
 };
 // Split-K bookkeeping: srad_launch_wgrad() writes partial tiles into `ws` and queues the layer; srad_wgrad_flush()
 // sums the queued layers into their dW / db with one launch (automatic when the batch or `ws` is full).
