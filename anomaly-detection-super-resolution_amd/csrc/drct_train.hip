@@ -460,18 +460,24 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
           SRAD_TRY(srad_launch_gemm(prec, p, s));
         }
       }
+      // the gradients only the weight gradients (and bf16 MFMA stagings) read go out as bf16 too: dh always when the MLP
+      // backward is fused, dx2 (pre-multiplied by its DropPath factor) when the adjust prologue computes it in that launch
+      const bool yh_dh = xh && fuse_mlp && srad_mlp_bwd_bf16_out(T), yh_dx2 = yh_dh && fuse_adj;
       {
         WgradParams g = wgrad_of(h, sw.fc2, G, dx2, d, 0, sv.hact, sw.hidden, T);
-        g.row_scale = ks2; g.rps = HW; g.x_bf16 = xh;
+        g.row_scale = ks2; g.rps = HW; g.x_bf16 = xh; g.dy_bf16 = yh_dx2;
+        if (yh_dx2) g.row_scale = nullptr;
         SRAD_TRY(srad_launch_wgrad_deferred(prec, g, wq, side));
         WgradParams g1 = wgrad_of(h, sw.fc1, G, dh, sw.hidden, 0, sv.xn2, d, T);
-        g1.x_bf16 = xh;
+        g1.x_bf16 = xh; g1.dy_bf16 = yh_dh;
         SRAD_TRY(srad_launch_wgrad_deferred(prec, g1, wq, side));
       }
       if (fuse_mlp) {   // both data gradients and the LayerNorm2 backward in one launch (kernels_fused_bwd.hip)
         MlpBwdParams mb{};
         mb.M = T; mb.d = d; mb.m = sw.hidden; mb.dx2 = dx2; mb.rs2 = ks2; mb.rps = HW;
         mb.w_fc2t = h->ts.tarena + h->ts.tf_off[sw.fc2.w]; mb.hpre = sv.hpre; mb.dh = dh;
+        if (yh_dh) mb.dh_h = reinterpret_cast<__bf16*>(dh);
+        if (yh_dx2) mb.dx2s_h = reinterpret_cast<__bf16*>(dx2);
         mb.w_fc1t = h->ts.tarena + h->ts.tf_off[sw.fc1.w]; mb.x1 = sv.x1; mb.ln_g = h->pt.fptr(sw.n2g); mb.dx1 = dx1;
         mb.dgamma = G + h->ts.flat_off[sw.n2g]; mb.dbeta = G + h->ts.flat_off[sw.n2b];
         if (fuse_adj) {   // ... and the adjust conv's data gradient (with its LeakyReLU') in front of them
@@ -500,6 +506,8 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
           SRAD_TRY(srad_launch_ln_bwd(l, wq, s));
         }
       }
+      // dqkv as bf16 when both of its readers take it that way (the fused qkv + LayerNorm1 backward and the weight gradient)
+      const bool yh_qkv = xh && fused_bwd && h->ts.tf_off[sw.qkv.w] >= 0 && srad_lin_ln_bwd_supported(prec, T, 3 * d, d);
       // ---- attention branch: x1 = x + rs1 * proj(attn(LN1(x)))                  (drct.py:477-509)
       {
         WgradParams g = wgrad_of(h, sw.proj, G, dx1, d, 0, sv.attn, d, T);
@@ -512,19 +520,20 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
         }
       }
       {
-        AttnBwdParams a{sv.qkv, w.dO, dqkv, h->pt.fptr(sw.table), G + h->ts.flat_off[sw.table], B, H, W, c.window_size,
+        AttnBwdParams a{sv.qkv, w.dO, dqkv, nullptr, h->pt.fptr(sw.table), G + h->ts.flat_off[sw.table], B, H, W, c.window_size,
                         sw.shift, d, sw.heads, hdp};
+        if (yh_qkv) a.dqkv_h = reinterpret_cast<__bf16*>(dqkv);
         SRAD_TRY(srad_launch_window_attn_bwd(prec, a, wq, s));
       }
       {
         WgradParams g = wgrad_of(h, sw.qkv, G, dqkv, 3 * d, 0, sv.xn1, d, T);
-        g.x_bf16 = xh;
+        g.x_bf16 = xh; g.dy_bf16 = yh_qkv;
         SRAD_TRY(srad_launch_wgrad_deferred(prec, g, wq, side));
       }
       if (fused_bwd && h->ts.tf_off[sw.qkv.w] >= 0 && srad_lin_ln_bwd_supported(prec, T, 3 * d, d)) {
         // gc[:, :d] += dx1 + dLN1(dqkv . Wqkv): data gradient + LayerNorm1 backward in one launch (kernels_fused_bwd.hip)
         LinLnBwdParams lb{};
-        lb.M = T; lb.K = 3 * d; lb.d = d; lb.dY = dqkv; lb.ld_dy = 3 * d; lb.w_t = h->ts.tarena + h->ts.tf_off[sw.qkv.w];
+        lb.M = T; lb.K = 3 * d; lb.d = d; lb.dY = dqkv; lb.ld_dy = 3 * d; lb.dy_bf16 = yh_qkv; lb.w_t = h->ts.tarena + h->ts.tf_off[sw.qkv.w];
         lb.x = cur; lb.ldx = D; lb.ln_g = h->pt.fptr(sw.n1g); lb.dres = dx1; lb.ld_dres = d;
         lb.out = gc; lb.ld_out = D; lb.accumulate = 1;
         lb.dgamma = G + h->ts.flat_off[sw.n1g]; lb.dbeta = G + h->ts.flat_off[sw.n1b];

@@ -1211,9 +1211,16 @@ __global__ __launch_bounds__(256) void window_attn_bwd_bf16_kernel(const AttnBwd
       for (int jt = 0; jt < 2; ++jt) {
         const int c = ch * 32 + jt * 16 + fr;
         if (c < hd) {
-          dst[c] = dq[jt][e] * scale;
-          dst[d + c] = dk[jt][e];
-          dst[2 * d + c] = dv[jt][e];
+          if (p.dqkv_h) {
+            __bf16* dh_ = p.dqkv_h + (size_t)tok[wave * 16 + fq * 4 + e] * (3 * d) + h * hd;
+            dh_[c] = (__bf16)(dq[jt][e] * scale);
+            dh_[d + c] = (__bf16)dk[jt][e];
+            dh_[2 * d + c] = (__bf16)dv[jt][e];
+          } else {
+            dst[c] = dq[jt][e] * scale;
+            dst[d + c] = dk[jt][e];
+            dst[2 * d + c] = dv[jt][e];
+          }
         }
       }
     }

@@ -12,6 +12,7 @@
 // It replaces two data-gradient GEMM launches and the LayerNorm backward launch of the unfused chain and the
 // [M][m] + [M][d] round trips between them.
 #include "srad_common.h"
+bool srad_mlp_bwd_bf16_out(int M);
 #include <type_traits>
 
 namespace {
@@ -155,7 +156,8 @@ __device__ __forceinline__ void ln_bwd_tail(f32x4 (&dxn)[GD][NRT], f32x4 (&xv)[G
 // channels: 1 for the 32-channel adjust1-4, 6 for adjust5's 180): dx2 = alpha * (dA (.) lrelu'(y)) . Wadj is computed from
 // the [FM][<=192] gradient tile, written out (fc2's weight gradient reads it) and kept on chip as this kernel's input.
 // KCD / KCM = exact 32-wide k chunks of the block dim / hidden (a stage loads and multiplies only its real chunks).
-template <int FM, int GD, int KCD, int GM, int KCM, int KCA>
+// HOUT: dh (and, with the adjust prologue, the dx2 copy times its DropPath factor) leave as bf16 for the weight gradients
+template <int FM, int GD, int KCD, int GM, int KCM, int KCA, bool HOUT = false>
 __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, float* __restrict__ part) {
   constexpr int KGD = (KCD + 7) / 8, KGM = (KCM + 7) / 8;       // 256-wide k groups
   constexpr int NRT = FM / 16;
@@ -321,7 +323,16 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
         for (int rt = 0; rt < NRT; ++rt) {
           const f32x4 v = c4 < d ? c[rt] * p.aalpha : z4;
           r2[g][rt] = v;
-          if (c4 < d) *reinterpret_cast<f32x4*>(p.dx2 + (size_t)(m0 + rt * 16 + fr) * d + c4) = v;
+          if constexpr (HOUT) {                        // bf16, times the DropPath factor: all fc2's weight gradient needs
+            if (c4 < d) {
+              const f32x4 vs = v * rs2v[rt];
+              bf16x4 hq;
+              hq[0] = (__bf16)vs[0]; hq[1] = (__bf16)vs[1]; hq[2] = (__bf16)vs[2]; hq[3] = (__bf16)vs[3];
+              *reinterpret_cast<bf16x4*>(p.dx2s_h + (size_t)(m0 + rt * 16 + fr) * d + c4) = hq;
+            }
+          } else if (c4 < d) {
+            *reinterpret_cast<f32x4*>(p.dx2 + (size_t)(m0 + rt * 16 + fr) * d + c4) = v;
+          }
           store_bf4(A1, FB_LDA, rt, c4, v);
         }
       } else if constexpr (ph == 0) {
@@ -332,7 +343,15 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = c[rt][e] * rs2v[rt] * dgelu_fast(hp[g][rt][e]);
           v = c4 < m ? v : z4;                         // m % 4 == 0
-          if (c4 < m) *reinterpret_cast<f32x4*>(p.dh + (size_t)(m0 + rt * 16 + fr) * m + c4) = v;
+          if constexpr (HOUT) {
+            if (c4 < m) {
+              bf16x4 hq;
+              hq[0] = (__bf16)v[0]; hq[1] = (__bf16)v[1]; hq[2] = (__bf16)v[2]; hq[3] = (__bf16)v[3];
+              *reinterpret_cast<bf16x4*>(p.dh_h + (size_t)(m0 + rt * 16 + fr) * m + c4) = hq;
+            }
+          } else if (c4 < m) {
+            *reinterpret_cast<f32x4*>(p.dh + (size_t)(m0 + rt * 16 + fr) * m + c4) = v;
+          }
           store_bf4(Hs, FB_LDH, rt, c4, v);
         }
       } else {
@@ -396,7 +415,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
 // dX = dY . W (K up to 4 x 256) + LayerNorm backward + residual: the qkv Linear / LayerNorm1 end of a Swin block.
 // GD = 128-column groups of d, KG = 256-wide k groups of K.
 // ------------------------------------------------------------------------------------------
-template <int FM, int GD, int KC>
+// YH: dY is stored as bf16 (compile-time: a run-time branch around the tile's loads drains the wait counts at its join)
+template <int FM, int GD, int KC, bool YH = false>
 __global__ __launch_bounds__(512) void lin_ln_bwd_kernel(const LinLnBwdParams p, float* __restrict__ part) {
   constexpr int KG = (KC + 7) / 8;                               // KC = exact 32-wide k chunks of K
   constexpr int NRT = FM / 16;
@@ -449,21 +469,28 @@ __global__ __launch_bounds__(512) void lin_ln_bwd_kernel(const LinLnBwdParams p,
     const int KQ = KG * 64;
     const int total = FM * KQ;
     for (int i0 = tid; i0 < total; i0 += 512 * 8) {
-      f32x4 v[8];
+      [[maybe_unused]] f32x4 v[8];
+      [[maybe_unused]] u32x2 vh[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int idx = min(i0 + 512 * u, total - 1), row = idx / KQ, c = (idx - row * KQ) * 4;
-        v[u] = *reinterpret_cast<const f32x4*>(p.dY + (size_t)(m0 + row) * p.ld_dy + min(c, K - 4));
+        const size_t e = (size_t)(m0 + row) * p.ld_dy + min(c, K - 4);
+        if constexpr (YH) vh[u] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(p.dY) + e);
+        else v[u] = *reinterpret_cast<const f32x4*>(p.dY + e);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int idx = i0 + 512 * u;
         if (idx < total) {
           const int row = idx / KQ, c = (idx - row * KQ) * 4;
-          const f32x4 w = c < K ? v[u] : z4;
-          bf16x4 h;
-          h[0] = (__bf16)w[0]; h[1] = (__bf16)w[1]; h[2] = (__bf16)w[2]; h[3] = (__bf16)w[3];
-          *reinterpret_cast<bf16x4*>(A1 + row * LDA + c) = h;
+          if constexpr (YH) {
+            *reinterpret_cast<u32x2*>(A1 + row * LDA + c) = c < K ? vh[u] : u32x2{0u, 0u};
+          } else {
+            const f32x4 w = c < K ? v[u] : z4;
+            bf16x4 h;
+            h[0] = (__bf16)w[0]; h[1] = (__bf16)w[1]; h[2] = (__bf16)w[2]; h[3] = (__bf16)w[3];
+            *reinterpret_cast<bf16x4*>(A1 + row * LDA + c) = h;
+          }
         }
       }
     }
@@ -511,11 +538,11 @@ template <int FM, int GD, int KC>
 int launch_lin_fm(const LinLnBwdParams& p, WgradQueue& q, hipStream_t stream) {
   constexpr int KG = (KC + 7) / 8;
   constexpr size_t lds = (size_t)FM * (KG * 256 + 8) * 2 + (384 + FM * 16) * sizeof(float);
-  auto kern = lin_ln_bwd_kernel<FM, GD, KC>;
-  static bool configured = false;
-  if (!configured) {
+  auto kern = p.dy_bf16 ? lin_ln_bwd_kernel<FM, GD, KC, true> : lin_ln_bwd_kernel<FM, GD, KC, false>;
+  static bool configured[2] = {false, false};
+  if (!configured[p.dy_bf16 ? 1 : 0]) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
+    configured[p.dy_bf16 ? 1 : 0] = true;
   }
   float* part = nullptr;
   SRAD_TRY(srad_wgrad_queue_ln_partials(q, p.dgamma, p.dbeta, p.d, p.M / FM, stream, &part));
@@ -536,11 +563,11 @@ struct BwdCfg { int gd, kcd, gm, kcm, kca; };
 inline BwdCfg bwd_cfg(int d, int m, int KA) {
   return BwdCfg{(d + FB_SC - 1) / FB_SC, srad_cp(d) / 32, (m + FB_SC - 1) / FB_SC, srad_cp(m) / 32, (KA + 31) / 32};
 }
-template <int FM, int GD, int KCD, int GM, int KCM, int KCA>
+template <int FM, int GD, int KCD, int GM, int KCM, int KCA, bool HOUT = false>
 int launch_bwd_fm(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream) {
   constexpr size_t lds = (size_t)(FM * FB_LDA + FM * FB_LDH) * 2 + (384 + FM * 16) * sizeof(float) +
                          (KCA > 0 ? (size_t)FM * (KCA * 32 + 8) * 2 : 0);
-  auto kern = mlp_bwd_kernel<FM, GD, KCD, GM, KCM, KCA>;
+  auto kern = mlp_bwd_kernel<FM, GD, KCD, GM, KCM, KCA, HOUT>;
   static bool configured = false;
   if (!configured) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -556,6 +583,10 @@ int launch_bwd_fm(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream) {
 }
 template <int GD, int KCD, int GM, int KCM, int KCA>
 int launch_bwd(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream) {
+  if (p.dh_h) {                                  // bf16 outputs for the weight gradients: the 32-row instances (srad_mlp_bwd_bf16_out)
+    SRAD_REQUIRE(srad_mlp_bwd_bf16_out(p.M) && (KCA == 0 || p.dx2s_h), "mlp_bwd: bf16 outputs need M >= 8192, M %% 32 == 0 (and the dx2 copy with the adjust prologue)");
+    return launch_bwd_fm<32, GD, KCD, GM, KCM, KCA, true>(p, q, stream);
+  }
   if (p.M >= 8192 && p.M % 32 == 0) return launch_bwd_fm<32, GD, KCD, GM, KCM, KCA>(p, q, stream);
   return launch_bwd_fm<16, GD, KCD, GM, KCM, KCA>(p, q, stream);
 }
@@ -565,6 +596,8 @@ int launch_bwd(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream) {
   X(2, 6, 3, 12, 0) X(2, 7, 4, 14, 0) X(2, 8, 4, 16, 0) X(3, 9, 3, 9, 0) X(3, 10, 3, 10, 0) \
   X(2, 6, 3, 12, 1) X(2, 7, 4, 14, 1) X(2, 8, 4, 16, 1) X(3, 9, 3, 9, 1) X(3, 10, 3, 10, 6)
 }  // namespace
+
+bool srad_mlp_bwd_bf16_out(int M) { return M >= 8192 && M % 32 == 0; }
 
 bool srad_mlp_bwd_supported(int prec, int M, int d, int m, int KA) {
   if (!(prec == SRAD_PREC_BF16 && M % 16 == 0 && d % 4 == 0 && m % 4 == 0 && d >= 32 && d <= SRAD_LNB_CP && m >= 32 && m <= 512 &&

@@ -289,7 +289,7 @@ int srad_op_layernorm_bwd(const float* dxn, const float* x, int ldx, const float
 int srad_op_window_attn_bwd(int precision, const float* qkv, const float* dout, float* dqkv, const float* table, float* dtable,
                             int B, int H, int W, int ws, int shift, int d, int heads, int hdp, void* workspace, void* stream) {
   SRAD_REQUIRE(qkv && dout && dqkv && table && dtable && workspace, "op_window_attn_bwd: null argument");
-  AttnBwdParams a{qkv, dout, dqkv, table, dtable, B, H, W, ws, shift, d, heads, hdp};
+  AttnBwdParams a{qkv, dout, dqkv, nullptr, table, dtable, B, H, W, ws, shift, d, heads, hdp};
   WgradQueue q;
   q.ws = reinterpret_cast<float*>(workspace);
   q.ws_floats = SRAD_WGRAD_WS_BYTES / sizeof(float);

@@ -295,6 +295,8 @@ struct MlpBwdParams {
   const void* w_fc2t;                   // fragments of fc2.weight^T: rows = hidden, k = d
   const float* hpre;                    // [M][m] fc1 pre-activation
   float* dh;                            // [M][m]
+  __bf16 *dh_h, *dx2s_h;                // bf16 forms for the weight gradients (used instead of dh / the dx2 copy when set):
+                                        // dh, and dx2 ALREADY multiplied by the MLP branch's DropPath factor (KA > 0 only)
   const void* w_fc1t;                   // fragments of fc1.weight^T: rows = d, k = hidden
   const float* x1;                      // [M][d] LayerNorm2 input
   const float* ln_g;
@@ -319,6 +321,7 @@ bool srad_mlp_bwd_supported(int prec, int M, int d, int m, int KA);
 struct LinLnBwdParams {
   int M, K, d;
   const float* dY; int ld_dy;           // [M][K]
+  int dy_bf16;                          // 1: dY is a __bf16 array (ld in elements)
   const void* w_t;
   const float* x; int ldx;              // LayerNorm input rows
   const float* ln_g;
@@ -329,12 +332,14 @@ struct LinLnBwdParams {
 bool srad_lin_ln_bwd_supported(int prec, int M, int K, int d);
 int srad_launch_lin_ln_bwd(const LinLnBwdParams& p, WgradQueue& q, hipStream_t stream);
 int srad_launch_mlp_bwd(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream);
+bool srad_mlp_bwd_bf16_out(int M);     // are the bf16-output instances of mlp_bwd built for this row count
 
 // Shifted-window attention backward (window size 8): recomputes P from the saved head-padded q|k|v.
 struct AttnBwdParams {
   const float* qkv;    // [T][3][heads][hdp] as written by the forward
   const float* dout;   // [T][d] gradient of the attention output (pre-proj)
   float* dqkv;         // [T][3*d] compact q | k | v gradients (plain Linear output order)
+  __bf16* dqkv_h;      // bf16 kernel: write them as bf16 instead (what both readers round them to anyway), or null
   const float* table;  // [(2ws-1)^2][heads]
   float* dtable;       // accumulated (atomicAdd)
   int B, H, W, ws, shift, d, heads, hdp;
