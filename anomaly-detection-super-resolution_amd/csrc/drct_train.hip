@@ -101,6 +101,22 @@ WgradParams wgrad_of(const srad_drct* h, const ConvW& c, float* flat_grad, const
 void geom(GemmParams& p, int H, int W) { p.Hi = p.Ho = H; p.Wi = p.Wo = W; }
 void geom(WgradParams& p, int H, int W) { p.Hi = p.Ho = H; p.Wi = p.Wo = W; }
 
+// Does this Swin block's attention backward run in its all-bf16 form (window_attn_bwd_h_kernel)?  It does when every kernel
+// around it is the fused bf16 one: the forward then saves q | k | v as bf16, mlp_bwd writes dO as bf16 per head and both
+// readers of dqkv take bf16.  Forward and backward must agree, so both ask here.
+bool attn_all_bf16(const srad_drct* h, const SwinW& sw, int H, int W, int T, int no) {
+  const srad_drct_config& c = h->cfg;
+  const int prec = h->pt.prec, d = sw.d, hd = d / sw.heads;
+  if (prec != SRAD_PREC_BF16 || getenv("SRAD_NO_FUSE") != nullptr || getenv("SRAD_ATTN_BWD_F32IO") != nullptr) return false;
+  if (!(h->fuse_mlp && srad_qkv_attn_supported(prec, c.window_size, H, W, d, sw.heads) && srad_mlp_block_supported(prec, T, d, sw.hidden, no)))
+    return false;
+  const TrainState& ts = h->ts;
+  if (ts.tf_off.empty() || ts.tf_off[sw.fc1.w] < 0 || ts.tf_off[sw.fc2.w] < 0 || ts.tf_off[sw.proj.w] < 0 || ts.tf_off[sw.qkv.w] < 0) return false;
+  return srad_mlp_bwd_supported(prec, T, d, sw.hidden, 0) && srad_mlp_bwd_bf16_out(T) && srad_lin_ln_bwd_supported(prec, T, 3 * d, d) &&
+         hd <= 32 && hd % 2 == 0 && c.window_size == 8;
+}
+int attn_hp(const SwinW& sw) { return srad_round_up(sw.d / sw.heads, 8); }
+
 int train_check(const srad_drct* h, int B, int H, int W) {
   SRAD_REQUIRE(h->ts.ready, "drct training: call srad_drct_train_bind() and srad_drct_sync_params() first");
   SRAD_REQUIRE(B > 0 && H > 0 && W > 0, "drct training: empty input");
@@ -211,6 +227,8 @@ int srad_drct_forward_train(srad_drct_t* h, const float* x, int B, int H, int W,
       const float* ks1 = keep_scale ? keep_scale + (size_t)(2 * bi) * B : nullptr;
       const float* ks2 = keep_scale ? keep_scale + (size_t)(2 * bi + 1) * B : nullptr;
       const int no = k < 4 ? c.gc : E;
+      if (h->qkv_saved_h.size() != h->blocks.size()) h->qkv_saved_h.assign(h->blocks.size(), 0);
+      h->qkv_saved_h[bi] = 0;
       if (h->fuse_mlp && srad_qkv_attn_supported(prec, c.window_size, H, W, d, sw.heads) &&
           srad_mlp_block_supported(prec, T, d, sw.hidden, no)) {
         // bf16: the two fused launches of the inference path, which also leave what the backward needs
@@ -221,7 +239,10 @@ int srad_drct_forward_train(srad_drct_t* h, const float* x, int B, int H, int W,
         a.out = sv.attn; a.ld_out = d; a.B = B; a.H = H; a.W = W; a.shift = sw.shift; a.d = d; a.heads = sw.heads;
         // the tensors only the weight gradients read (LN1(x), LN2(.), GELU(.), the block output) are left as bf16, which is
         // what the MFMA would round them to anyway: half the bytes written here and read (3 - 9 times each) by wgrad
-        a.save_xn_h = reinterpret_cast<__bf16*>(sv.xn1); a.save_qkv = sv.qkv; a.hdp = hdp;
+        a.save_xn_h = reinterpret_cast<__bf16*>(sv.xn1); a.hdp = hdp;
+        h->qkv_saved_h[bi] = attn_all_bf16(h, sw, H, W, T, no);
+        if (h->qkv_saved_h[bi]) { a.save_qkv_h = reinterpret_cast<__bf16*>(sv.qkv); a.hp_h = attn_hp(sw); }   // as the MFMA took them
+        else a.save_qkv = sv.qkv;
         SRAD_TRY(srad_launch_qkv_attn(a, s));
         MlpBlockParams q{};
         q.attn = sv.attn; q.ld_attn = d; q.shortcut = cur; q.ld_short = D;
@@ -462,7 +483,12 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       }
       // the gradients only the weight gradients (and bf16 MFMA stagings) read go out as bf16 too: dh always when the MLP
       // backward is fused, dx2 (pre-multiplied by its DropPath factor) when the adjust prologue computes it in that launch
-      const bool yh_dh = xh && fuse_mlp && srad_mlp_bwd_bf16_out(T), yh_dx2 = yh_dh && fuse_adj;
+      const bool attn_h = attn_all_bf16(h, sw, H, W, T, KA);      // then fuse_proj, yh_dh and yh_qkv (below) all hold
+      if (attn_h != (bi < (int)h->qkv_saved_h.size() && h->qkv_saved_h[bi] != 0))
+        return srad_set_error(SRAD_ERR_STATE, "drct_backward: the forward saved q | k | v of block %d as %s but this backward reads %s "
+                              "(SRAD_NO_FUSE / SRAD_ATTN_BWD_F32IO must not change between the two)", bi, attn_h ? "fp32" : "bf16", attn_h ? "bf16" : "fp32");
+      // (the bf16-output mlp_bwd writes dO as bf16 too, which only the all-bf16 attention backward reads)
+      const bool yh_dh = xh && fuse_mlp && srad_mlp_bwd_bf16_out(T) && (attn_h || !fuse_proj), yh_dx2 = yh_dh && fuse_adj;
       {
         WgradParams g = wgrad_of(h, sw.fc2, G, dx2, d, 0, sv.hact, sw.hidden, T);
         g.row_scale = ks2; g.rps = HW; g.x_bf16 = xh; g.dy_bf16 = yh_dx2;
@@ -486,6 +512,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
           else { mb.dA = gn; mb.ld_dA = D; }
         }
         if (fuse_proj) { mb.w_projt = h->ts.tarena + h->ts.tf_off[sw.proj.w]; mb.rs1 = ks1; mb.rps = HW; mb.dO = w.dO; }
+        if (fuse_proj && yh_dh) { mb.dO_h = reinterpret_cast<__bf16*>(w.dO); mb.dO_heads = sw.heads; mb.dO_hp = attn_hp(sw); }
         SRAD_TRY(srad_launch_mlp_bwd(mb, wq, s));
       } else {
         {
@@ -523,6 +550,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
         AttnBwdParams a{sv.qkv, w.dO, dqkv, nullptr, h->pt.fptr(sw.table), G + h->ts.flat_off[sw.table], B, H, W, c.window_size,
                         sw.shift, d, sw.heads, hdp};
         if (yh_qkv) a.dqkv_h = reinterpret_cast<__bf16*>(dqkv);
+        if (attn_h) { a.qkv_h = reinterpret_cast<const __bf16*>(sv.qkv); a.dout_h = reinterpret_cast<const __bf16*>(w.dO); a.hp_h = attn_hp(sw); }
         SRAD_TRY(srad_launch_window_attn_bwd(prec, a, wq, s));
       }
       {

@@ -1227,6 +1227,212 @@ __global__ __launch_bounds__(256) void window_attn_bwd_bf16_kernel(const AttnBwd
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// All-bf16 form of the same backward for head dims <= 32 (DRCT-L: 30), the training step's case: q (already scaled and
+// rounded, exactly the operand the forward's MFMA took) | k | v and dO arrive as bf16 in per-head slots of hp columns, so a
+// thread stages its share with four 16-byte loads issued before anything else (it derives its row's token itself), and
+// dq | dk | dv leave as bf16.  There is one 32-column chunk, so the second operands of the three pass-B products are
+// fetched (transposing LDS reads) right after pass A and the staging tiles are dead from then on: the fp32 dS copy the
+// bias-table gradient sums is laid over them.  That brings the workgroup to 48.5 KB of LDS - three per CU, which for the
+// 768 (window, head) pairs of the 8-image training batch is ONE resident round on 256 CUs instead of one and a half.
+// ------------------------------------------------------------------------------------------
+constexpr size_t AG_LDS = (size_t)(4 * 64 * AH_HS + 3 * 64 * AH_PS) * sizeof(__bf16) + 256 * sizeof(float) + 2 * 64 * sizeof(int);
+static_assert((size_t)64 * 68 * sizeof(float) <= (size_t)4 * 64 * AH_HS * sizeof(__bf16), "the fp32 dS copy must fit in the staging tiles");
+
+__global__ __launch_bounds__(256) void window_attn_bwd_h_kernel(const AttnBwdParams p, float* __restrict__ tpart) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* Qs = reinterpret_cast<__bf16*>(smem);          // [64][AH_HS] q * scale
+  __bf16* Ks = Qs + 64 * AH_HS;
+  __bf16* Vs = Ks + 64 * AH_HS;
+  __bf16* Gs = Vs + 64 * AH_HS;                          // dO
+  float* Df = reinterpret_cast<float*>(smem);            // [64][68] fp32 dS, over Qs .. Gs once pass A is done with them
+  __bf16* Dm = Gs + 64 * AH_HS;                          // [query][key] dS
+  __bf16* DmT = Dm + 64 * AH_PS;                         // [key][query] dS
+  __bf16* PmT = DmT + 64 * AH_PS;                        // [key][query] P
+  float* tbl = reinterpret_cast<float*>(PmT + 64 * AH_PS);   // [225] (256 reserved)
+  int* tok = reinterpret_cast<int*>(tbl + 256);
+  int* inf = tok + 64;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int ws = 8, d = p.d, heads = p.heads, hd = d / heads, hp = p.hp_h;
+  const int nWx = p.W / ws, nW = (p.H / ws) * nWx;
+  int win, h;                                            // all heads of a window on one XCD (see the kernel above)
+  {
+    const int L = blockIdx.x, nwin = p.B * nW;
+    if ((nwin & 7) == 0) { const int slot = L >> 3; win = (slot / heads) * 8 + (L & 7); h = slot - (slot / heads) * heads; }
+    else { win = L / heads; h = L - win * heads; }
+  }
+  const int b = win / nW, widx = win - b * nW;
+  const int wy = widx / nWx, wx = widx - wy * nWx;
+  const float scale = rsqrtf((float)hd);
+  const int tw = 2 * ws - 1;
+
+  auto geometry = [&](int row, int& token, int& info) {
+    const int py = row >> 3, px = row & 7;
+    const int r = wy * ws + py, c = wx * ws + px;
+    int orr = r + p.shift; if (orr >= p.H) orr -= p.H;
+    int occ = c + p.shift; if (occ >= p.W) occ -= p.W;
+    token = (b * p.H + orr) * p.W + occ;
+    const int rh = r < p.H - ws ? 0 : (r < p.H - p.shift ? 1 : 2);
+    const int rw = c < p.W - ws ? 0 : (c < p.W - p.shift ? 1 : 2);
+    info = ((rh * 3 + rw) << 16) | (py << 8) | px;
+  };
+
+  // ---- staging: thread = (row tid / 4, 8 columns), everything in flight before the first LDS store ----
+  {
+    const int srow = tid >> 2, scl = (tid & 3) * 8;
+    int stok, sinf;
+    geometry(srow, stok, sinf);
+    const int off = min(scl, hp - 8);
+    const __bf16* qb = p.qkv_h + (size_t)stok * (3 * heads * hp) + h * hp + off;
+    const u32x4 q4 = *reinterpret_cast<const u32x4*>(qb);
+    const u32x4 k4 = *reinterpret_cast<const u32x4*>(qb + heads * hp);
+    const u32x4 v4 = *reinterpret_cast<const u32x4*>(qb + 2 * heads * hp);
+    const u32x4 g4 = *reinterpret_cast<const u32x4*>(p.dout_h + (size_t)stok * (heads * hp) + h * hp + off);
+    const float tv = p.table[(size_t)min(tid, tw * tw - 1) * heads + h];
+    if ((tid & 3) == 0) { tok[srow] = stok; inf[srow] = sinf; }
+    tbl[tid] = tv;
+    auto put = [&](__bf16* tile, const u32x4& raw) {       // columns at or beyond the head dim are zero in LDS
+      bf16x8 v = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = scl + e < hd ? v[e] : (__bf16)0.f;
+      *reinterpret_cast<bf16x8*>(tile + srow * AH_HS + scl) = v;
+    };
+    put(Qs, q4); put(Ks, k4); put(Vs, v4); put(Gs, g4);
+  }
+  __syncthreads();
+
+  // ---- pass A: S = q k^T, dP = dO v^T (row = 16 wave + 4 fq + e, key = 16 j + fr) ----
+  f32x4 s[4], dp[4];
+  {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(Qs + (wave * 16 + fr) * AH_HS + 8 * fq);
+    const bf16x8 g = *reinterpret_cast<const bf16x8*>(Gs + (wave * 16 + fr) * AH_HS + 8 * fq);
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16x8 kb = *reinterpret_cast<const bf16x8*>(Ks + (j * 16 + fr) * AH_HS + 8 * fq);
+      const bf16x8 vb = *reinterpret_cast<const bf16x8*>(Vs + (j * 16 + fr) * AH_HS + 8 * fq);
+      s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, kb, z4, 0, 0, 0);
+      dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g, vb, z4, 0, 0, 0);
+    }
+  }
+  // second operands of pass B: B[k = token kk + 8 fq + t][j = column 16 jt + fr] of the row-major tiles
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  bf16x8 bK[2][2], bQ[2][2], bG[2][2];
+  {
+    const int tq = fr >> 2, tp = fr & 3;
+    auto tr8 = [&](const __bf16* tile, int kk, int jt) -> bf16x8 {
+      const __bf16* r0 = tile + (kk + 8 * fq + tq) * AH_HS + jt * 16 + 4 * tp;
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0 + 4 * AH_HS));
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
+      return o;
+    };
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) { bK[k2][jt] = tr8(Ks, 32 * k2, jt); bQ[k2][jt] = tr8(Qs, 32 * k2, jt); bG[k2][jt] = tr8(Gs, 32 * k2, jt); }
+  }
+
+  // ---- softmax and dS in registers (their LDS reads are tbl / inf only) ----
+  f32x4 pr[4], dsr[4];
+  {
+    int kinf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kinf[j] = inf[j * 16 + fr];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = wave * 16 + fq * 4 + e;
+      const int qi = inf[row];
+      const int qy = (qi >> 8) & 0xff, qx = qi & 0xff, qr = qi >> 16;
+      float mx = -1e30f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kyy = (kinf[j] >> 8) & 0xff, kxx = kinf[j] & 0xff, kr = kinf[j] >> 16;
+        float v = s[j][e] + tbl[(qy - kyy + ws - 1) * tw + (qx - kxx + ws - 1)];
+        if (p.shift > 0 && qr != kr) v += -100.0f;
+        s[j][e] = v;
+        mx = fmaxf(mx, v);
+      }
+      mx = srad_row16_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s[j][e] = __expf(s[j][e] - mx); sum += s[j][e]; }
+      sum = srad_row16_sum(sum);
+      const float inv = 1.0f / sum;
+      float dl = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s[j][e] *= inv; dl += s[j][e] * dp[j][e]; }
+      dl = srad_row16_sum(dl);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { pr[j][e] = s[j][e]; dsr[j][e] = s[j][e] * (dp[j][e] - dl); }
+    }
+  }
+  __syncthreads();                                       // every wave has read the staging tiles: Df may overwrite them
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int row = wave * 16 + fq * 4 + e;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      Dm[row * AH_PS + j * 16 + fr] = (__bf16)dsr[j][e];
+      Df[row * 68 + j * 16 + fr] = dsr[j][e];
+    }
+  }
+  // transposed tiles: this lane's four rows 4 fq .. 4 fq + 3 of query slab `wave` are consecutive along k
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    bf16x4 ph, dh;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ph[e] = (__bf16)pr[j][e]; dh[e] = (__bf16)dsr[j][e]; }
+    *reinterpret_cast<bf16x4*>(PmT + (j * 16 + fr) * AH_PS + wave * 16 + 4 * fq) = ph;
+    *reinterpret_cast<bf16x4*>(DmT + (j * 16 + fr) * AH_PS + wave * 16 + 4 * fq) = dh;
+  }
+  __syncthreads();
+
+  // ---- pass B: dq = dS k, dk = dS^T q, dv = P^T dO ----
+  {
+    f32x4 dq[2], dk[2], dv[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) { dq[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[jt] = dq[jt]; dv[jt] = dq[jt]; }
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+      const bf16x8 a_ds = *reinterpret_cast<const bf16x8*>(Dm + (wave * 16 + fr) * AH_PS + 32 * k2 + 8 * fq);
+      const bf16x8 a_dst = *reinterpret_cast<const bf16x8*>(DmT + (wave * 16 + fr) * AH_PS + 32 * k2 + 8 * fq);
+      const bf16x8 a_pt = *reinterpret_cast<const bf16x8*>(PmT + (wave * 16 + fr) * AH_PS + 32 * k2 + 8 * fq);
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        dq[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_ds, bK[k2][jt], dq[jt], 0, 0, 0);
+        dk[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_dst, bQ[k2][jt], dk[jt], 0, 0, 0);
+        dv[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_pt, bG[k2][jt], dv[jt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      __bf16* dst = p.dqkv_h + (size_t)tok[wave * 16 + fq * 4 + e] * (3 * d) + h * hd;
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        const int c = jt * 16 + fr;
+        if (c < hd) {
+          dst[c] = (__bf16)(dq[jt][e] * scale);
+          dst[d + c] = (__bf16)dk[jt][e];
+          dst[2 * d + c] = (__bf16)dv[jt][e];
+        }
+      }
+    }
+  }
+  if (tid < tw * tw) {                                   // bias-table gradient row of this (window, head), fp32
+    const int dy = tid / tw - (ws - 1), dx = tid - (tid / tw) * tw - (ws - 1);
+    float acc = 0.f;
+    for (int qy = max(0, dy); qy < min(ws, ws + dy); ++qy)
+      for (int qx = max(0, dx); qx < min(ws, ws + dx); ++qx)
+        acc += Df[(qy * ws + qx) * 68 + (qy - dy) * ws + (qx - dx)];
+    tpart[(size_t)win * (tw * tw * heads) + (size_t)tid * heads + h] = acc;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ elementwise
 __global__ void dact_kernel(const float* __restrict__ dy, int ld_dy, const float* __restrict__ y, int ld_y,
                             float* __restrict__ out, int ld_out, int rows, int C, float slope) {
@@ -1431,7 +1637,19 @@ int srad_launch_window_attn_bwd(int prec, const AttnBwdParams& p, WgradQueue& q,
   q.used += need;
   SRAD_TRY(queue_colsum(q, p.dtable, tpart, ncols, ncols, nwin, 1.f, stream));
   SradProfScope prof(stream, SRAD_K_ATTN_BWD, 10.0 * T * 64 * p.d, 4.0 * T * 8 * p.d);
-  if (prec == SRAD_PREC_BF16) {
+  if (prec == SRAD_PREC_BF16 && p.qkv_h) {
+    const int hd = p.d / p.heads;
+    SRAD_REQUIRE(p.dout_h && p.dqkv_h && hd <= 32 && p.hp_h % 8 == 0 && p.hp_h >= hd && p.hp_h <= 32 &&
+                     (((uintptr_t)p.qkv_h | (uintptr_t)p.dout_h) & 15) == 0,
+                 "window_attn_bwd: the all-bf16 form takes head dims <= 32 in 16-byte aligned slots of hp columns, and writes bf16");
+    static bool configured_h = false;
+    if (!configured_h) {
+      SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_h_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)AG_LDS));
+      configured_h = true;
+    }
+    hipLaunchKernelGGL(window_attn_bwd_h_kernel, dim3(p.B * nW * p.heads), dim3(256), AG_LDS, stream, p, tpart);
+  } else if (prec == SRAD_PREC_BF16) {
     static bool configured16 = false;
     if (!configured16) {
       SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_bf16_kernel),

@@ -242,6 +242,8 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) hh[e] = (__bf16)(c + e < hd ? v[e] : 0.f);
           *reinterpret_cast<bf16x4*>(QKV + (which * 64 + t * 16 + fr) * HS + c) = hh;
+          if (p.save_qkv_h && c < p.hp_h)
+            *reinterpret_cast<bf16x4*>(p.save_qkv_h + (size_t)tok[t * 16 + fr] * (3 * heads * p.hp_h) + (which * heads + h) * p.hp_h + c) = hh;
         }
       }
     }

@@ -253,7 +253,53 @@ int srad_op_wgrad(int precision, const float* dy, int ldy, const float* x, int l
   return srad_wgrad_flush(q, reinterpret_cast<hipStream_t>(stream));
 }
 
+// A Linear layer's weight gradient the way the training step issues it: queued, sent with the (one-layer) deferred launch,
+// reduced.  x_bf16 / dy_bf16: the operand pointer is a bf16 array (ld in elements).
+int srad_op_wgrad_deferred(int precision, const void* dy, int ldy, int dy_bf16, const void* x, int ldx, int x_bf16, int M, int N,
+                           int Cin, const float* row_scale, int rps, float alpha, float* dw, float* db, void* workspace,
+                           void* stream) {
+  SRAD_REQUIRE(dy && x && dw && workspace, "op_wgrad_deferred: null argument");
+  WgradParams p{};
+  p.dY = reinterpret_cast<const float*>(dy); p.ldy = ldy; p.X = reinterpret_cast<const float*>(x); p.ldx = ldx; p.M = M;
+  p.N = N; p.Cin = Cin; p.n_real = N; p.cin_real = Cin; p.ntaps = 1; p.stride = 1;
+  p.row_scale = row_scale; p.rps = rps; p.alpha = alpha; p.dW = dw; p.db = db; p.x_bf16 = x_bf16; p.dy_bf16 = dy_bf16;
+  WgradQueue q;
+  q.ws = reinterpret_cast<float*>(workspace);
+  q.ws_floats = SRAD_WGRAD_WS_BYTES / sizeof(float);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  SRAD_TRY(srad_launch_wgrad_deferred(precision, p, q, s));
+  SRAD_TRY(srad_wgrad_launch_deferred(precision, q, s));
+  return srad_wgrad_flush(q, s);
+}
+
 size_t srad_op_wgrad_workspace_bytes(void) { return SRAD_WGRAD_WS_BYTES; }
+
+// tools/wgrad_bench.py: the five weight gradients of one Swin block (qkv, proj, fc1, fc2, adjust) exactly as the training
+// step issues them - deferred into one launch, then the reduce - `iters` times.  storage bit 0: X operands are bf16,
+// bit 1: dY operands are bf16.  All layers read the same two operand buffers (the timing does not care).
+int srad_bench_wgrad_block(int M, int d, int hidden, int KA, int storage, const void* xbuf, const void* ybuf, float* dw,
+                           void* workspace, int iters, void* stream) {
+  SRAD_REQUIRE(xbuf && ybuf && dw && workspace && M > 0 && iters > 0, "bench_wgrad_block: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int N[5] = {3 * d, d, hidden, d, KA}, C[5] = {d, d, d, hidden, d};
+  WgradQueue q;
+  q.ws = reinterpret_cast<float*>(workspace);
+  q.ws_floats = SRAD_WGRAD_WS_BYTES / sizeof(float);
+  for (int it = 0; it < iters; ++it) {
+    float* w = dw;
+    for (int l = 0; l < 5; ++l) {
+      WgradParams p{};
+      p.dY = reinterpret_cast<const float*>(ybuf); p.ldy = N[l]; p.X = reinterpret_cast<const float*>(xbuf); p.ldx = C[l];
+      p.M = M; p.N = N[l]; p.Cin = C[l]; p.n_real = N[l]; p.cin_real = C[l]; p.ntaps = 1; p.stride = 1; p.alpha = 1.f;
+      p.dW = w; p.x_bf16 = storage & 1; p.dy_bf16 = (storage >> 1) & 1;
+      w += (size_t)N[l] * C[l];
+      SRAD_TRY(srad_launch_wgrad_deferred(SRAD_PREC_BF16, p, q, s));
+    }
+    SRAD_TRY(srad_wgrad_launch_deferred(SRAD_PREC_BF16, q, s));
+    SRAD_TRY(srad_wgrad_flush(q, s));
+  }
+  return SRAD_OK;
+}
 
 int srad_op_dgrad(int precision, const float* dy, int ldy, int B, int H, int W, int N, const float* w, int Cin,
                   int ntaps, const float* r, int ldr, int rmode, float slope, float alpha, const float* row_scale,
@@ -294,6 +340,21 @@ int srad_op_window_attn_bwd(int precision, const float* qkv, const float* dout, 
   q.ws = reinterpret_cast<float*>(workspace);
   q.ws_floats = SRAD_WGRAD_WS_BYTES / sizeof(float);
   SRAD_TRY(srad_launch_window_attn_bwd(precision, a, q, reinterpret_cast<hipStream_t>(stream)));
+  return srad_wgrad_flush(q, reinterpret_cast<hipStream_t>(stream));
+}
+
+// The all-bf16 form (head dim <= 32): qkv_h [T][3][heads][hp] with q already scaled, dout_h [T][heads][hp] (padding columns
+// are ignored), dqkv_h [T][3 d] - all bf16; table / dtable fp32.
+int srad_op_window_attn_bwd_h(const void* qkv_h, const void* dout_h, void* dqkv_h, const float* table, float* dtable,
+                              int B, int H, int W, int ws, int shift, int d, int heads, int hp, void* workspace, void* stream) {
+  SRAD_REQUIRE(qkv_h && dout_h && dqkv_h && table && dtable && workspace, "op_window_attn_bwd_h: null argument");
+  AttnBwdParams a{nullptr, nullptr, nullptr, reinterpret_cast<__bf16*>(dqkv_h), table, dtable, B, H, W, ws, shift, d, heads,
+                  srad_round_up(d / (heads > 0 ? heads : 1), 4)};
+  a.qkv_h = reinterpret_cast<const __bf16*>(qkv_h); a.dout_h = reinterpret_cast<const __bf16*>(dout_h); a.hp_h = hp;
+  WgradQueue q;
+  q.ws = reinterpret_cast<float*>(workspace);
+  q.ws_floats = SRAD_WGRAD_WS_BYTES / sizeof(float);
+  SRAD_TRY(srad_launch_window_attn_bwd(SRAD_PREC_BF16, a, q, reinterpret_cast<hipStream_t>(stream)));
   return srad_wgrad_flush(q, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -16,6 +16,7 @@ enum { SRAD_ACT_NONE = 0, SRAD_ACT_GELU = 1, SRAD_ACT_LRELU = 2, SRAD_ACT_RELU =
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
@@ -206,6 +207,7 @@ struct QkvAttnParams {
   float* save_xn;                          // [T][d] LayerNorm1(x) (written by the head-0 workgroups)
   __bf16* save_xn_h;                       // the same as bf16 (only the weight gradient reads it: half the bytes), or null
   float* save_qkv; int hdp;                // [T][3][heads][hdp] head-padded q | k | v (q unscaled), as the QKV GEMM writes it
+  __bf16* save_qkv_h; int hp_h;            // or [T][3][heads][hp_h] bf16 exactly as the attention used them (q scaled, padding 0), hp_h % 8 == 0
   unsigned long long* stamps;              // diagnostic build: [workgroup][8 waves][16] s_memtime stamps, else null
 };
 bool srad_qkv_attn_supported(int prec, int ws, int H, int W, int d, int heads);
@@ -313,6 +315,7 @@ struct MlpBwdParams {
   const void* w_projt;                  // fragments of proj.weight^T: rows = d, k = d
   const float* rs1;                     // DropPath factor of the attention branch per sample (null = 1; rows per sample = rps)
   float* dO;                            // [M][d]
+  __bf16* dO_h = nullptr; int dO_heads = 0, dO_hp = 0;   // bf16-output instances: dO as [M][heads][hp] bf16 instead (column c -> head c / (d / heads))
 };
 bool srad_mlp_bwd_supported(int prec, int M, int d, int m, int KA);
 // dX = dY . W followed by the backward of the LayerNorm that produced the Linear's input, one launch (bf16 mode):
@@ -343,6 +346,9 @@ struct AttnBwdParams {
   const float* table;  // [(2ws-1)^2][heads]
   float* dtable;       // accumulated (atomicAdd)
   int B, H, W, ws, shift, d, heads, hdp;
+  // all-bf16 form (window_attn_bwd_h_kernel; head dim <= 32): q (scaled) | k | v as the fused forward saved them,
+  // [T][3][heads][hp_h], and dO as [T][heads][hp_h] (padding columns may hold anything); needs dqkv_h
+  const __bf16* qkv_h = nullptr; const __bf16* dout_h = nullptr; int hp_h = 0;
 };
 int srad_launch_window_attn_bwd(int prec, const AttnBwdParams& p, WgradQueue& q, hipStream_t stream);   // dtable via the queue
 

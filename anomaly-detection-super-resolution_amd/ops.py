@@ -176,6 +176,46 @@ def window_attention_bwd(qkv: torch.Tensor, dout: torch.Tensor, table: torch.Ten
     return dqkv, dtable
 
 
+def wgrad_linear_deferred(dy: torch.Tensor, x: torch.Tensor, row_scale: Optional[torch.Tensor] = None, rps: int = 0,
+                          alpha: float = 1.0, bias: bool = True, precision: str = "bf16"):
+    """dW [N, Cin] (and db [N]) of a Linear layer from dy [M, N] and x [M, Cin], issued the way the training step does
+    (deferred launch + reduce).  fp32 or bf16 operand tensors (bf16 dy: already scaled, needs a bf16 x)."""
+    _need_cuda(dy, x)
+    M, N = dy.shape
+    Cin = x.shape[1]
+    dw = torch.zeros(N, Cin, dtype=torch.float32, device=dy.device)
+    db = torch.zeros(N, dtype=torch.float32, device=dy.device) if bias else None
+    dy, x = dy.contiguous(), x.contiguous()
+    L.check(L.lib().srad_op_wgrad_deferred(L.PRECISIONS[precision], L.dptr(dy), N, int(dy.dtype == torch.bfloat16), L.dptr(x), Cin,
+                                           int(x.dtype == torch.bfloat16), M, N, Cin, L.dptr(row_scale), rps, alpha, L.dptr(dw), L.dptr(db),
+                                           wgrad_workspace(dy.device), L.current_stream_ptr()), "op_wgrad_deferred")
+    return dw, db
+
+
+def window_attention_bwd_bf16io(qkv: torch.Tensor, dout: torch.Tensor, table: torch.Tensor, B: int, H: int, W: int, ws: int,
+                                shift: int, heads: int, pad_fill: float = float("nan")):
+    """The training step's form of ``window_attention_bwd`` (head dim <= 32): the operands cross the boundary as bf16 in
+    per-head slots of ``hp = ceil8(head dim)`` columns - q already scaled, as the fused forward saves it - and dq | dk | dv
+    come back as bf16.  ``pad_fill`` goes into dO's padding columns, which the kernel must ignore."""
+    _need_cuda(qkv, dout, table)
+    d = qkv.shape[1] // 3
+    hd = d // heads
+    hp = (hd + 7) // 8 * 8
+    T = qkv.shape[0]
+    q3 = qkv.reshape(T, 3, heads, hd).float().clone()
+    q3[:, 0] *= hd ** -0.5
+    qkv_h = torch.zeros(T, 3, heads, hp, dtype=torch.bfloat16, device=qkv.device)
+    qkv_h[..., :hd] = q3.to(torch.bfloat16)
+    dout_h = torch.full((T, heads, hp), pad_fill, dtype=torch.bfloat16, device=qkv.device)
+    dout_h[..., :hd] = dout.reshape(T, heads, hd).to(torch.bfloat16)
+    dqkv_h = torch.empty(T, 3 * d, dtype=torch.bfloat16, device=qkv.device)
+    dtable = torch.zeros_like(table, dtype=torch.float32).contiguous()
+    L.check(L.lib().srad_op_window_attn_bwd_h(L.dptr(qkv_h), L.dptr(dout_h), L.dptr(dqkv_h), L.dptr(table.contiguous()), L.dptr(dtable),
+                                              B, H, W, ws, shift, d, heads, hp, wgrad_workspace(qkv.device), L.current_stream_ptr()),
+            "op_window_attn_bwd_h")
+    return dqkv_h.float(), dtable
+
+
 def _scratch(nbytes: int, device) -> Tuple[torch.Tensor, C.c_void_p, C.c_size_t]:
     t = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
     off = (-t.data_ptr()) % 256

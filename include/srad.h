@@ -255,6 +255,12 @@ int srad_op_mlp_block(int M, int d, int m, int no, int fm, const float* attn, co
 int srad_op_wgrad(int precision, const float* dy, int ldy, const float* x, int ldx, int B, int Hi, int Wi, int N,
                   int Cin, int ntaps, int stride, const float* row_scale, float alpha, float* dw, float* db,
                   void* workspace, void* stream);
+/* The same for a Linear layer, issued as the training step issues it (queued, one deferred launch, reduce).  x_bf16 /
+ * dy_bf16 = 1: that operand is a bf16 array (ld in elements; a bf16 dY is taken as already multiplied by its per-sample
+ * factor, so row_scale must be null with it, and it needs a bf16 X).  precision SRAD_PREC_BF16 for bf16 operands. */
+int srad_op_wgrad_deferred(int precision, const void* dy, int ldy, int dy_bf16, const void* x, int ldx, int x_bf16, int M, int N,
+                           int Cin, const float* row_scale, int rps, float alpha, float* dw, float* db, void* workspace,
+                           void* stream);
 /* split-K workspace of srad_op_wgrad (256-byte aligned scratch, contents irrelevant, reusable by later calls on the
  * same stream) */
 size_t srad_op_wgrad_workspace_bytes(void);
@@ -271,6 +277,11 @@ int srad_op_layernorm_bwd(const float* dxn, const float* x, int ldx, const float
 int srad_op_window_attn_bwd(int precision, const float* qkv, const float* dout, float* dqkv, const float* table,
                             float* dtable, int B, int H, int W, int ws, int shift, int d, int heads, int hdp,
                             void* workspace, void* stream);
+/* The all-bf16 form of the same backward, for head dims <= 32 (what the DRCT training step runs): qkv_h [T][3][heads][hp]
+ * bf16 with q ALREADY multiplied by head_dim^-0.5 (the forward's MFMA operand), dout_h [T][heads][hp] bf16 (columns at
+ * or beyond the head dim are ignored), dqkv_h [T][3 d] bf16 out; hp % 8 == 0; table / dtable fp32. */
+int srad_op_window_attn_bwd_h(const void* qkv_h, const void* dout_h, void* dqkv_h, const float* table, float* dtable,
+                              int B, int H, int W, int ws, int shift, int d, int heads, int hp, void* workspace, void* stream);
 /* Fused backward of the MLP branch of a Swin block (bf16 MFMA; src/drct.py:510, 184-190, 389-396, 300):
  *   [KA > 0] dx2 = aalpha * (dA (.) lrelu'(y_act)) . w_adj          (written; dA (.) lrelu' -> dA_out if given)
  *   dh  = (dx2 . w_fc2) * rs2 * gelu'(hpre);  dx1 = dx2 + LayerNorm'(dh . w_fc1; x1, gamma);  dgamma / dbeta accumulated
@@ -308,6 +319,10 @@ int srad_bench_window_attn(int precision, const float* qkv, float* out, const fl
                            int shift, int d, int heads, int hdp, int iters, float* us_out, void* stream);
 int srad_bench_qkv_attn(const float* x, int ldx, int B, int H, int W, int shift, int d, int heads, const float* w_fp32,
                         float* out, void* scratch, size_t scratch_bytes, int iters, float* us_out, void* stream);
+/* tools/wgrad_bench.py: one Swin block's five weight gradients as the training step issues them (one deferred launch +
+ * the reduce), `iters` times; storage bit 0 / 1: the X / dY operands are bf16. */
+int srad_bench_wgrad_block(int M, int d, int hidden, int KA, int storage, const void* xbuf, const void* ybuf, float* dw,
+                           void* workspace, int iters, void* stream);
 
 #ifdef __cplusplus
 }

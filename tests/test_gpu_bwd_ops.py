@@ -49,6 +49,37 @@ def test_wgrad_linear(dev, prec, M, K, N):
         assert _rel(db2, (dy * sc).sum(0)) < TOL[prec]
 
 
+@pytest.mark.parametrize("storage", ["f32", "xh", "xh_yh"])
+@pytest.mark.parametrize("M,N,K", [(2048, 540, 180), (1024, 180, 360), (2048, 32, 180), (1024, 360, 244), (3072, 128, 64), (1536, 180, 180)])
+def test_wgrad_linear_deferred(dev, storage, M, N, K):
+    """The training step's route (queue -> one deferred launch -> reduce), with the operands as fp32, X as bf16, or both as
+    bf16 with dY pre-multiplied by its per-sample factor; whole 128-row steps (mask-free path) and not (M = 1536 ... )."""
+    from srad_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = torch.randn(M, N, generator=g).to(dev)
+    x = torch.randn(M, K, generator=g).to(dev)
+    rps = 256
+    rs = (torch.floor(0.7 + torch.rand(M // rps, generator=g)) / 0.7).to(dev)
+    dys = dy * rs.repeat_interleave(rps).unsqueeze(1)
+    dw_ref = dys.double().t() @ x.double()
+    db_ref = dys.double().sum(0)
+    if storage == "f32":
+        dw, db = ops.wgrad_linear_deferred(dy, x, row_scale=rs, rps=rps, alpha=0.5)
+    elif storage == "xh":
+        dw, db = ops.wgrad_linear_deferred(dy, x.to(torch.bfloat16), row_scale=rs, rps=rps, alpha=0.5)
+    else:
+        dw, db = ops.wgrad_linear_deferred(dys.to(torch.bfloat16), x.to(torch.bfloat16), alpha=0.5)
+    # operands rounded to bf16 (relative 2^-9 each), fp32 accumulation over M rows
+    assert _rel(dw, 0.5 * dw_ref.float()) < 6e-3
+    assert _rel(db, 0.5 * db_ref.float()) < 6e-3
+    # accumulation: a second pass adds onto the first
+    if storage == "f32":
+        L = ops.L
+        L.check(L.lib().srad_op_wgrad_deferred(L.PRECISIONS["bf16"], L.dptr(dy), N, 0, L.dptr(x), K, 0, M, N, K, L.dptr(rs), rps, 0.5, L.dptr(dw),
+                                               L.dptr(db), ops.wgrad_workspace(dy.device), L.current_stream_ptr()), "op_wgrad_deferred")
+        assert _rel(dw, dw_ref.float()) < 6e-3 and _rel(db, db_ref.float()) < 6e-3
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(2, 32, 32, 180, 64, 1), (1, 17, 23, 4, 180, 1), (2, 16, 12, 64, 4, 1),
                                                    (1, 32, 32, 20, 20, 2), (1, 15, 11, 40, 80, 2),
@@ -134,9 +165,12 @@ def test_layernorm_bwd(dev, rows, C):
     assert _rel(out2, x.grad + dres + prev) < 1e-4
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
-@pytest.mark.parametrize("d,heads,shift", [(180, 6, 0), (212, 4, 4), (244, 2, 0), (276, 6, 4), (308, 4, 0), (32, 2, 3)])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "bf16io"])
+@pytest.mark.parametrize("d,heads,shift", [(180, 6, 0), (180, 6, 4), (212, 4, 4), (244, 2, 0), (276, 6, 4), (308, 4, 0), (32, 2, 3),
+                                           (48, 2, 5), (64, 2, 0)])
 def test_window_attention_bwd(dev, d, heads, shift, prec):
+    if prec == "bf16io" and d // heads > 32:
+        pytest.skip("the all-bf16 kernel takes head dims <= 32")
     from oracle import sr_ref as R
     from srad_amd import ops
     B, H, W, ws = 2, 16, 24, 8
@@ -169,8 +203,11 @@ def test_window_attention_bwd(dev, d, heads, shift, prec):
     out_ref.backward(dout)
     out = ops.window_attention(qkv.detach().to(dev), table.detach().to(dev), B, H, W, ws, shift, heads)
     assert _rel(out, out_ref.detach()) < 1e-4
-    dqkv, dtable = ops.window_attention_bwd(qkv.detach().to(dev), dout.to(dev), table.detach().to(dev), B, H, W, ws, shift, heads,
-                                            precision=prec)
+    if prec == "bf16io":      # the training step's kernel: bf16 operands in per-head slots (NaN in dO's padding), bf16 results
+        dqkv, dtable = ops.window_attention_bwd_bf16io(qkv.detach().to(dev), dout.to(dev), table.detach().to(dev), B, H, W, ws, shift, heads)
+    else:
+        dqkv, dtable = ops.window_attention_bwd(qkv.detach().to(dev), dout.to(dev), table.detach().to(dev), B, H, W, ws, shift, heads,
+                                                precision=prec)
     # bf16 mode: q, k, v, dO, P and dS are rounded to bf16 for the MFMA (fp32 accumulation, fp32 softmax statistics)
     tol = 2e-4 if prec == "fp32" else 2e-2
     assert _rel(dqkv, qkv.grad) < tol

@@ -433,9 +433,11 @@ def test_bf16_fused_mlp_backward_matches_unfused(sr_golden, monkeypatch, batch):
         monkeypatch.delenv("SRAD_NO_FUSE", raising=False)
         m = build_train(cfg, sd, "bf16", drop_path_rate=0.1)
         m.keep_scale_override = keep
-        out = m(xt)
         if mode == "unfused":
-            monkeypatch.setenv("SRAD_NO_FUSE", "1")       # read at backward time: only the backward changes
+            # after the engine is built (its forward stays fused), before the forward (which saves q | k | v in the form the
+            # backward will take): only the backward changes
+            monkeypatch.setenv("SRAD_NO_FUSE", "1")
+        out = m(xt)
         F.l1_loss(out, hr).backward()
         torch.cuda.synchronize()
         grads[mode] = m.flat_grads.clone()

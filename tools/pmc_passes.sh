@@ -8,7 +8,7 @@ OUT=${1:-gpurun_out/pmc}
 TAG=${2:-r02}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 3 --warmup 3 --no-graph --no-train --no-eval --no-cpu-baseline"
+BENCH=${PMC_BENCH:-"python3 bench.py --steps 3 --warmup 3 --no-graph --no-train --no-eval --no-cpu-baseline"}   # PMC_BENCH="python3 tools/x.py": another program
 run() {  # name, counters...
   local name=$1; shift
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- $BENCH > "$OUT.$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT.$name.log"; return 1; }
