@@ -26,45 +26,90 @@ __device__ __forceinline__ float luma_of(const uint8_t* px, int C) {
   return r * c0 + g * c1 + b * c2;
 }
 
-// one thread per (image, row): running sums along the row -> sat[img][row+1][col+1][q]
-__global__ void sat_rows_kernel(const uint8_t* __restrict__ sr, const uint8_t* __restrict__ hr, double* __restrict__ sat,
-                                int n_img, int H, int W, int C) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// Table layout: planar, sat[img][q][row + 1][col + 1] (row 0 and column 0 are zero), so that the 64 lanes of a wave - 64
+// consecutive pixels of a row - read and write 512 contiguous bytes per quantity.
+//
+// Row pass: one wave per (image, table row).  The row is walked in 64-pixel chunks; a chunk's five running sums are a
+// 6-step wave scan (float64 shuffles) plus the carry of the chunks before it.
+__global__ __launch_bounds__(256) void sat_rows_kernel(const uint8_t* __restrict__ sr, const uint8_t* __restrict__ hr,
+                                                       double* __restrict__ sat, int n_img, int H, int W, int C) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= n_img * (H + 1)) return;
   const int img = t / (H + 1), r = t - img * (H + 1);
-  double* row = sat + ((size_t)img * (H + 1) + r) * (W + 1) * kQ;
-  for (int q = 0; q < kQ; ++q) row[q] = 0.0;
+  const size_t plane = (size_t)(H + 1) * (W + 1);
+  double* const base = sat + (size_t)img * kQ * plane + (size_t)r * (W + 1);
   if (r == 0) {
-    for (int c = 1; c <= W; ++c)
-      for (int q = 0; q < kQ; ++q) row[(size_t)c * kQ + q] = 0.0;
+    for (int c = lane; c <= W; c += 64)
+#pragma unroll
+      for (int q = 0; q < kQ; ++q) base[q * plane + c] = 0.0;
     return;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < kQ; ++q) base[q * plane] = 0.0;
   }
   const uint8_t* ps = sr + ((size_t)img * H + (r - 1)) * W * C;
   const uint8_t* ph = hr + ((size_t)img * H + (r - 1)) * W * C;
-  double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
-  for (int c = 0; c < W; ++c) {
-    const float x = luma_of(ph + (size_t)c * C, C);     // "ref" = HR
-    const float y = luma_of(ps + (size_t)c * C, C);     // "out" = SR
-    a0 += (double)x; a1 += (double)y;
-    a2 += (double)(x * x); a3 += (double)(y * y); a4 += (double)(x * y);    // fp32 products as in metrics.py:60-62
-    double* o = row + (size_t)(c + 1) * kQ;
-    o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4;
+  double carry[kQ] = {0, 0, 0, 0, 0};
+  for (int c0 = 0; c0 < W; c0 += 64) {
+    const int c = c0 + lane;
+    double v[kQ] = {0, 0, 0, 0, 0};
+    if (c < W) {
+      const float x = luma_of(ph + (size_t)c * C, C);     // "ref" = HR
+      const float y = luma_of(ps + (size_t)c * C, C);     // "out" = SR
+      v[0] = (double)x; v[1] = (double)y;
+      v[2] = (double)(x * x); v[3] = (double)(y * y); v[4] = (double)(x * y);    // fp32 products as in metrics.py:60-62
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+      for (int q = 0; q < kQ; ++q) {
+        const double up = __shfl_up(v[q], o);
+        if (lane >= o) v[q] += up;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kQ; ++q) {
+      v[q] += carry[q];
+      if (c < W) base[q * plane + c + 1] = v[q];
+      carry[q] = __shfl(v[q], 63);
+    }
   }
 }
 
-// one thread per (image, column, quantity): running sums down the column, in place
-__global__ void sat_cols_kernel(double* __restrict__ sat, int n_img, int H, int W) {
+// Column pass, in two launches so that a 1024-row table is not one thread's 1024 dependent steps: (1) every 32-row
+// segment of a column is summed down in place (its last row = the segment's total, also copied to `segtot`); (2) each
+// segment adds the totals of the segments above it.  Threads of a wave are consecutive columns: coalesced rows.
+constexpr int kSeg = 32;
+__global__ void sat_cols_local_kernel(double* __restrict__ sat, double* __restrict__ segtot, int n_planes, int H, int W, int nseg) {
   const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  const size_t per = (size_t)(W + 1) * kQ;
-  if (t >= (size_t)n_img * per) return;
-  const int img = (int)(t / per);
-  const size_t cq = t - (size_t)img * per;
-  double* p = sat + (size_t)img * (H + 1) * per + cq;
+  const size_t per = (size_t)(W + 1);
+  if (t >= (size_t)n_planes * nseg * per) return;
+  const int col = (int)(t % per);
+  const int seg = (int)((t / per) % nseg);
+  const int pl = (int)(t / (per * nseg));
+  double* p = sat + (size_t)pl * (H + 1) * per + col;
+  const int r0 = seg * kSeg + 1, r1 = min(H, r0 + kSeg - 1);
   double acc = 0.0;
-  for (int r = 1; r <= H; ++r) {
+  for (int r = r0; r <= r1; ++r) {
     acc += p[(size_t)r * per];
     p[(size_t)r * per] = acc;
   }
+  segtot[((size_t)pl * nseg + seg) * per + col] = acc;
+}
+__global__ void sat_cols_carry_kernel(double* __restrict__ sat, const double* __restrict__ segtot, int n_planes, int H, int W, int nseg) {
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t per = (size_t)(W + 1);
+  if (t >= (size_t)n_planes * (nseg - 1) * per) return;
+  const int col = (int)(t % per);
+  const int seg = (int)((t / per) % (nseg - 1)) + 1;
+  const int pl = (int)(t / (per * (nseg - 1)));
+  double carry = 0.0;
+  for (int s = 0; s < seg; ++s) carry += segtot[((size_t)pl * nseg + s) * per + col];
+  double* p = sat + (size_t)pl * (H + 1) * per + col;
+  const int r0 = seg * kSeg + 1, r1 = min(H, r0 + kSeg - 1);
+  for (int r = r0; r <= r1; ++r) p[(size_t)r * per] += carry;
 }
 
 struct Seg { int a, b; };   // inclusive index range of the unpadded image
@@ -78,14 +123,18 @@ __device__ __forceinline__ int reflect_segments(int lo, int hi, int n, Seg* s) {
   return k;
 }
 
-// grid (pixel blocks, images): SSIM map values for one window size, block partial sums (float64)
+// grid (pixel blocks, window sizes of the group, images): SSIM map values, block partial sums (float64).  Up to kWsGroup
+// window sizes share one launch (the list travels as a kernel argument).
+constexpr int kWsGroup = 16;
+struct WsList { int ws[kWsGroup]; };
 __global__ __launch_bounds__(256) void ssim_eval_kernel(const double* __restrict__ sat, double* __restrict__ partial,
-                                                        int H, int W, int ws, int nblk) {
-  const int img = blockIdx.y;
-  const size_t per = (size_t)(W + 1) * kQ;
-  const double* S = sat + (size_t)img * (H + 1) * per;
+                                                        int H, int W, const WsList wl, int nblk) {
+  const int kw = blockIdx.y, img = blockIdx.z;     // an image's window sizes run back to back: its tables stay in L2
+  const int ws = wl.ws[kw];
+  const size_t per = (size_t)(W + 1), plane = (size_t)(H + 1) * per;
+  const int iper = W + 1;
+  const double* S = sat + (size_t)img * kQ * plane;
   const int pad = ws / 2;
-  const float inv = 1.0f / (float)(ws * ws);
   const double dinv = 1.0 / (double)(ws * ws);
   const float C1 = (float)(0.01 * 0.01), C2 = (float)(0.03 * 0.03);
   double local = 0.0;
@@ -93,20 +142,25 @@ __global__ __launch_bounds__(256) void ssim_eval_kernel(const double* __restrict
     const int pix = blockIdx.x * kEvalPix + k * 256 + threadIdx.x;
     if (pix >= H * W) continue;
     const int i = pix / W, j = pix - i * W;
-    Seg rs[3], cs[3];
-    const int nr = reflect_segments(i - pad, i + ws - 1 - pad, H, rs);
-    const int nc = reflect_segments(j - pad, j + ws - 1 - pad, W, cs);
+    const int rlo = i - pad, rhi = i + ws - 1 - pad, clo = j - pad, chi = j + ws - 1 - pad;
     double sum[kQ] = {0, 0, 0, 0, 0};
-    for (int a = 0; a < nr; ++a)
-      for (int b = 0; b < nc; ++b) {
-        const double* p11 = S + (size_t)(rs[a].b + 1) * per + (size_t)(cs[b].b + 1) * kQ;
-        const double* p01 = S + (size_t)(rs[a].a) * per + (size_t)(cs[b].b + 1) * kQ;
-        const double* p10 = S + (size_t)(rs[a].b + 1) * per + (size_t)(cs[b].a) * kQ;
-        const double* p00 = S + (size_t)(rs[a].a) * per + (size_t)(cs[b].a) * kQ;
+    auto rect = [&](int ra, int rb, int ca, int cb) {          // rows ra..rb, columns ca..cb of the unpadded image (32-bit offsets:
+      const int o11 = (rb + 1) * iper + cb + 1, o01 = ra * iper + cb + 1, o10 = (rb + 1) * iper + ca, o00 = ra * iper + ca;   // a chunk's tables are < 2^31 doubles)
 #pragma unroll
-        for (int q = 0; q < kQ; ++q) sum[q] += (p11[q] - p01[q]) - (p10[q] - p00[q]);
+      for (int q = 0; q < kQ; ++q) {
+        const double* Sq = S + (size_t)q * plane;
+        sum[q] += (Sq[o11] - Sq[o01]) - (Sq[o10] - Sq[o00]);
       }
-    (void)inv;
+    };
+    if (rlo >= 0 && rhi < H && clo >= 0 && chi < W) {          // the window lies inside the image: one rectangle
+      rect(rlo, rhi, clo, chi);
+    } else {
+      Seg rs[3], cs[3];
+      const int nr = reflect_segments(rlo, rhi, H, rs);
+      const int nc = reflect_segments(clo, chi, W, cs);
+      for (int a = 0; a < nr; ++a)
+        for (int b = 0; b < nc; ++b) rect(rs[a].a, rs[a].b, cs[b].a, cs[b].b);
+    }
     const float mu1 = (float)(sum[0] * dinv), mu2 = (float)(sum[1] * dinv);
     const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
     const float s1 = (float)(sum[2] * dinv) - mu1_sq;
@@ -123,26 +177,32 @@ __global__ __launch_bounds__(256) void ssim_eval_kernel(const double* __restrict
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) partial[(size_t)img * nblk + blockIdx.x] = red[0];
+  if (threadIdx.x == 0) partial[((size_t)img * kWsGroup + kw) * nblk + blockIdx.x] = red[0];
 }
 
-__global__ void ssim_finish_kernel(const double* __restrict__ partial, double* __restrict__ out, int n_img, int nblk,
-                                   int out_stride, int out_col, double inv_count) {
-  const int img = blockIdx.x * blockDim.x + threadIdx.x;
-  if (img >= n_img) return;
+// one wave per (image, window size of the group): lanes sum every 64th block partial, then a fixed-order wave sum
+__global__ __launch_bounds__(256) void ssim_finish_kernel(const double* __restrict__ partial, double* __restrict__ out, int n_img, int n_grp,
+                                                          int nblk, int out_stride, int out_col0, double inv_count) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= n_img * n_grp) return;
+  const int img = t / n_grp, kw = t - img * n_grp;
+  const double* p = partial + ((size_t)img * kWsGroup + kw) * nblk;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += partial[(size_t)img * nblk + b];
-  out[(size_t)img * out_stride + out_col] = s * inv_count;
+  for (int b = lane; b < nblk; b += 64) s += p[b];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) out[(size_t)img * out_stride + out_col0 + kw] = s * inv_count;
 }
 
-// one workgroup per image: mean((sr/255 - hr/255)^2) over all H*W*C values, PSNR with data_range 1
-__global__ __launch_bounds__(256) void mse_psnr_kernel(const uint8_t* __restrict__ sr, const uint8_t* __restrict__ hr,
-                                                       double* __restrict__ mse, double* __restrict__ psnr, size_t n) {
-  const int img = blockIdx.x;
+// mean((sr/255 - hr/255)^2) over all H*W*C values of an image: block partial sums (grid = blocks x images) ...
+__global__ __launch_bounds__(256) void mse_partial_kernel(const uint8_t* __restrict__ sr, const uint8_t* __restrict__ hr,
+                                                          double* __restrict__ partial, size_t n, int nb) {
+  const int img = blockIdx.y;
   const uint8_t* a = sr + (size_t)img * n;
   const uint8_t* b = hr + (size_t)img * n;
   double local = 0.0;
-  for (size_t i = threadIdx.x; i < n; i += 256) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)nb * 256) {
     const float d = (float)a[i] / 255.0f - (float)b[i] / 255.0f;
     local += (double)(d * d);
   }
@@ -153,11 +213,18 @@ __global__ __launch_bounds__(256) void mse_psnr_kernel(const uint8_t* __restrict
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    const double m = (double)(float)(red[0] / (double)n);      // np.mean of a float32 array is float32
-    mse[img] = m;
-    psnr[img] = m == 0.0 ? INFINITY : 10.0 * log10(1.0 / m);
-  }
+  if (threadIdx.x == 0) partial[(size_t)img * nb + blockIdx.x] = red[0];
+}
+// ... and one thread per image: the mean as float32 (np.mean of a float32 array), PSNR with data_range 1
+__global__ void mse_finish_kernel(const double* __restrict__ partial, double* __restrict__ mse, double* __restrict__ psnr, int n_img,
+                                  int nb, double n) {
+  const int img = blockIdx.x * blockDim.x + threadIdx.x;
+  if (img >= n_img) return;
+  double s = 0.0;
+  for (int b = 0; b < nb; ++b) s += partial[(size_t)img * nb + b];
+  const double m = (double)(float)(s / n);
+  mse[img] = m;
+  psnr[img] = m == 0.0 ? INFINITY : 10.0 * log10(1.0 / m);
 }
 
 __global__ void to_u8_hwc_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, int B, int C, int HW, float mul) {
@@ -308,8 +375,10 @@ int srad_score_workspace_bytes(int n_img, int H, int W, size_t* bytes) {
   SRAD_REQUIRE(bytes && n_img > 0 && H > 0 && W > 0, "score_workspace_bytes: bad argument");
   const int chunk = chunk_images(n_img, H, W);
   const int nblk = (H * W + kEvalPix - 1) / kEvalPix;
+  const int nseg = (H + kSeg - 1) / kSeg;
   *bytes = srad_align_up((size_t)chunk * (H + 1) * (W + 1) * kQ * sizeof(double), 256) +
-           srad_align_up((size_t)chunk * nblk * sizeof(double), 256);
+           srad_align_up((size_t)chunk * kWsGroup * nblk * sizeof(double), 256) +
+           srad_align_up((size_t)chunk * kQ * nseg * (W + 1) * sizeof(double), 256);
   return SRAD_OK;
 }
 
@@ -318,6 +387,7 @@ int srad_score_pairs(const uint8_t* sr, const uint8_t* hr, int n_img, int H, int
                      size_t workspace_bytes, void* stream) {
   SRAD_REQUIRE(sr && hr && workspace && n_img > 0 && H > 1 && W > 1, "score_pairs: bad argument");
   SRAD_REQUIRE(C == 1 || C == 3, "score_pairs: channels must be 1 or 3 (got %d)", C);
+  SRAD_REQUIRE((long long)(H + 1) * (W + 1) < (1ll << 31), "score_pairs: %dx%d images are too large for the 32-bit table offsets", H, W);
   SRAD_REQUIRE(n_ws == 0 || (ws_host && ssim_out), "score_pairs: window list / output missing");
   size_t need = 0;
   SRAD_TRY(srad_score_workspace_bytes(n_img, H, W, &need));
@@ -332,32 +402,45 @@ int srad_score_pairs(const uint8_t* sr, const uint8_t* hr, int n_img, int H, int
   double* sat = reinterpret_cast<double*>(workspace);
   double* partial = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) +
                                               srad_align_up((size_t)chunk * (H + 1) * (W + 1) * kQ * sizeof(double), 256));
+  double* segtot = reinterpret_cast<double*>(reinterpret_cast<char*>(partial) + srad_align_up((size_t)chunk * kWsGroup * nblk * sizeof(double), 256));
+  const int nseg = (H + kSeg - 1) / kSeg;
   const size_t img_bytes = (size_t)H * W * C;
-  if (mse_out && psnr_out) {
-    SradProfScope prof(s, SRAD_K_SCORE, 3.0 * n_img * img_bytes, 2.0 * n_img * img_bytes);
-    hipLaunchKernelGGL(mse_psnr_kernel, dim3(n_img), dim3(256), 0, s, sr, hr, mse_out, psnr_out, img_bytes);
-  }
-  for (int i0 = 0; i0 < n_img && n_ws > 0; i0 += chunk) {
+  const bool want_mse = mse_out && psnr_out;
+  for (int i0 = 0; i0 < n_img && (n_ws > 0 || want_mse); i0 += chunk) {
     const int n = std::min(chunk, n_img - i0);
     const uint8_t* srp = sr + (size_t)i0 * img_bytes;
     const uint8_t* hrp = hr + (size_t)i0 * img_bytes;
+    if (want_mse) {                                   // block partials in the (not yet used) SSIM partial area: nb <= kWsGroup * nblk
+      const int nb = std::min(64, nblk);
+      SradProfScope prof(s, SRAD_K_SCORE, 3.0 * n * img_bytes, 2.0 * n * img_bytes);
+      hipLaunchKernelGGL(mse_partial_kernel, dim3(nb, n), dim3(256), 0, s, srp, hrp, partial, img_bytes, nb);
+      hipLaunchKernelGGL(mse_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, s, partial, mse_out + i0, psnr_out + i0, n, nb, (double)img_bytes);
+    }
+    if (n_ws == 0) continue;
     {
       SradProfScope prof(s, SRAD_K_SCORE, 10.0 * n * H * W, 2.0 * n * img_bytes + 40.0 * n * (H + 1) * (W + 1));
-      hipLaunchKernelGGL(sat_rows_kernel, dim3((n * (H + 1) + 63) / 64), dim3(64), 0, s, srp, hrp, sat, n, H, W, C);
+      hipLaunchKernelGGL(sat_rows_kernel, dim3((n * (H + 1) + 3) / 4), dim3(256), 0, s, srp, hrp, sat, n, H, W, C);
     }
     {
-      const size_t t = (size_t)n * (W + 1) * kQ;
+      const size_t t = (size_t)n * kQ * nseg * (W + 1);
       SradProfScope prof(s, SRAD_K_SCORE, 1.0 * n * (H + 1) * (W + 1) * kQ, 80.0 * n * (H + 1) * (W + 1));
-      hipLaunchKernelGGL(sat_cols_kernel, dim3((unsigned)((t + 63) / 64)), dim3(64), 0, s, sat, n, H, W);
+      hipLaunchKernelGGL(sat_cols_local_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, sat, segtot, n * kQ, H, W, nseg);
+      if (nseg > 1) {
+        const size_t t2 = (size_t)n * kQ * (nseg - 1) * (W + 1);
+        hipLaunchKernelGGL(sat_cols_carry_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, sat, segtot, n * kQ, H, W, nseg);
+      }
     }
-    for (int k = 0; k < n_ws; ++k) {
+    for (int k0 = 0; k0 < n_ws; k0 += kWsGroup) {      // up to kWsGroup window sizes per launch
+      const int g = std::min(kWsGroup, n_ws - k0);
+      WsList wl{};
+      for (int k = 0; k < g; ++k) wl.ws[k] = (int)ws_host[k0 + k];
       {
         // algorithmic bytes per (pair, window): the two fp32 luminance planes read once
-        SradProfScope prof(s, SRAD_K_SCORE, 40.0 * n * H * W, 8.0 * n * H * W);
-        hipLaunchKernelGGL(ssim_eval_kernel, dim3(nblk, n), dim3(256), 0, s, sat, partial, H, W, (int)ws_host[k], nblk);
+        SradProfScope prof(s, SRAD_K_SCORE, 40.0 * n * H * W * g, 8.0 * n * H * W * g);
+        hipLaunchKernelGGL(ssim_eval_kernel, dim3(nblk, g, n), dim3(256), 0, s, sat, partial, H, W, wl, nblk);
       }
-      hipLaunchKernelGGL(ssim_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, s, partial, ssim_out + (size_t)i0 * n_ws, n,
-                         nblk, n_ws, k, 1.0 / ((double)H * W));
+      hipLaunchKernelGGL(ssim_finish_kernel, dim3((n * g + 3) / 4), dim3(256), 0, s, partial, ssim_out + (size_t)i0 * n_ws, n, g,
+                         nblk, n_ws, k0, 1.0 / ((double)H * W));
     }
   }
   SRAD_CHECK_HIP(hipGetLastError());
