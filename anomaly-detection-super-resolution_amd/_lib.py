@@ -124,7 +124,7 @@ _SIG = {
     "srad_bench_qkv_attn": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_size_t,
                                       C.c_int, C.POINTER(C.c_float), _P]),
     "srad_op_swin_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
-    "srad_op_qkv_attn": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P,
+    "srad_op_qkv_attn": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P,
                                    C.c_size_t, _P]),
     "srad_op_mlp_block": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P,
                                     _P, _P, C.c_int, C.c_float, C.c_float, _P, C.c_int, _P, C.c_int, C.c_int, _P, C.c_size_t, _P]),

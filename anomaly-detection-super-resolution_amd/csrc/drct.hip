@@ -89,13 +89,18 @@ int forward_body(srad_drct* h, const float* x, int B, int H, int W, float* y, co
     for (int k = 0; k < 5; ++k) {
       const SwinW& sw = h->blocks[i * 5 + k];
       const int d = sw.d;
+      const int no = k < 4 ? c.gc : E;
+      // the attention output is handed to the fused second half as bf16 (what its MFMA rounds it to anyway: half the bytes)
+      const bool mlp_fused = h->fuse_mlp && srad_mlp_block_supported(prec, T, d, sw.hidden, no);
+      __bf16* const attn_h = reinterpret_cast<__bf16*>(w.attn);
       if (h->fuse_mlp && srad_qkv_attn_supported(prec, c.window_size, H, W, d, sw.heads)) {
         // norm1 + qkv + shifted-window attention of one (window, head) per workgroup, one launch
         // (drct.py:477-504, 278-299)
         QkvAttnParams a{};
         a.x = cur; a.ldx = D; a.ln_g = h->pt.fptr(sw.n1g); a.ln_b = h->pt.fptr(sw.n1b);
         a.w_qkv = h->pt.frag_ptr(sw.qkv.w); a.b_qkv = h->pt.fptr(sw.qkv.b); a.table = h->pt.fptr(sw.table);
-        a.out = w.attn; a.ld_out = d; a.B = B; a.H = H; a.W = W; a.shift = sw.shift; a.d = d; a.heads = sw.heads;
+        a.out = w.attn; a.out_h = mlp_fused ? attn_h : nullptr; a.ld_out = d;
+        a.B = B; a.H = H; a.W = W; a.shift = sw.shift; a.d = d; a.heads = sw.heads;
         SRAD_TRY(srad_launch_qkv_attn(a, s));
       } else {
       // norm1 + qkv                                   (drct.py:477, 278)
@@ -110,15 +115,15 @@ int forward_body(srad_drct* h, const float* x, int B, int H, int W, float* y, co
         {
           AttnParams a{w.qkv, w.attn, h->pt.fptr(sw.table), B, H, W, c.window_size, sw.shift, d, sw.heads,
                        hdp_of(d, sw.heads)};
+          if (mlp_fused) a.out_h = attn_h;
           SRAD_TRY(srad_launch_window_attn(prec, a, s));
         }
       }
-      const int no = k < 4 ? c.gc : E;
-      if (h->fuse_mlp && srad_mlp_block_supported(prec, T, d, sw.hidden, no)) {
+      if (mlp_fused) {
         // proj + shortcut -> norm2 -> fc1 -> GELU -> fc2 + residual -> adjust_k, one launch
         // (drct.py:300, 509-510, 184-190, 389-396)
         MlpBlockParams q{};
-        q.attn = w.attn; q.ld_attn = d; q.shortcut = cur; q.ld_short = D;
+        q.attn_h = attn_h; q.ld_attn = d; q.shortcut = cur; q.ld_short = D;
         q.M = T; q.d = d; q.m = sw.hidden; q.no = no;
         q.w_proj = h->pt.frag_ptr(sw.proj.w); q.w_fc1 = h->pt.frag_ptr(sw.fc1.w); q.w_fc2 = h->pt.frag_ptr(sw.fc2.w);
         q.w_adj = h->pt.frag_ptr(sw.adjust.w);

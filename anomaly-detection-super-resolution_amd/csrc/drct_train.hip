@@ -236,7 +236,8 @@ int srad_drct_forward_train(srad_drct_t* h, const float* x, int B, int H, int W,
         QkvAttnParams a{};
         a.x = cur; a.ldx = D; a.ln_g = h->pt.fptr(sw.n1g); a.ln_b = h->pt.fptr(sw.n1b);
         a.w_qkv = h->pt.frag_ptr(sw.qkv.w); a.b_qkv = h->pt.fptr(sw.qkv.b); a.table = h->pt.fptr(sw.table);
-        a.out = sv.attn; a.ld_out = d; a.B = B; a.H = H; a.W = W; a.shift = sw.shift; a.d = d; a.heads = sw.heads;
+        a.out_h = reinterpret_cast<__bf16*>(sv.attn); a.ld_out = d;      // bf16 hand-off to mlp_block (and to the proj weight gradient)
+        a.B = B; a.H = H; a.W = W; a.shift = sw.shift; a.d = d; a.heads = sw.heads;
         // the tensors only the weight gradients read (LN1(x), LN2(.), GELU(.), the block output) are left as bf16, which is
         // what the MFMA would round them to anyway: half the bytes written here and read (3 - 9 times each) by wgrad
         a.save_xn_h = reinterpret_cast<__bf16*>(sv.xn1); a.hdp = hdp;
@@ -245,7 +246,7 @@ int srad_drct_forward_train(srad_drct_t* h, const float* x, int B, int H, int W,
         else a.save_qkv = sv.qkv;
         SRAD_TRY(srad_launch_qkv_attn(a, s));
         MlpBlockParams q{};
-        q.attn = sv.attn; q.ld_attn = d; q.shortcut = cur; q.ld_short = D;
+        q.attn_h = reinterpret_cast<const __bf16*>(sv.attn); q.ld_attn = d; q.shortcut = cur; q.ld_short = D;
         q.M = T; q.d = d; q.m = sw.hidden; q.no = no;
         q.w_proj = h->pt.frag_ptr(sw.proj.w); q.w_fc1 = h->pt.frag_ptr(sw.fc1.w); q.w_fc2 = h->pt.frag_ptr(sw.fc2.w);
         q.w_adj = h->pt.frag_ptr(sw.adjust.w);
@@ -538,7 +539,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       // ---- attention branch: x1 = x + rs1 * proj(attn(LN1(x)))                  (drct.py:477-509)
       {
         WgradParams g = wgrad_of(h, sw.proj, G, dx1, d, 0, sv.attn, d, T);
-        g.row_scale = ks1; g.rps = HW;
+        g.row_scale = ks1; g.rps = HW; g.x_bf16 = xh;          // the fused forward left the attention output as bf16
         SRAD_TRY(srad_launch_wgrad_deferred(prec, g, wq, side));
         if (!fuse_proj) {
           GemmParams p = dgrad_gemm(h, sw.proj, dx1, d, T, w.dO, d);

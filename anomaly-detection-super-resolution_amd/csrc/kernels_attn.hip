@@ -348,14 +348,25 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
     }
     if (q0 + row < N) {
       const float inv = 1.0f / lrow;
-      float* dst = p.out + (size_t)tokq[row] * d + h * hd;
+      if (p.out_h) {                                            // bf16 hand-off to mlp_block
+        __bf16* dst = p.out_h + (size_t)tokq[row] * d + h * hd;
 #pragma unroll
-      for (int j = 0; j < NT_O; ++j)
+        for (int j = 0; j < NT_O; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int c = j * 16 + 4 * fq + e;
-          if (c < hd) dst[c] = o[j][e] * inv;
-        }
+          for (int e = 0; e < 4; ++e) {
+            const int c = j * 16 + 4 * fq + e;
+            if (c < hd) dst[c] = (__bf16)(o[j][e] * inv);
+          }
+      } else {
+        float* dst = p.out + (size_t)tokq[row] * d + h * hd;
+#pragma unroll
+        for (int j = 0; j < NT_O; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int c = j * 16 + 4 * fq + e;
+            if (c < hd) dst[c] = o[j][e] * inv;
+          }
+      }
     }
   }
 }

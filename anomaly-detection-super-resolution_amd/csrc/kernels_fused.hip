@@ -156,12 +156,12 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
   constexpr int NAQ = 32 * GD;                                    // float4 per row of the attn tile actually needed
   constexpr int NAJ = FM * NAQ / 512;                             // float4 per thread
   static_assert(FM * NAQ % 512 == 0, "attn tile must divide over the workgroup");
-  f32x4 a_reg[NAJ];
+  u32x2 a_reg[NAJ];                                               // four bf16 columns each
 #pragma unroll
   for (int j = 0; j < NAJ; ++j) {
     const int idx = tid + 512 * j, row = idx / NAQ, c = (idx - row * NAQ) * 4;
-    a_reg[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.attn) + (size_t)(m0 + row) * p.ld_attn * 4 +
-                                               (unsigned)min(c, d - 4) * 4u);
+    a_reg[j] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(p.attn_h) + (size_t)(m0 + row) * p.ld_attn * 2 +
+                                               (unsigned)min(c, d - 4) * 2u);
   }
   // accumulator layout of this lane: token row 16*rt + fr, columns 128*g + 16*wave + 4*fq + (0..3)
   f32x4 x1[GD][NRT];
@@ -213,10 +213,7 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
 #pragma unroll
     for (int j = 0; j < NAJ; ++j) {
       const int idx = tid + 512 * j, row = idx / NAQ, c = (idx - row * NAQ) * 4;
-      const f32x4 v = c < d ? a_reg[j] : f32x4{0.f, 0.f, 0.f, 0.f};
-      bf16x4 h;
-      h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-      *reinterpret_cast<bf16x4*>(A1 + row * F_LDA + c) = h;
+      *reinterpret_cast<u32x2*>(A1 + row * F_LDA + c) = c < d ? a_reg[j] : u32x2{0u, 0u};
     }
   }
   static_for<1, NSETS>([&](auto Q) { load_w(Q, w_reg[decltype(Q)::value]); });   // the rest of the look-ahead, behind the tile
@@ -448,7 +445,7 @@ bool srad_mlp_block_supported(int prec, int M, int d, int m, int no) {
 
 int srad_launch_mlp_block(const MlpBlockParams& p, hipStream_t stream) {
   SRAD_REQUIRE(srad_mlp_block_supported(SRAD_PREC_BF16, p.M, p.d, p.m, p.no), "mlp_block: unsupported shape M=%d d=%d m=%d no=%d", p.M, p.d, p.m, p.no);
-  SRAD_REQUIRE((p.ld_attn & 3) == 0 && ((uintptr_t)p.attn & 15) == 0, "mlp_block: attn rows must be float4-addressable");
+  SRAD_REQUIRE((p.ld_attn & 3) == 0 && ((uintptr_t)p.attn_h & 7) == 0, "mlp_block: the bf16 attn rows must be 8-byte addressable");
   SRAD_REQUIRE((p.ld_short & 3) == 0 && ((uintptr_t)p.shortcut & 15) == 0 && (p.ldy & 3) == 0 && (p.yoff & 3) == 0 &&
                    ((uintptr_t)p.Y & 15) == 0 && (!p.R || ((p.ldr & 3) == 0 && ((uintptr_t)p.R & 15) == 0)),
                "mlp_block: shortcut / output / residual rows must be float4-addressable");

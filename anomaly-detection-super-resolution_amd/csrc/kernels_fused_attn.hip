@@ -318,11 +318,20 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
       }
       const int row = rt * 16 + fr;
       const float inv = 1.0f / (lsum[row] + lsum[64 + row]);
-      float* dst = p.out + (size_t)tok[row] * p.ld_out + h * hd;
+      if (p.out_h) {                                              // bf16 hand-off to mlp_block
+        __bf16* dst = p.out_h + (size_t)tok[row] * p.ld_out + h * hd;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int c = j * 16 + 4 * fq + e;
-        if (c < hd) dst[c] = o[e] * inv;
+        for (int e = 0; e < 4; ++e) {
+          const int c = j * 16 + 4 * fq + e;
+          if (c < hd) dst[c] = (__bf16)(o[e] * inv);
+        }
+      } else {
+        float* dst = p.out + (size_t)tok[row] * p.ld_out + h * hd;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = j * 16 + 4 * fq + e;
+          if (c < hd) dst[c] = o[e] * inv;
+        }
       }
     }
   }

@@ -101,7 +101,7 @@ int srad_bench_window_attn(int precision, const float* qkv, float* out, const fl
 
 // Diagnostic: the fused MLP block on synthetic operands, `iters` back-to-back launches, microseconds per launch.
 // scratch must hold the four packed bf16 weights; x/y are [M][320] fp32 buffers.
-int srad_bench_mlp_block(int M, int d, int m, int no, const float* attn, const float* shortcut, float* y,
+int srad_bench_mlp_block(int M, int d, int m, int no, const void* attn /* bf16 [M][320] */, const float* shortcut, float* y,
                          const float* w_fp32 /* >= 512*512 floats */, void* scratch, size_t scratch_bytes, int dbg,
                          int iters, float* us_out, void* stream) {
   SRAD_REQUIRE(attn && shortcut && y && w_fp32 && scratch && us_out && iters > 0, "bench_mlp_block: bad argument");
@@ -115,7 +115,7 @@ int srad_bench_mlp_block(int M, int d, int m, int no, const float* attn, const f
   SRAD_TRY(srad_launch_pack_weight_frag(w_fp32, sc + b1 + b2, d, m, s));
   SRAD_TRY(srad_launch_pack_weight_frag(w_fp32, sc + b1 + b2 + b3, no, d, s));
   MlpBlockParams q{};
-  q.attn = attn; q.ld_attn = 320; q.shortcut = shortcut; q.ld_short = 320; q.M = M; q.d = d; q.m = m; q.no = no;
+  q.attn_h = reinterpret_cast<const __bf16*>(attn); q.ld_attn = 320; q.shortcut = shortcut; q.ld_short = 320; q.M = M; q.d = d; q.m = m; q.no = no;
   q.w_proj = sc; q.w_fc1 = sc + b1; q.w_fc2 = sc + b1 + b2; q.w_adj = sc + b1 + b2 + b3;
   q.b_proj = q.b_fc1 = q.b_fc2 = q.b_adj = q.ln_g = q.ln_b = w_fp32;
   q.act = SRAD_ACT_LRELU; q.slope = 0.2f; q.alpha = 1.f; q.R = nullptr; q.ldr = 0; q.Y = y; q.ldy = 320; q.yoff = 0; q.dbg = dbg & 0xff;
@@ -159,8 +159,8 @@ size_t srad_op_swin_scratch_bytes(int d, int heads, int m, int no) {
 // First half of a Swin block: LayerNorm1 -> qkv Linear -> shifted-window attention (src/drct.py:477-504, 271-299).
 //   x [B*H*W][ldx] (columns [0, d)), w_qkv [3d][d], b_qkv [3d], table [225][heads] -> out [B*H*W][d]
 int srad_op_qkv_attn(const float* x, int ldx, int B, int H, int W, int shift, int d, int heads, const float* ln_g,
-                     const float* ln_b, const float* w_qkv, const float* b_qkv, const float* table, float* out, void* scratch,
-                     size_t scratch_bytes, void* stream) {
+                     const float* ln_b, const float* w_qkv, const float* b_qkv, const float* table, void* out, int out_bf16,
+                     void* scratch, size_t scratch_bytes, void* stream) {
   SRAD_REQUIRE(x && ln_g && ln_b && w_qkv && b_qkv && table && out && scratch, "op_qkv_attn: null argument");
   SRAD_REQUIRE(srad_qkv_attn_supported(SRAD_PREC_BF16, 8, H, W, d, heads), "op_qkv_attn: unsupported shape d=%d heads=%d %dx%d", d, heads, H, W);
   SRAD_REQUIRE(scratch_bytes >= srad_align_up(srad_qkv_frag_bytes(d, heads), 256) && ((uintptr_t)scratch & 255) == 0,
@@ -169,13 +169,14 @@ int srad_op_qkv_attn(const float* x, int ldx, int B, int H, int W, int shift, in
   SRAD_TRY(srad_launch_pack_qkv_frag(w_qkv, scratch, d, heads, s));
   QkvAttnParams a{};
   a.x = x; a.ldx = ldx; a.ln_g = ln_g; a.ln_b = ln_b; a.w_qkv = scratch; a.b_qkv = b_qkv; a.table = table;
-  a.out = out; a.ld_out = d; a.B = B; a.H = H; a.W = W; a.shift = shift; a.d = d; a.heads = heads;
+  if (out_bf16) a.out_h = reinterpret_cast<__bf16*>(out); else a.out = reinterpret_cast<float*>(out);
+  a.ld_out = d; a.B = B; a.H = H; a.W = W; a.shift = shift; a.d = d; a.heads = heads;
   return srad_launch_qkv_attn(a, s);
 }
 
 // Diagnostic twin of srad_bench_mlp_block for the first half: microseconds per launch, back-to-back launches.
 int srad_bench_qkv_attn(const float* x, int ldx, int B, int H, int W, int shift, int d, int heads, const float* w_fp32,
-                        float* out, void* scratch, size_t scratch_bytes, int iters, float* us_out, void* stream) {
+                        void* out, void* scratch, size_t scratch_bytes, int iters, float* us_out, void* stream) {
   SRAD_REQUIRE(x && w_fp32 && out && scratch && us_out && iters > 0, "bench_qkv_attn: bad argument");
   SRAD_REQUIRE(srad_qkv_attn_supported(SRAD_PREC_BF16, 8, H, W, d, heads), "bench_qkv_attn: unsupported shape");
   SRAD_REQUIRE(scratch_bytes >= srad_align_up(srad_qkv_frag_bytes(d, heads), 256), "bench_qkv_attn: scratch too small");
@@ -183,7 +184,8 @@ int srad_bench_qkv_attn(const float* x, int ldx, int B, int H, int W, int shift,
   SRAD_TRY(srad_launch_pack_qkv_frag(w_fp32, scratch, d, heads, s));
   QkvAttnParams a{};
   a.x = x; a.ldx = ldx; a.ln_g = w_fp32; a.ln_b = w_fp32; a.w_qkv = scratch; a.b_qkv = w_fp32; a.table = w_fp32;
-  a.out = out; a.ld_out = d; a.B = B; a.H = H; a.W = W; a.shift = shift & 0xff; a.d = d; a.heads = heads;
+  a.out_h = reinterpret_cast<__bf16*>(out); a.ld_out = d;        // the hand-off the engines use (bf16, in the caller's buffer)
+  a.B = B; a.H = H; a.W = W; a.shift = shift & 0xff; a.d = d; a.heads = heads;
   if (shift & 0x10000) {                            // bit 16 of `shift`: the stamp build; stamps go behind the weight pack in scratch
     const size_t wb = srad_align_up(srad_qkv_frag_bytes(d, heads), 256);
     SRAD_REQUIRE(scratch_bytes >= wb + (size_t)B * (H / 8) * (W / 8) * heads * 8 * 16 * 8, "bench_qkv_attn: scratch too small for the stamps");
@@ -208,7 +210,7 @@ int srad_bench_qkv_attn(const float* x, int ldx, int B, int H, int W, int shift,
 // Second half of a Swin block + the RDG's adjust conv (src/drct.py:300, 509-510, 184-190, 389-396):
 //   x1 = shortcut + proj(attn); x2 = x1 + fc2(GELU(fc1(LN2(x1)))); Y[:, yoff:yoff+no] = act(adjust(x2)) * alpha (+ R)
 //   fm: token rows per workgroup (16 / 32 / 64; 0 = the engine's choice for M)
-int srad_op_mlp_block(int M, int d, int m, int no, int fm, const float* attn, const float* shortcut, int ld_short,
+int srad_op_mlp_block(int M, int d, int m, int no, int fm, const void* attn /* bf16 [M][d] */, const float* shortcut, int ld_short,
                       const float* w_proj, const float* b_proj, const float* ln_g, const float* ln_b, const float* w_fc1,
                       const float* b_fc1, const float* w_fc2, const float* b_fc2, const float* w_adj, const float* b_adj, int act,
                       float slope, float alpha, const float* r, int ldr, float* y, int ldy, int yoff, void* scratch,
@@ -227,7 +229,7 @@ int srad_op_mlp_block(int M, int d, int m, int no, int fm, const float* attn, co
   SRAD_TRY(srad_launch_pack_weight_frag(w_fc2, sc + off[3], d, m, s));
   SRAD_TRY(srad_launch_pack_weight_frag(w_adj, sc + off[4], no, d, s));
   MlpBlockParams q{};
-  q.attn = attn; q.ld_attn = d; q.shortcut = shortcut; q.ld_short = ld_short; q.M = M; q.d = d; q.m = m; q.no = no;
+  q.attn_h = reinterpret_cast<const __bf16*>(attn); q.ld_attn = d; q.shortcut = shortcut; q.ld_short = ld_short; q.M = M; q.d = d; q.m = m; q.no = no;
   q.w_proj = sc + off[1]; q.w_fc1 = sc + off[2]; q.w_fc2 = sc + off[3]; q.w_adj = sc + off[4];
   q.b_proj = b_proj; q.b_fc1 = b_fc1; q.b_fc2 = b_fc2; q.b_adj = b_adj; q.ln_g = ln_g; q.ln_b = ln_b;
   q.act = act; q.slope = slope; q.alpha = alpha; q.R = r; q.ldr = ldr; q.Y = y; q.ldy = ldy; q.yoff = yoff; q.fm = fm;

@@ -164,6 +164,7 @@ struct AttnParams {
   const float* table; // [(2ws-1)^2][heads]
   int B, H, W, ws, shift, d, heads;
   int hdp;            // padded head_dim (multiple of 4, >= d / heads)
+  __bf16* out_h = nullptr;   // write the output as bf16 [T][d] instead (the hand-off to mlp_block, which rounds it to bf16 anyway)
 };
 int srad_launch_window_attn(int prec, const AttnParams& p, hipStream_t stream);
 
@@ -173,7 +174,7 @@ int srad_launch_window_attn(int prec, const AttnParams& p, hipStream_t stream);
 // Weights are the fragment-major bf16 packs (srad_launch_pack_weight_frag).
 // ------------------------------------------------------------------------------------------
 struct MlpBlockParams {
-  const float* attn; int ld_attn;        // [M][d] attention output (pre-proj)
+  const __bf16* attn_h; int ld_attn;     // [M][d] attention output (pre-proj) as bf16 - what the MFMA takes; ld in elements, % 4 == 0
   const float* shortcut; int ld_short;   // [M][>=d] block input (residual)
   int M, d, m, no;                       // rows, block dim, MLP hidden, adjust output channels
   const void *w_proj, *w_fc1, *w_fc2, *w_adj;
@@ -201,7 +202,8 @@ struct QkvAttnParams {
   const float *ln_g, *ln_b;
   const void* w_qkv; const float* b_qkv;   // per-head fragment pack (srad_launch_pack_qkv_frag), bias [3d]
   const float* table;                      // [225][heads]
-  float* out; int ld_out;                  // attention output [T][d]
+  float* out; int ld_out;                  // attention output [T][d] ...
+  __bf16* out_h;                           // ... or, when set, as bf16 (same ld, in elements): the hand-off to mlp_block
   int B, H, W, shift, d, heads;
   // ---- training (optional): what the backward needs ----
   float* save_xn;                          // [T][d] LayerNorm1(x) (written by the head-0 workgroups)

@@ -288,19 +288,20 @@ def lin_ln_bwd(dy: torch.Tensor, w: torch.Tensor, x: torch.Tensor, gamma: torch.
 
 # ----------------------------------------------------------------------------------- fused Swin-block halves (bf16, window 8)
 def qkv_attn(x: torch.Tensor, ln_g: torch.Tensor, ln_b: torch.Tensor, w_qkv: torch.Tensor, b_qkv: torch.Tensor,
-             table: torch.Tensor, B: int, H: int, W: int, shift: int, heads: int) -> torch.Tensor:
+             table: torch.Tensor, B: int, H: int, W: int, shift: int, heads: int, out_bf16: bool = False) -> torch.Tensor:
     """First half of a Swin block in ONE launch (``srad_op_qkv_attn``; src/drct.py:477-504 up to attn.proj, 271-299):
     x [B*H*W, >=d] block input rows (columns [0, d) are read), w_qkv [3d, d], table [225, heads] -> attention output
-    [B*H*W, d] in token order (window partition, cyclic shift and their inverses are index arithmetic inside)."""
+    [B*H*W, d] in token order (window partition, cyclic shift and their inverses are index arithmetic inside); fp32, or
+    with ``out_bf16`` the bf16 tensor the engines hand to ``mlp_block``."""
     _need_cuda(x, ln_g, ln_b, w_qkv, b_qkv, table)
     d = w_qkv.shape[1]
     assert x.dim() == 2 and x.shape[0] == B * H * W and x.stride(1) == 1 and x.dtype == torch.float32 and w_qkv.shape[0] == 3 * d
     f = lambda t: t.detach().float().contiguous()
     keep = [f(ln_g), f(ln_b), f(w_qkv), f(b_qkv), f(table)]
-    out = torch.empty(x.shape[0], d, dtype=torch.float32, device=x.device)
+    out = torch.empty(x.shape[0], d, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     sbuf, sp, sb = _scratch(L.lib().srad_op_swin_scratch_bytes(d, heads, 4, 4), x.device)
     L.check(L.lib().srad_op_qkv_attn(L.dptr(x), x.stride(0), B, H, W, shift, d, heads, L.dptr(keep[0]), L.dptr(keep[1]),
-                                     L.dptr(keep[2]), L.dptr(keep[3]), L.dptr(keep[4]), L.dptr(out), sp, sb,
+                                     L.dptr(keep[2]), L.dptr(keep[3]), L.dptr(keep[4]), L.dptr(out), int(out_bf16), sp, sb,
                                      L.current_stream_ptr()), "op_qkv_attn")
     return out
 
@@ -309,13 +310,14 @@ def mlp_block(attn: torch.Tensor, shortcut: torch.Tensor, w_proj, b_proj, ln_g, 
               act: int = L.ACT_LRELU, slope: float = 0.2, alpha: float = 1.0, residual: Optional[torch.Tensor] = None,
               out: Optional[torch.Tensor] = None, out_offset: int = 0, fm: int = 0) -> torch.Tensor:
     """Second half of a Swin block + the RDG's 1x1 adjust conv in ONE launch (``srad_op_mlp_block``; src/drct.py:300,
-    509-510, 184-190, 389-396).  attn [M, d], shortcut [M, >=d]; returns / fills out[:, out_offset:out_offset+no]."""
+    509-510, 184-190, 389-396).  attn [M, d] (crosses the boundary as bf16 - the operand the MFMA takes; an fp32 tensor is
+    rounded here), shortcut [M, >=d]; returns / fills out[:, out_offset:out_offset+no]."""
     _need_cuda(attn, shortcut, w_proj, w_fc1, w_fc2, w_adj)
     M, d = attn.shape
     m, no = w_fc1.shape[0], w_adj.shape[0]
     f = lambda t: t.detach().float().contiguous()
     keep = [f(w_proj), f(b_proj), f(ln_g), f(ln_b), f(w_fc1), f(b_fc1), f(w_fc2), f(b_fc2), f(w_adj.reshape(no, d)), f(b_adj)]
-    attn = f(attn)
+    attn = attn.detach().to(torch.bfloat16).contiguous()
     if out is None:
         out = torch.empty(M, no, dtype=torch.float32, device=attn.device)
     sbuf, sp, sb = _scratch(L.lib().srad_op_swin_scratch_bytes(d, 1, m, no), attn.device)

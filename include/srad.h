@@ -234,15 +234,17 @@ int srad_op_layernorm(const float* x, int ldx, float* y, int ldy, int rows, int 
  *   srad_op_qkv_attn : norm1 -> attn.qkv -> cyclic shift + window partition -> softmax(q k^T * scale + relative position
  *                      bias + 0/-100 shift mask) v -> window reverse + shift back
  *                      (SwinTransformerBlock.forward src/drct.py:477-504 up to attn.proj; WindowAttention.forward 271-299)
- *                      x [B*H*W][ldx] (columns [0,d)) , w_qkv [3d][d], b_qkv [3d], table [225][heads] -> out [B*H*W][d]
+ *                      x [B*H*W][ldx] (columns [0,d)) , w_qkv [3d][d], b_qkv [3d], table [225][heads] -> out [B*H*W][d],
+ *                      fp32, or bf16 with out_bf16 = 1 (the form the engines hand to the second half)
  *   srad_op_mlp_block: x1 = shortcut + attn.proj(attn); x2 = x1 + mlp(norm2(x1)) (src/drct.py:300, 509-510, 184-190), then
  *                      the RDG's 1x1 adjust conv: y[:, yoff:yoff+no] = act(adjust(x2) + b) * alpha (+ r) (src/drct.py:389-396)
- *                      fm = token rows per workgroup (16 | 32 | 64, 0 = the engine's choice for M) */
+ *                      fm = token rows per workgroup (16 | 32 | 64, 0 = the engine's choice for M); attn is a bf16 [M][d]
+ *                      array: the first half's output in the form the MFMA takes it */
 size_t srad_op_swin_scratch_bytes(int d, int heads, int m, int no);
 int srad_op_qkv_attn(const float* x, int ldx, int B, int H, int W, int shift, int d, int heads, const float* ln_g,
-                     const float* ln_b, const float* w_qkv, const float* b_qkv, const float* table, float* out, void* scratch,
-                     size_t scratch_bytes, void* stream);
-int srad_op_mlp_block(int M, int d, int m, int no, int fm, const float* attn, const float* shortcut, int ld_short,
+                     const float* ln_b, const float* w_qkv, const float* b_qkv, const float* table, void* out, int out_bf16,
+                     void* scratch, size_t scratch_bytes, void* stream);
+int srad_op_mlp_block(int M, int d, int m, int no, int fm, const void* attn, const float* shortcut, int ld_short,
                       const float* w_proj, const float* b_proj, const float* ln_g, const float* ln_b, const float* w_fc1,
                       const float* b_fc1, const float* w_fc2, const float* b_fc2, const float* w_adj, const float* b_adj, int act,
                       float slope, float alpha, const float* r, int ldr, float* y, int ldy, int yoff, void* scratch,
@@ -312,13 +314,14 @@ int srad_bench_gemm(int precision, const float* x, int ldx, int B, int Hi, int W
                     int ntaps, int stride, const float* bias, const float* ln_g, const float* ln_b, int act,
                     const float* r, int ldr, float* y, int ldy, int hsplit_hd, int hsplit_hdp, void* scratch,
                     size_t scratch_bytes, int iters, float* us_out, void* stream);
-int srad_bench_mlp_block(int M, int d, int m, int no, const float* attn, const float* shortcut, float* y,
+int srad_bench_mlp_block(int M, int d, int m, int no, const void* attn /* bf16 [M][320] */, const float* shortcut, float* y,
                          const float* w_fp32, void* scratch, size_t scratch_bytes, int dbg, int iters, float* us_out,
                          void* stream);
 int srad_bench_window_attn(int precision, const float* qkv, float* out, const float* table, int B, int H, int W, int ws,
                            int shift, int d, int heads, int hdp, int iters, float* us_out, void* stream);
 int srad_bench_qkv_attn(const float* x, int ldx, int B, int H, int W, int shift, int d, int heads, const float* w_fp32,
-                        float* out, void* scratch, size_t scratch_bytes, int iters, float* us_out, void* stream);
+                        void* out /* written as bf16 [B*H*W][d] */, void* scratch, size_t scratch_bytes, int iters, float* us_out,
+                        void* stream);
 /* tools/wgrad_bench.py: one Swin block's five weight gradients as the training step issues them (one deferred launch +
  * the reduce), `iters` times; storage bit 0 / 1: the X / dY operands are bf16. */
 int srad_bench_wgrad_block(int M, int d, int hidden, int KA, int storage, const void* xbuf, const void* ybuf, float* dw,

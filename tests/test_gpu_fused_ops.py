@@ -69,6 +69,10 @@ def test_qkv_attn_kernel_matches_oracle(d, heads, hidden, shift, B, H, W):
     print(f"qkv_attn d={d} heads={heads} shift={shift} {B}x{H}x{W}: rel err {e:.2e}")
     assert e < BAR, e
     assert not torch.isnan(out).any()
+    # the bf16 hand-off the engines use (qkv_attn -> mlp_block) is the same values, rounded once
+    out_h = ops.qkv_attn(xg, sd["norm1.weight"].cuda(), sd["norm1.bias"].cuda(), sd["attn.qkv.weight"].cuda(), sd["attn.qkv.bias"].cuda(),
+                         sd["attn.relative_position_bias_table"].cuda(), B, H, W, shift, heads, out_bf16=True)
+    assert out_h.dtype == torch.bfloat16 and torch.equal(out_h, out.to(torch.bfloat16))
 
 
 def test_qkv_attn_check_is_sensitive_to_bias_and_mask():

@@ -3,7 +3,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from srad_amd import _lib as L
 dev = torch.device("cuda:0")
 for M in (4096, 8192):
-    attn = torch.randn(M, 320, device=dev); short = torch.randn(M, 320, device=dev); y = torch.empty(M, 320, device=dev)
+    attn = torch.randn(M, 320, device=dev).to(torch.bfloat16); short = torch.randn(M, 320, device=dev); y = torch.empty(M, 320, device=dev)
     w = torch.randn(512 * 512, device=dev) * 0.05
     scratch = torch.empty(16 << 20, dtype=torch.uint8, device=dev); off = (-scratch.data_ptr()) % 256
     s = torch.cuda.Stream()

@@ -11,7 +11,7 @@ from srad_amd import _lib as L  # noqa: E402
 
 dev = torch.device("cuda:0")
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-attn = torch.randn(M, 320, device=dev)
+attn = torch.randn(M, 320, device=dev).to(torch.bfloat16)
 short = torch.randn(M, 320, device=dev)
 y = torch.empty(M, 320, device=dev)
 w = torch.randn(512 * 512, device=dev) * 0.05

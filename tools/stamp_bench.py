@@ -17,7 +17,7 @@ NAMES = ["entry", "loads issued", "vectors arrived", "proj: prev done", "proj: b
          "adj: barrier", "adj: MFMAs issued", "end"]
 dev = torch.device("cuda:0")
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-attn = torch.randn(M, 320, device=dev)
+attn = torch.randn(M, 320, device=dev).to(torch.bfloat16)
 short = torch.randn(M, 320, device=dev)
 y = torch.empty(M, 320, device=dev)
 w = torch.randn(1024 * 1024, device=dev) * 0.05          # >= 3 d x d floats for the widest block (924 x 308)
