@@ -20,7 +20,7 @@ struct srad_drct {
   int pe_g, pe_b, norm_g, norm_b;
   std::vector<SwinW> blocks;      // n_rdg * 5
   int dmax, hmax, qkvmax;         // widest block dim / hidden / head-padded qkv row
-  std::vector<char> qkv_saved_h;  // per Swin block: the last training forward saved q | k | v as bf16 (attn_all_bf16)
+  std::vector<char> saved_h;      // per Swin block, what the last training forward saved as bf16: 1 q | k | v, 2 the fc1 pre-activation (plan_block)
   bool fuse_mlp = true;           // bf16: second half of each Swin block as one launch (kernels_fused.hip)
   GraphCache gc;
   TrainState ts;                  // training (drct_train.hip)

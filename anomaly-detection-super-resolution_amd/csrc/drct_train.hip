@@ -101,19 +101,39 @@ WgradParams wgrad_of(const srad_drct* h, const ConvW& c, float* flat_grad, const
 void geom(GemmParams& p, int H, int W) { p.Hi = p.Ho = H; p.Wi = p.Wo = W; }
 void geom(WgradParams& p, int H, int W) { p.Hi = p.Ho = H; p.Wi = p.Wo = W; }
 
-// Does this Swin block's attention backward run in its all-bf16 form (window_attn_bwd_h_kernel)?  It does when every kernel
-// around it is the fused bf16 one: the forward then saves q | k | v as bf16, mlp_bwd writes dO as bf16 per head and both
-// readers of dqkv take bf16.  Forward and backward must agree, so both ask here.
-bool attn_all_bf16(const srad_drct* h, const SwinW& sw, int H, int W, int T, int no) {
+// Which kernels a Swin block's backward takes, and with them the storage form of what the forward saves for it.  The
+// training forward and the backward both ask here (same inputs -> same answer); the forward records what it saved and the
+// backward refuses a mismatch (SRAD_NO_FUSE changing between the two).
+struct BlockPlan {
+  bool xh;         // fused forward (qkv_attn + mlp_block): LN1(x), attention output, LN2(.), GELU(.), block output saved as bf16
+  bool fuse_mlp;   // mlp_bwd: fc2 / fc1 data gradients + LayerNorm2 backward in one launch
+  bool fuse_proj;  // ... with the projection's data gradient behind them
+  bool fuse_adj;   // ... and the adjust conv's in front
+  bool fuse_qkv;   // lin_ln_bwd: qkv data gradient + LayerNorm1 backward in one launch
+  bool attn_h;     // all-bf16 attention backward: q | k | v saved as bf16, dO as bf16 per head, dqkv as bf16
+  bool yh_dh;      // bf16-output mlp_bwd (32-row instances): dh (and dO) as bf16, the fc1 pre-activation SAVED as bf16
+  bool yh_dx2;     // ... and the dx2 copy (times its DropPath factor)
+  bool yh_qkv;     // dqkv as bf16 for both of its readers
+};
+BlockPlan plan_block(const srad_drct* h, const SwinW& sw, int H, int W, int T, int KA) {
   const srad_drct_config& c = h->cfg;
   const int prec = h->pt.prec, d = sw.d, hd = d / sw.heads;
-  if (prec != SRAD_PREC_BF16 || getenv("SRAD_NO_FUSE") != nullptr || getenv("SRAD_ATTN_BWD_F32IO") != nullptr) return false;
-  if (!(h->fuse_mlp && srad_qkv_attn_supported(prec, c.window_size, H, W, d, sw.heads) && srad_mlp_block_supported(prec, T, d, sw.hidden, no)))
-    return false;
   const TrainState& ts = h->ts;
-  if (ts.tf_off.empty() || ts.tf_off[sw.fc1.w] < 0 || ts.tf_off[sw.fc2.w] < 0 || ts.tf_off[sw.proj.w] < 0 || ts.tf_off[sw.qkv.w] < 0) return false;
-  return srad_mlp_bwd_supported(prec, T, d, sw.hidden, 0) && srad_mlp_bwd_bf16_out(T) && srad_lin_ln_bwd_supported(prec, T, 3 * d, d) &&
-         hd <= 32 && hd % 2 == 0 && c.window_size == 8;
+  const bool fused_bwd = prec == SRAD_PREC_BF16 && getenv("SRAD_NO_FUSE") == nullptr;
+  auto tf = [&](int w) { return !ts.tf_off.empty() && ts.tf_off[w] >= 0; };
+  BlockPlan b{};
+  b.xh = h->fuse_mlp && srad_qkv_attn_supported(prec, c.window_size, H, W, d, sw.heads) && srad_mlp_block_supported(prec, T, d, sw.hidden, KA);
+  b.fuse_mlp = fused_bwd && tf(sw.fc1.w) && tf(sw.fc2.w) && srad_mlp_bwd_supported(prec, T, d, sw.hidden, 0);
+  b.fuse_proj = b.fuse_mlp && tf(sw.proj.w);
+  b.fuse_adj = b.fuse_mlp && tf(sw.adjust.w) && srad_mlp_bwd_supported(prec, T, d, sw.hidden, KA);
+  b.fuse_qkv = fused_bwd && tf(sw.qkv.w) && srad_lin_ln_bwd_supported(prec, T, 3 * d, d);
+  b.yh_qkv = b.xh && b.fuse_qkv;
+  b.attn_h = b.xh && b.fuse_proj && b.yh_qkv && srad_mlp_bwd_bf16_out(T) && hd <= 32 && hd % 2 == 0 && c.window_size == 8 &&
+             getenv("SRAD_ATTN_BWD_F32IO") == nullptr;
+  // (the bf16-output mlp_bwd writes dO as bf16 too, which only the all-bf16 attention backward reads)
+  b.yh_dh = b.xh && b.fuse_mlp && srad_mlp_bwd_bf16_out(T) && (b.attn_h || !b.fuse_proj);
+  b.yh_dx2 = b.yh_dh && b.fuse_adj;
+  return b;
 }
 int attn_hp(const SwinW& sw) { return srad_round_up(sw.d / sw.heads, 8); }
 
@@ -227,8 +247,8 @@ int srad_drct_forward_train(srad_drct_t* h, const float* x, int B, int H, int W,
       const float* ks1 = keep_scale ? keep_scale + (size_t)(2 * bi) * B : nullptr;
       const float* ks2 = keep_scale ? keep_scale + (size_t)(2 * bi + 1) * B : nullptr;
       const int no = k < 4 ? c.gc : E;
-      if (h->qkv_saved_h.size() != h->blocks.size()) h->qkv_saved_h.assign(h->blocks.size(), 0);
-      h->qkv_saved_h[bi] = 0;
+      if (h->saved_h.size() != h->blocks.size()) h->saved_h.assign(h->blocks.size(), 0);
+      h->saved_h[bi] = 0;
       if (h->fuse_mlp && srad_qkv_attn_supported(prec, c.window_size, H, W, d, sw.heads) &&
           srad_mlp_block_supported(prec, T, d, sw.hidden, no)) {
         // bf16: the two fused launches of the inference path, which also leave what the backward needs
@@ -241,8 +261,9 @@ int srad_drct_forward_train(srad_drct_t* h, const float* x, int B, int H, int W,
         // the tensors only the weight gradients read (LN1(x), LN2(.), GELU(.), the block output) are left as bf16, which is
         // what the MFMA would round them to anyway: half the bytes written here and read (3 - 9 times each) by wgrad
         a.save_xn_h = reinterpret_cast<__bf16*>(sv.xn1); a.hdp = hdp;
-        h->qkv_saved_h[bi] = attn_all_bf16(h, sw, H, W, T, no);
-        if (h->qkv_saved_h[bi]) { a.save_qkv_h = reinterpret_cast<__bf16*>(sv.qkv); a.hp_h = attn_hp(sw); }   // as the MFMA took them
+        const BlockPlan bp = plan_block(h, sw, H, W, T, no);
+        h->saved_h[bi] = (char)((bp.attn_h ? 1 : 0) | (bp.yh_dh ? 2 : 0));
+        if (bp.attn_h) { a.save_qkv_h = reinterpret_cast<__bf16*>(sv.qkv); a.hp_h = attn_hp(sw); }   // as the MFMA took them
         else a.save_qkv = sv.qkv;
         SRAD_TRY(srad_launch_qkv_attn(a, s));
         MlpBlockParams q{};
@@ -253,7 +274,9 @@ int srad_drct_forward_train(srad_drct_t* h, const float* x, int B, int H, int W,
         q.b_proj = h->pt.fptr(sw.proj.b); q.b_fc1 = h->pt.fptr(sw.fc1.b); q.b_fc2 = h->pt.fptr(sw.fc2.b); q.b_adj = h->pt.fptr(sw.adjust.b);
         q.ln_g = h->pt.fptr(sw.n2g); q.ln_b = h->pt.fptr(sw.n2b);
         q.rs1 = ks1; q.rs2 = ks2; q.rps = HW;
-        q.save_x1 = sv.x1; q.save_hpre = sv.hpre;
+        q.save_x1 = sv.x1;
+        if (bp.yh_dh) q.save_hpre_h = reinterpret_cast<__bf16*>(sv.hpre);     // GELU' takes it as bf16 in the bf16-output mlp_bwd
+        else q.save_hpre = sv.hpre;
         q.save_xn2_h = reinterpret_cast<__bf16*>(sv.xn2); q.save_hact_h = reinterpret_cast<__bf16*>(sv.hact); q.save_x2_h = reinterpret_cast<__bf16*>(sv.x2);
         if (k < 4) { q.act = SRAD_ACT_LRELU; q.slope = 0.2f; q.alpha = 1.f; q.Y = cur; q.ldy = D; q.yoff = d; }
         else { q.act = SRAD_ACT_NONE; q.alpha = 0.2f; q.R = cur; q.ldr = D; q.Y = nxt; q.ldy = D; q.yoff = 0; }
@@ -350,8 +373,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
   // the weight gradients, which nothing in the backward waits for, run on a side stream and fill the idle CUs.
   // Set SRAD_BWD_ONE_STREAM=1 to keep everything on the caller's stream.
   static const bool one_stream = getenv("SRAD_BWD_ONE_STREAM") != nullptr;
-  // bf16 mode: the MLP branch's two data gradients + LayerNorm2 backward as one kernel (SRAD_NO_FUSE=1: separate launches)
-  const bool fused_bwd = prec == SRAD_PREC_BF16 && getenv("SRAD_NO_FUSE") == nullptr;
+  // (bf16 mode: which fused backward kernels a block takes is plan_block's decision; SRAD_NO_FUSE=1: separate launches)
   // (default priority: a low-priority side stream gained nothing here, and a process that had created one ran later
   //  hipGraph replays of other models at half speed - measured with bench.py's C3 leg)
   if (!one_stream && !h->side) SRAD_CHECK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
@@ -451,20 +473,24 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       const int d = sw.d, hdp = hdp_of(d, sw.heads);
       const float* ks1 = keep_scale ? keep_scale + (size_t)(2 * bi) * B : nullptr;
       const float* ks2 = keep_scale ? keep_scale + (size_t)(2 * bi + 1) * B : nullptr;
-      // the fused training forward left this block's wgrad-only activations as bf16 (see srad_drct_forward_train)
-      const bool xh = h->fuse_mlp && srad_qkv_attn_supported(prec, c.window_size, H, W, d, sw.heads) &&
-                      srad_mlp_block_supported(prec, T, d, sw.hidden, k < 4 ? c.gc : E);
+      const int KA = k < 4 ? c.gc : E;
+      // which kernels this block takes and what form the forward left its saved tensors in (see srad_drct_forward_train)
+      const BlockPlan bp = plan_block(h, sw, H, W, T, KA);
+      const bool xh = bp.xh, fuse_mlp = bp.fuse_mlp, fuse_proj = bp.fuse_proj, fuse_adj = bp.fuse_adj, attn_h = bp.attn_h;
+      const bool yh_dh = bp.yh_dh, yh_dx2 = bp.yh_dx2, yh_qkv = bp.yh_qkv;
+      {
+        const int saved = bi < (int)h->saved_h.size() ? h->saved_h[bi] : 0;
+        if (xh && saved != ((attn_h ? 1 : 0) | (yh_dh ? 2 : 0)))
+          return srad_set_error(SRAD_ERR_STATE, "drct_backward: block %d was saved by the forward for other backward kernels than this call "
+                                "takes (q|k|v %s, fc1 pre-activation %s): SRAD_NO_FUSE / SRAD_ATTN_BWD_F32IO must not change between the two",
+                                bi, (saved & 1) ? "bf16" : "fp32", (saved & 2) ? "bf16" : "fp32");
+      }
       const int set = blk_count & 1;                       // temporaries + partial workspace of this block
       if (side != s && side_done[set]) SRAD_CHECK_HIP(hipStreamWaitEvent(s, side_done[set], 0));   // block n - 2 fully consumed
       wq.ws = wq_base + (size_t)set * wq_half; wq.ws_floats = wq_half;
       float *dx2 = w.dx2[set], *dx1 = w.dx1[set], *dh = w.dh[set], *dqkv = w.dqkv[set];
       // ---- adjust_k: 1x1 conv (+ LeakyReLU 0.2 | * 0.2)                        (drct.py:389-393)
       // ---- MLP branch: x2 = x1 + rs2 * fc2(gelu(fc1(LN2(x1))))                 (drct.py:510, 184-190)
-      const int KA = k < 4 ? c.gc : E;
-      const bool fuse_mlp = fused_bwd && h->ts.tf_off[sw.fc1.w] >= 0 && h->ts.tf_off[sw.fc2.w] >= 0 &&
-                            srad_mlp_bwd_supported(prec, T, d, sw.hidden, 0);
-      const bool fuse_proj = fuse_mlp && h->ts.tf_off[sw.proj.w] >= 0;      // ... and the projection's data gradient behind them
-      const bool fuse_adj = fuse_mlp && h->ts.tf_off[sw.adjust.w] >= 0 && srad_mlp_bwd_supported(prec, T, d, sw.hidden, KA);
       const float* dA; int ldA; float aalpha = 1.f;
       if (k < 4) {
         if (!fuse_adj) SRAD_TRY(srad_launch_dact(gc + d, D, cur + d, D, w.dA[set], c.gc, T, c.gc, 0.2f, s));
@@ -484,12 +510,6 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       }
       // the gradients only the weight gradients (and bf16 MFMA stagings) read go out as bf16 too: dh always when the MLP
       // backward is fused, dx2 (pre-multiplied by its DropPath factor) when the adjust prologue computes it in that launch
-      const bool attn_h = attn_all_bf16(h, sw, H, W, T, KA);      // then fuse_proj, yh_dh and yh_qkv (below) all hold
-      if (attn_h != (bi < (int)h->qkv_saved_h.size() && h->qkv_saved_h[bi] != 0))
-        return srad_set_error(SRAD_ERR_STATE, "drct_backward: the forward saved q | k | v of block %d as %s but this backward reads %s "
-                              "(SRAD_NO_FUSE / SRAD_ATTN_BWD_F32IO must not change between the two)", bi, attn_h ? "fp32" : "bf16", attn_h ? "bf16" : "fp32");
-      // (the bf16-output mlp_bwd writes dO as bf16 too, which only the all-bf16 attention backward reads)
-      const bool yh_dh = xh && fuse_mlp && srad_mlp_bwd_bf16_out(T) && (attn_h || !fuse_proj), yh_dx2 = yh_dh && fuse_adj;
       {
         WgradParams g = wgrad_of(h, sw.fc2, G, dx2, d, 0, sv.hact, sw.hidden, T);
         g.row_scale = ks2; g.rps = HW; g.x_bf16 = xh; g.dy_bf16 = yh_dx2;
@@ -503,6 +523,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
         MlpBwdParams mb{};
         mb.M = T; mb.d = d; mb.m = sw.hidden; mb.dx2 = dx2; mb.rs2 = ks2; mb.rps = HW;
         mb.w_fc2t = h->ts.tarena + h->ts.tf_off[sw.fc2.w]; mb.hpre = sv.hpre; mb.dh = dh;
+        if (yh_dh) mb.hpre_h = reinterpret_cast<const __bf16*>(sv.hpre);
         if (yh_dh) mb.dh_h = reinterpret_cast<__bf16*>(dh);
         if (yh_dx2) mb.dx2s_h = reinterpret_cast<__bf16*>(dx2);
         mb.w_fc1t = h->ts.tarena + h->ts.tf_off[sw.fc1.w]; mb.x1 = sv.x1; mb.ln_g = h->pt.fptr(sw.n2g); mb.dx1 = dx1;
@@ -535,7 +556,6 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
         }
       }
       // dqkv as bf16 when both of its readers take it that way (the fused qkv + LayerNorm1 backward and the weight gradient)
-      const bool yh_qkv = xh && fused_bwd && h->ts.tf_off[sw.qkv.w] >= 0 && srad_lin_ln_bwd_supported(prec, T, 3 * d, d);
       // ---- attention branch: x1 = x + rs1 * proj(attn(LN1(x)))                  (drct.py:477-509)
       {
         WgradParams g = wgrad_of(h, sw.proj, G, dx1, d, 0, sv.attn, d, T);
@@ -559,7 +579,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
         g.x_bf16 = xh; g.dy_bf16 = yh_qkv;
         SRAD_TRY(srad_launch_wgrad_deferred(prec, g, wq, side));
       }
-      if (fused_bwd && h->ts.tf_off[sw.qkv.w] >= 0 && srad_lin_ln_bwd_supported(prec, T, 3 * d, d)) {
+      if (bp.fuse_qkv) {
         // gc[:, :d] += dx1 + dLN1(dqkv . Wqkv): data gradient + LayerNorm1 backward in one launch (kernels_fused_bwd.hip)
         LinLnBwdParams lb{};
         lb.M = T; lb.K = 3 * d; lb.d = d; lb.dY = dqkv; lb.ld_dy = 3 * d; lb.dy_bf16 = yh_qkv; lb.w_t = h->ts.tarena + h->ts.tf_off[sw.qkv.w];

@@ -300,6 +300,11 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     for (int rt = 0; rt < NRT; ++rt) {
       f32x4 v = c[rt] + b1;
       if (p.save_hpre && c4 < m) *reinterpret_cast<f32x4*>(p.save_hpre + (size_t)(m0 + rt * 16 + fr) * m + c4) = v;
+      if (p.save_hpre_h && c4 < m) {
+        bf16x4 hq;
+        hq[0] = (__bf16)v[0]; hq[1] = (__bf16)v[1]; hq[2] = (__bf16)v[2]; hq[3] = (__bf16)v[3];
+        *reinterpret_cast<bf16x4*>(p.save_hpre_h + (size_t)(m0 + rt * 16 + fr) * m + c4) = hq;
+      }
       if (!(dbg & 4)) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);

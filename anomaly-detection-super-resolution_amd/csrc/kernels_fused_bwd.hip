@@ -264,12 +264,16 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
   }
   // every group's fc1 pre-activations now: they come from HBM (written a whole forward ago) and a group is only one
   // or two stages long, so a load issued at its start would be waited for in full at its end
-  f32x4 hp[GM][NRT];
+  typedef typename std::conditional<HOUT, u32x2, f32x4>::type hp_t;     // the bf16-output instances read it as bf16 (half the
+  hp_t hp[GM][NRT];                                                      // bytes, half of the registers held across the kernel)
 #pragma unroll
   for (int g = 0; g < GM; ++g) {
     const int c4 = min(col4_of(g), m - 4);
 #pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) hp[g][rt] = *reinterpret_cast<const f32x4*>(p.hpre + (size_t)(m0 + rt * 16 + fr) * m + c4);
+    for (int rt = 0; rt < NRT; ++rt) {
+      if constexpr (HOUT) hp[g][rt] = *reinterpret_cast<const u32x2*>(p.hpre_h + (size_t)(m0 + rt * 16 + fr) * m + c4);
+      else hp[g][rt] = *reinterpret_cast<const f32x4*>(p.hpre + (size_t)(m0 + rt * 16 + fr) * m + c4);
+    }
   }
   load_w(std::integral_constant<int, 0>{}, w_reg[0]);
   if (tid < 384) v_g[tid] = gq;
@@ -339,9 +343,15 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
         const int c4 = col4_of(g);
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt) {
-          f32x4 v;
+          f32x4 v, hv;
+          if constexpr (HOUT) {
+            const bf16x4 hb = __builtin_bit_cast(bf16x4, hp[g][rt]);
+            hv = f32x4{(float)hb[0], (float)hb[1], (float)hb[2], (float)hb[3]};
+          } else {
+            hv = hp[g][rt];
+          }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = c[rt][e] * rs2v[rt] * dgelu_fast(hp[g][rt][e]);
+          for (int e = 0; e < 4; ++e) v[e] = c[rt][e] * rs2v[rt] * dgelu_fast(hv[e]);
           v = c4 < m ? v : z4;                         // m % 4 == 0
           if constexpr (HOUT) {
             if (c4 < m) {
@@ -600,7 +610,8 @@ int launch_bwd_fm(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream) {
 template <int GD, int KCD, int GM, int KCM, int KCA>
 int launch_bwd(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream) {
   if (p.dh_h) {                                  // bf16 outputs for the weight gradients: the 32-row instances (srad_mlp_bwd_bf16_out)
-    SRAD_REQUIRE(srad_mlp_bwd_bf16_out(p.M) && (KCA == 0 || p.dx2s_h), "mlp_bwd: bf16 outputs need M >= 8192, M %% 32 == 0 (and the dx2 copy with the adjust prologue)");
+    SRAD_REQUIRE(srad_mlp_bwd_bf16_out(p.M) && (KCA == 0 || p.dx2s_h) && p.hpre_h && ((uintptr_t)p.hpre_h & 7) == 0,
+                 "mlp_bwd: bf16 outputs need M >= 8192, M %% 32 == 0, the fc1 pre-activation as bf16 (and the dx2 copy with the adjust prologue)");
     SRAD_REQUIRE(!p.w_projt || (p.dO_h && p.dO_heads > 0 && p.d % p.dO_heads == 0 && (p.d / p.dO_heads) % 2 == 0 && p.dO_hp % 8 == 0 &&
                                 p.dO_hp >= p.d / p.dO_heads),
                  "mlp_bwd: the bf16-output instances write dO per head ([M][heads][hp], even head dim, hp %% 8 == 0)");

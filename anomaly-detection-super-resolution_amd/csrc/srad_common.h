@@ -188,6 +188,7 @@ struct MlpBlockParams {
   // ---- training (all optional): DropPath factors of the two residual branches and the tensors the backward needs ----
   const float *rs1, *rs2; int rps;       // per-sample factors (row m belongs to sample m / rps), null = 1
   float *save_x1, *save_xn2, *save_hpre, *save_hact, *save_x2;   // [M][d] x + attn branch, [M][d] LayerNorm2, [M][m] fc1 pre-activation, [M][m] GELU, [M][d] block output
+  __bf16 *save_hpre_h;                                           // the fc1 pre-activation as bf16 instead (the bf16-output mlp_bwd's GELU' takes it so)
   __bf16 *save_xn2_h, *save_hact_h, *save_x2_h;                  // bf16 forms of the three only the weight gradients read (used instead of the fp32 ones when set)
 };
 bool srad_mlp_block_supported(int prec, int M, int d, int m, int no);
@@ -298,6 +299,7 @@ struct MlpBwdParams {
   const float* rs2; int rps;            // DropPath factor of the MLP branch per sample (null = 1)
   const void* w_fc2t;                   // fragments of fc2.weight^T: rows = hidden, k = d
   const float* hpre;                    // [M][m] fc1 pre-activation
+  const __bf16* hpre_h = nullptr;       // ... as bf16: what the bf16-output instances (dh_h set) read instead
   float* dh;                            // [M][m]
   __bf16 *dh_h, *dx2s_h;                // bf16 forms for the weight gradients (used instead of dh / the dx2 copy when set):
                                         // dh, and dx2 ALREADY multiplied by the MLP branch's DropPath factor (KA > 0 only)
