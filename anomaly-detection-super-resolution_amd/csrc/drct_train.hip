@@ -489,6 +489,9 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       if (side != s && side_done[set]) SRAD_CHECK_HIP(hipStreamWaitEvent(s, side_done[set], 0));   // block n - 2 fully consumed
       wq.ws = wq_base + (size_t)set * wq_half; wq.ws_floats = wq_half;
       float *dx2 = w.dx2[set], *dx1 = w.dx1[set], *dh = w.dh[set], *dqkv = w.dqkv[set];
+      // with the adjust prologue fused the dx2 buffer only holds the bf16 copy (its first half): dx1 * rs1 as bf16 goes behind it
+      const bool yh_dx1 = yh_dx2 && fuse_proj;
+      __bf16* const dx1s_h = reinterpret_cast<__bf16*>(dx2) + (size_t)T * d;
       // ---- adjust_k: 1x1 conv (+ LeakyReLU 0.2 | * 0.2)                        (drct.py:389-393)
       // ---- MLP branch: x2 = x1 + rs2 * fc2(gelu(fc1(LN2(x1))))                 (drct.py:510, 184-190)
       const float* dA; int ldA; float aalpha = 1.f;
@@ -500,7 +503,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       }
       {
         WgradParams g = wgrad_of(h, sw.adjust, G, dA, ldA, 0, sv.x2, d, T);
-        g.alpha = aalpha; g.x_bf16 = xh;
+        g.alpha = aalpha; g.x_bf16 = xh; g.dy_bf16 = yh_dx2 && k < 4;      // (mlp_bwd writes w.dA as bf16 then)
         SRAD_TRY(srad_launch_wgrad_deferred(prec, g, wq, side));
         if (!fuse_adj) {
           GemmParams p = dgrad_gemm(h, sw.adjust, dA, ldA, T, dx2, d);
@@ -530,11 +533,15 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
         mb.dgamma = G + h->ts.flat_off[sw.n2g]; mb.dbeta = G + h->ts.flat_off[sw.n2b];
         if (fuse_adj) {   // ... and the adjust conv's data gradient (with its LeakyReLU') in front of them
           mb.KA = KA; mb.w_adjt = h->ts.tarena + h->ts.tf_off[sw.adjust.w]; mb.aalpha = aalpha; mb.slope = 0.2f;
-          if (k < 4) { mb.dA = gc + d; mb.ld_dA = D; mb.y_act = cur + d; mb.ld_y = D; mb.dA_out = w.dA[set]; }
+          if (k < 4) {
+            mb.dA = gc + d; mb.ld_dA = D; mb.y_act = cur + d; mb.ld_y = D; mb.dA_out = w.dA[set];
+            if (yh_dx2) mb.dA_out_h = reinterpret_cast<__bf16*>(w.dA[set]);       // the adjust weight gradient takes it as bf16
+          }
           else { mb.dA = gn; mb.ld_dA = D; }
         }
         if (fuse_proj) { mb.w_projt = h->ts.tarena + h->ts.tf_off[sw.proj.w]; mb.rs1 = ks1; mb.rps = HW; mb.dO = w.dO; }
         if (fuse_proj && yh_dh) { mb.dO_h = reinterpret_cast<__bf16*>(w.dO); mb.dO_heads = sw.heads; mb.dO_hp = attn_hp(sw); }
+        if (yh_dx1) mb.dx1s_h = dx1s_h;
         SRAD_TRY(srad_launch_mlp_bwd(mb, wq, s));
       } else {
         {
@@ -560,6 +567,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       {
         WgradParams g = wgrad_of(h, sw.proj, G, dx1, d, 0, sv.attn, d, T);
         g.row_scale = ks1; g.rps = HW; g.x_bf16 = xh;          // the fused forward left the attention output as bf16
+        if (yh_dx1) { g.dY = reinterpret_cast<const float*>(dx1s_h); g.dy_bf16 = 1; g.row_scale = nullptr; }   // dx1 * rs1 as bf16, from mlp_bwd
         SRAD_TRY(srad_launch_wgrad_deferred(prec, g, wq, side));
         if (!fuse_proj) {
           GemmParams p = dgrad_gemm(h, sw.proj, dx1, d, T, w.dO, d);

@@ -46,7 +46,8 @@ __device__ __forceinline__ float dgelu_fast(float x) {
 template <int NRT, int GD>
 __device__ __forceinline__ void ln_bwd_tail(f32x4 (&dxn)[GD][NRT], f32x4 (&xv)[GD][NRT], const f32x4 (&r2)[GD][NRT],
                                             const float* v_g, float* red, int d, int wave, int fr, int fq, float* out0,
-                                            int ld_out, float* prow, __bf16* a_out = nullptr, int lda_out = 0) {
+                                            int ld_out, float* prow, __bf16* a_out = nullptr, int lda_out = 0,
+                                            __bf16* h_out0 = nullptr, const float* h_scale = nullptr) {
   const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
   auto col4_of = [&](int g) { return FB_SC * g + 16 * wave + 4 * fq; };
   const float invC = 1.0f / (float)d;
@@ -130,6 +131,12 @@ __device__ __forceinline__ void ln_bwd_tail(f32x4 (&dxn)[GD][NRT], f32x4 (&xv)[G
     for (int rt = 0; rt < NRT; ++rt) {
       const f32x4 o4 = (dxn[g][rt] - s1[rt] * invC - xv[g][rt] * (s2[rt] * invC)) * rstd[rt] + r2[g][rt];
       if (c4 < d) *reinterpret_cast<f32x4*>(out0 + (size_t)(rt * 16 + fr) * ld_out + c4) = o4;
+      if (h_out0 && c4 < d) {                                    // and times a per-row factor as bf16 [rows][d]: a weight gradient's operand
+        const f32x4 v = o4 * h_scale[rt];
+        bf16x4 hq;
+        hq[0] = (__bf16)v[0]; hq[1] = (__bf16)v[1]; hq[2] = (__bf16)v[2]; hq[3] = (__bf16)v[3];
+        *reinterpret_cast<bf16x4*>(h_out0 + (size_t)(rt * 16 + fr) * d + c4) = hq;
+      }
       if (a_out) {                                               // the result as the next GEMM's bf16 A tile (zero beyond d)
         const f32x4 v = c4 < d ? o4 : z4;
         bf16x4 h;
@@ -289,8 +296,9 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
           for (int e = 0; e < 4; ++e) v[e] = y_reg[j][e] > 0.f ? v[e] : v[e] * p.slope;
         }
         v = c < p.KA ? v : z4;
-        if (p.dA_out && c < p.KA) *reinterpret_cast<f32x4*>(p.dA_out + (size_t)(m0 + row) * p.KA + c) = v;
         h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+        if (p.dA_out_h) { if (c < p.KA) *reinterpret_cast<bf16x4*>(p.dA_out_h + (size_t)(m0 + row) * p.KA + c) = h; }
+        else if (p.dA_out && c < p.KA) *reinterpret_cast<f32x4*>(p.dA_out + (size_t)(m0 + row) * p.KA + c) = v;
         *reinterpret_cast<bf16x4*>(Aa + row * LDAA + c) = h;
       } else {
         const f32x4 v = c < d ? a_reg[j] : z4;
@@ -395,7 +403,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
     }
   }
   ln_bwd_tail<NRT, GD>(dxn, xv, r2, v_g, red, d, wave, fr, fq, p.dx1 + (size_t)m0 * d, d, part + (size_t)blockIdx.x * (2 * SRAD_LNB_CP),
-                       p.w_projt ? A1 : nullptr, FB_LDA);
+                       p.w_projt ? A1 : nullptr, FB_LDA, (HOUT && p.w_projt && p.dx1s_h) ? p.dx1s_h + (size_t)m0 * d : nullptr, rs1v);
   if (p.w_projt) {
     __syncthreads();                                             // the dx1 tile is complete
     static_for<0, n_proj>([&](auto S) {

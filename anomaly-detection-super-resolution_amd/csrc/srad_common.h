@@ -314,11 +314,13 @@ struct MlpBwdParams {
   const float* y_act; int ld_y;         // the conv's forward output for LeakyReLU' (null: no activation)
   float slope, aalpha;
   float* dA_out;                        // [M][KA] dA (.) lrelu'(y): operand of the conv's weight gradient (null: not needed)
+  __bf16* dA_out_h = nullptr;           // ... written as bf16 instead when set
   const void* w_adjt;                   // fragments of adjust.weight^T: rows = d, k = KA
   // ---- optional epilogue (w_projt != null): the attention projection's data gradient dO = (dx1 . Wproj) * rs1 ----
   const void* w_projt;                  // fragments of proj.weight^T: rows = d, k = d
   const float* rs1;                     // DropPath factor of the attention branch per sample (null = 1; rows per sample = rps)
   float* dO;                            // [M][d]
+  __bf16* dx1s_h = nullptr;             // bf16-output instances: also dx1 times rs1 as bf16 [M][d] (proj's weight-gradient operand)
   __bf16* dO_h = nullptr; int dO_heads = 0, dO_hp = 0;   // bf16-output instances: dO as [M][heads][hp] bf16 instead (column c -> head c / (d / heads))
 };
 bool srad_mlp_bwd_supported(int prec, int M, int d, int m, int KA);
