@@ -104,11 +104,15 @@ int forward_body(srad_drct* h, const float* x, int B, int H, int W, float* y, co
         SRAD_TRY(srad_launch_qkv_attn(a, s));
       } else {
       // norm1 + qkv                                   (drct.py:477, 278)
+        // (64 x 64 windows, bf16: the GEMM leaves q | k | v as the bf16 operands the attention's MFMAs take)
+        float qscale = 1.f;
+        const bool qkv_bf16 = srad_window_attn_bf16_in(prec, c.window_size, sw.shift, d, sw.heads, &qscale);
         {
           const int hdp = hdp_of(d, sw.heads);
           GemmParams p = base_gemm(h, sw.qkv, cur, D, T, w.qkv, 3 * sw.heads * hdp);
           p.hsplit_hd = d / sw.heads; p.hsplit_hdp = hdp;      // head-padded q|k|v rows for the attention kernel
           p.ln_g = h->pt.fptr(sw.n1g); p.ln_b = h->pt.fptr(sw.n1b);
+          if (qkv_bf16) { p.Yh = reinterpret_cast<__bf16*>(w.qkv); p.hsplit_heads = sw.heads; p.hsplit_qscale = qscale; }
           SRAD_TRY(srad_launch_gemm(prec, p, s));
         }
         // shifted-window attention                      (drct.py:481-504, 281-299)
@@ -116,6 +120,7 @@ int forward_body(srad_drct* h, const float* x, int B, int H, int W, float* y, co
           AttnParams a{w.qkv, w.attn, h->pt.fptr(sw.table), B, H, W, c.window_size, sw.shift, d, sw.heads,
                        hdp_of(d, sw.heads)};
           if (mlp_fused) a.out_h = attn_h;
+          if (qkv_bf16) a.qkv_h = reinterpret_cast<const __bf16*>(w.qkv);
           SRAD_TRY(srad_launch_window_attn(prec, a, s));
         }
       }

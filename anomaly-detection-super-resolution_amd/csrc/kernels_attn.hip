@@ -48,8 +48,12 @@ __device__ __forceinline__ void store4(typename AT<PREC>::type* dst, f32x4 v) {
 // the 0 / -100 mask is one per-tile addend - no per-score index arithmetic.  Scores live in the log2 domain (q pre-scaled
 // by log2 e, table staged x log2 e), so the probabilities are bare v_exp_f32.  The softmax was the bound of this kernel
 // (~14 VALU instructions per score against 0.5 - 2 MFMA issue slots); this path needs ~6.
-template <int PREC, int NT_O, bool TBL_LDS, int NW, bool FULL, bool ROW64 = false>
+// QH (ROW64 only): q | k | v arrive as bf16, already scaled / zero-padded / with V's ones column (the QKV GEMM's epilogue did
+// that ONCE per token; staged from fp32 every one of a window's 32 workgroups converted and masked all 4096 keys again -
+// a quarter of this VALU-bound kernel's vector instructions): a chunk is staged with 8-byte loads and plain LDS stores.
+template <int PREC, int NT_O, bool TBL_LDS, int NW, bool FULL, bool ROW64 = false, bool QH = false>
 __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p) {
+  static_assert(!QH || (ROW64 && PREC == SRAD_PREC_BF16), "bf16 input: the one-row-per-chunk bf16 path only");
   using T = typename AT<PREC>::type;
   constexpr int PAD = AT<PREC>::PAD;
   constexpr int HDP = NT_O * 16;
@@ -129,22 +133,29 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
 
   // All global loads are unconditional on clamped addresses and masked by selects afterwards:
   // a load inside a per-element branch is waited for before the next one issues.
-  f32x4 qv[NLQ], kv[NLV], vv[NLV];
+  typedef typename std::conditional<QH, u32x2, f32x4>::type ld_t;     // four columns of a staged row
+  ld_t qv[NLQ], kv[NLV], vv[NLV];
   auto load_tile = [&](const int* toks, int which, auto& dst) {
-    constexpr int NL = sizeof(dst) / sizeof(f32x4);
+    constexpr int NL = sizeof(dst) / sizeof(ld_t);
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const int idx = tid + NT * i;
       const int row = idx / V4R, c = (idx - row * V4R) * 4;
-      dst[i] = *reinterpret_cast<const f32x4*>(p.qkv + (size_t)toks[row] * ldq + (which * heads + h) * hdp + min(c, hdp - 4));
+      const size_t off = (size_t)toks[row] * ldq + (which * heads + h) * hdp + min(c, hdp - 4);
+      if constexpr (QH) dst[i] = *reinterpret_cast<const u32x2*>(p.qkv_h + off);
+      else dst[i] = *reinterpret_cast<const f32x4*>(p.qkv + off);
     }
   };
   auto store_tile = [&](T* base, int first, float mul, const auto& src, bool ones_col = false) {
-    constexpr int NL = sizeof(src) / sizeof(f32x4);
+    constexpr int NL = sizeof(src) / sizeof(ld_t);
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const int idx = tid + NT * i;
       const int row = idx / V4R, c = (idx - row * V4R) * 4;
+      if constexpr (QH) {                                  // ready made: only the tile columns past the stored slot are cleared
+        *reinterpret_cast<u32x2*>(base + row * HS + c) = c < hdp ? src[i] : u32x2{0u, 0u};
+        continue;
+      } else {
       // selects, not a multiply by 0: the pad columns of the head-padded rows (and rows past N) may hold anything,
       // NaN bit patterns included - nobody has to clear them
       const bool rok = first + row < N;
@@ -152,6 +163,7 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = (rok && c + e < hd) ? src[i][e] * mul : ((ones_col && c + e == hd) ? 1.0f : 0.f);
       store4<PREC>(base + row * HS + c, v);
+      }
     }
   };
 
@@ -388,14 +400,16 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
   // 64 x 64 windows with a shift of 0 or 32 (what DRCT builds: window_size // 2): the one-row-per-chunk path
   const bool row64 = PREC == SRAD_PREC_BF16 && NW == 8 && p.ws == 64 && tbl_in_lds && (p.shift == 0 || p.shift == 32) &&
                      getenv("SRAD_NO_ROW64") == nullptr;
+  SRAD_REQUIRE(!p.qkv_h || (row64 && (p.d / p.heads) % 4 != 0 && ((uintptr_t)p.qkv_h & 7) == 0),
+               "window_attn: bf16 q | k | v are for the 64 x 64-window bf16 path (srad_window_attn_bf16_in)");
   if constexpr (PREC == SRAD_PREC_BF16 && NW == 8) {
     if (row64) {
-      kern = window_attn_kernel<PREC, NT_O, true, NW, true, true>;
+      kern = p.qkv_h ? window_attn_kernel<PREC, NT_O, true, NW, true, true, true> : window_attn_kernel<PREC, NT_O, true, NW, true, true>;
       lds = base + (size_t)4 * 128 * 4;            // a four-row ring of the bias table
     }
   }
-  static size_t configured[5] = {0, 0, 0, 0, 0};
-  const int slot = row64 ? 4 : tbl_in_lds * 2 + full;
+  static size_t configured[6] = {0, 0, 0, 0, 0, 0};
+  const int slot = row64 ? (p.qkv_h ? 5 : 4) : tbl_in_lds * 2 + full;
   if (lds > configured[slot]) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured[slot] = lds;
@@ -432,12 +446,21 @@ int launch_attn_prec(const AttnParams& p, hipStream_t stream) {
 
 }  // namespace
 
+bool srad_window_attn_bf16_in(int prec, int ws, int shift, int d, int heads, float* qscale) {
+  // the conditions of launch_attn's one-row-per-chunk path (its table ring always fits), plus a spare column for V's ones
+  const int hd = heads > 0 ? d / heads : 0;
+  const bool ok = prec == SRAD_PREC_BF16 && ws == 64 && (shift == 0 || shift == 32) && hd > 0 && hd <= 128 && hd % 4 != 0 &&
+                  getenv("SRAD_NO_ROW64") == nullptr && getenv("SRAD_ATTN_F32IN") == nullptr;
+  if (ok && qscale) *qscale = (1.0f / sqrtf((float)hd)) * 1.4426950408889634f;
+  return ok;
+}
+
 int srad_launch_window_attn(int prec, const AttnParams& p, hipStream_t stream) {
   SRAD_REQUIRE(p.ws >= 1 && p.ws <= 128, "window_attn: window size %d out of range", p.ws);
   SRAD_REQUIRE(p.H % p.ws == 0 && p.W % p.ws == 0, "window_attn: %dx%d not a multiple of window %d", p.H, p.W, p.ws);
   SRAD_REQUIRE(p.d % p.heads == 0, "window_attn: dim %d not divisible by heads %d", p.d, p.heads);
   SRAD_REQUIRE(p.shift >= 0 && p.shift < p.ws, "window_attn: shift %d must be in [0, ws)", p.shift);
-  SRAD_REQUIRE(p.hdp >= p.d / p.heads && p.hdp % 4 == 0 && ((uintptr_t)p.qkv & 15) == 0,
+  SRAD_REQUIRE(p.hdp >= p.d / p.heads && p.hdp % 4 == 0 && (p.qkv_h || ((uintptr_t)p.qkv & 15) == 0),
                "window_attn: head-padded layout needs hdp %% 4 == 0 and hdp >= head_dim (hdp=%d)", p.hdp);
   return prec == SRAD_PREC_BF16 ? launch_attn_prec<SRAD_PREC_BF16>(p, stream) : launch_attn_prec<SRAD_PREC_F32>(p, stream);
 }

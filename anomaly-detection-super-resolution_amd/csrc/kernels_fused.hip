@@ -114,7 +114,7 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
   // LDS stage, no barrier per stage), from the fragment-major pack (one contiguous kilobyte per wave load).
   constexpr int NSETS = FM == 16 ? SRAD_MLP_NSETS16 : 3;   // 16-row tiles leave ~100 VGPRs free at 2 waves per SIMD: deeper weight stream
   u32x4 w_reg[NSETS][8];
-  auto load_w = [&](auto S, u32x4 (&reg)[8]) {
+  auto load_w = [&](auto S, u32x4 (&reg)[8]) __attribute__((always_inline)) {
     constexpr StageGeo sg = geo(decltype(S)::value);
     const char* w = (const char*)(sg.ph == 0 ? p.w_proj : (sg.ph == 1 ? p.w_fc1 : (sg.ph == 2 ? p.w_fc2 : p.w_adj)));
     const int nreal = sg.ph == 0 ? d : (sg.ph == 1 ? m : (sg.ph == 2 ? d : no));
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     for (int cc = 0; cc < sg.nch; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + cc * step);
   };
   // c[rt] += (A[16 rows][k0 .. k0 + nch*32) . W[16 columns of this wave][..]^T)^T
-  auto mma_stage = [&](const __bf16* A, int lda, int k0, int nch, const u32x4 (&reg)[8], f32x4 (&c)[NRT]) {
+  auto mma_stage = [&](const __bf16* A, int lda, int k0, int nch, const u32x4 (&reg)[8], f32x4 (&c)[NRT]) __attribute__((always_inline)) {
     const __bf16* ar = A + fr * lda + k0 + 8 * fq;
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
@@ -222,13 +222,13 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
   auto col4_of = [&](int g) { return F_SC * g + 16 * wave + 4 * fq; };
   // bf16 quad into the LDS tile and, when `gsave` is set and the quad holds real columns, into the global bf16 copy the
   // weight gradient reads ([M][gld])
-  auto store_bf4 = [&](__bf16* base, int ld, int rt, int c4, f32x4 v, __bf16* gsave = nullptr, int gld = 0, bool real = false) {
+  auto store_bf4 = [&](__bf16* base, int ld, int rt, int c4, f32x4 v, __bf16* gsave = nullptr, int gld = 0, bool real = false) __attribute__((always_inline)) {
     bf16x4 h;
     h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
     *reinterpret_cast<bf16x4*>(base + (rt * 16 + fr) * ld + c4) = h;
     if (gsave && real) *reinterpret_cast<bf16x4*>(gsave + (size_t)(m0 + rt * 16 + fr) * gld + c4) = h;
   };
-  auto epi_proj = [&](auto G, const f32x4 (&c)[NRT]) {
+  auto epi_proj = [&](auto G, const f32x4 (&c)[NRT]) __attribute__((always_inline)) {
     constexpr int g = decltype(G)::value;
     {
       const f32x4 bp = *reinterpret_cast<const f32x4*>(v_bp + min(col4_of(g), 380));
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
       }
     }
   };
-  auto epi_fc1 = [&](int g, const f32x4 (&c)[NRT]) {
+  auto epi_fc1 = [&](int g, const f32x4 (&c)[NRT]) __attribute__((always_inline)) {
     const int c4 = col4_of(g);
     const f32x4 b1 = *reinterpret_cast<const f32x4*>(v_b1 + min(c4, 508));
 #pragma unroll
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
       store_bf4(Hs, F_LDH, rt, c4, c4 < m ? v : f32x4{0.f, 0.f, 0.f, 0.f}, p.save_hact_h, m, c4 < m);      // m % 4 == 0
     }
   };
-  auto epi_fc2 = [&](auto G, const f32x4 (&c)[NRT]) {
+  auto epi_fc2 = [&](auto G, const f32x4 (&c)[NRT]) __attribute__((always_inline)) {
     constexpr int g = decltype(G)::value;
     {
       const f32x4 b2 = *reinterpret_cast<const f32x4*>(v_b2 + min(col4_of(g), 380));
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
       for (int rt = 0; rt < NRT; ++rt) store_bf4(A1, F_LDA, rt, c4, c4 < d ? x1[gg][rt] : f32x4{0.f, 0.f, 0.f, 0.f}, p.save_x2_h, d, c4 < d);
     }
   };
-  auto epi_adj = [&](int g, const f32x4 (&c)[NRT]) {
+  auto epi_adj = [&](int g, const f32x4 (&c)[NRT]) __attribute__((always_inline)) {
     const int c4 = col4_of(g);
     const int cc = min(c4, no - 4);                                 // no % 4 == 0
     const f32x4 ba = *reinterpret_cast<const f32x4*>(v_ba + min(c4, 380));

@@ -366,17 +366,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         for (int e = 0; e < 4; ++e) acc[i][j][e] = fmaxf(acc[i][j][e], 0.f);
   }
   unsigned ycol[NT];                                  // element offset of column j inside an output row
+  float hq[NT];                                       // bf16 head-split output (Yh): the column's factor (q slices: the attention's scale) ...
+  int hpad[NT];                                       // ... and, for a slice's last real column, what its padding starts with (0 / 1), else -1
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = ncol[j];
     ycol[j] = (unsigned)n;
+    hq[j] = 1.f; hpad[j] = -1;
     if constexpr (SPECIAL) {
       if (p.ps == 2) {
         const int c = n >> 2, dy = (n >> 1) & 1, dx = n & 1;
         ycol[j] = (unsigned)((dy * (2 * p.Wo) + dx) * p.ldy + c);
       } else if (p.hsplit_hd > 0) {
-        const int hh = n / p.hsplit_hd;
-        ycol[j] = (unsigned)(hh * p.hsplit_hdp + (n - hh * p.hsplit_hd));
+        const int hh = n / p.hsplit_hd, cc = n - hh * p.hsplit_hd;
+        ycol[j] = (unsigned)(hh * p.hsplit_hdp + cc);
+        hq[j] = hh < p.hsplit_heads ? p.hsplit_qscale : 1.f;
+        if (cc == p.hsplit_hd - 1) hpad[j] = hh >= 2 * p.hsplit_heads ? 1 : 0;
       }
     }
   }
@@ -409,6 +414,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
           else v *= r > 0.f ? 1.f : p.slope;
         }
         if (m_ok && ncol[j] < p.N) {
+          if constexpr (SPECIAL) {
+            if (p.Yh) {                                    // head-split bf16 output for the window attention (see GemmParams::Yh)
+              __bf16* const dst = p.Yh + yrow + ycol[j];
+              dst[0] = (__bf16)(v * hq[j]);
+              if (hpad[j] >= 0) {                          // the slice's last real column: its (at most 3) padding columns go out with it
+                dst[1] = (__bf16)(float)hpad[j];
+                for (int q = 2; q <= p.hsplit_hdp - p.hsplit_hd; ++q) dst[q] = (__bf16)0.f;
+              }
+              continue;
+            }
+          }
           p.Y[yrow + ycol[j]] = v;
         }
       }

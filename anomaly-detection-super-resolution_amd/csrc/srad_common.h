@@ -118,6 +118,10 @@ struct GemmParams {
   int ps;          // 0: plain store, 2: PixelShuffle(2) scatter (N = 4 * ldy-channels)
   int hsplit_hd;   // > 0: column n is stored at (n / hsplit_hd) * hsplit_hdp + n % hsplit_hd, i.e. every
   int hsplit_hdp;  //      head's slice is padded to hsplit_hdp floats (the attention kernel's input layout)
+  // hsplit output as bf16 for the one-row-per-chunk window attention (srad_window_attn_bf16_in): written to Yh instead of Y
+  // (same element offsets), the q slices (heads [0, hsplit_heads)) times hsplit_qscale before rounding, and each slice's
+  // padding columns written too: 0, except 1 in column hsplit_hd of the v slices (P.V then also sums the probabilities)
+  __bf16* Yh = nullptr; int hsplit_heads = 0; float hsplit_qscale = 1.f;
   // ---- training extensions (all off when zero) ----
   int rmode;                 // how R enters: 0 v = act(acc)*alpha*rs + R (residual); 1 v = acc*alpha*rs * gelu'(R);
                              //               2 v = acc*alpha*rs * (R > 0 ? 1 : slope)   (backward through an activation)
@@ -165,8 +169,11 @@ struct AttnParams {
   int B, H, W, ws, shift, d, heads;
   int hdp;            // padded head_dim (multiple of 4, >= d / heads)
   __bf16* out_h = nullptr;   // write the output as bf16 [T][d] instead (the hand-off to mlp_block, which rounds it to bf16 anyway)
+  const __bf16* qkv_h = nullptr;   // q | k | v as bf16 in the same layout, prepared by the QKV GEMM (GemmParams::Yh): q scaled, padding set
 };
 int srad_launch_window_attn(int prec, const AttnParams& p, hipStream_t stream);
+// does the window attention of this geometry take its input as bf16 (the 64 x 64-window path)?  *qscale = what q must carry
+bool srad_window_attn_bf16_in(int prec, int ws, int shift, int d, int heads, float* qscale);
 
 // ------------------------------------------------------------------------------------------
 // Fused second half of a Swin block (kernels_fused.hip): proj + shortcut -> LayerNorm2 -> fc1 -> GELU

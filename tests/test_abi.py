@@ -93,3 +93,19 @@ def test_state_dict_surface_matches_reference_names():
     sd = DRN(O2()).state_dict()
     sp = S.drn_spec(S.DRNConfig.for_scale(4, 3))
     assert list(sd.keys()) == list(sp.keys()) and len(sd) == 664
+
+
+def test_no_kernel_uses_scratch():
+    """Every gfx950 kernel of the shipped library keeps its state in registers: a private-memory (scratch) allocation in the
+    code object's metadata means a register array was spilled or indexed dynamically - a silent 4x on the 64-row mlp_block
+    instances once (tools/check_scratch.py)."""
+    import importlib.util
+    so = os.path.join(ROOT, "anomaly-detection-super-resolution_amd", "libsrad.so")
+    if not os.path.exists(so) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("needs the built library and the ROCm LLVM tools")
+    spec = importlib.util.spec_from_file_location("check_scratch", os.path.join(ROOT, "tools", "check_scratch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    found, total = mod.kernels_with_scratch(so)
+    assert total > 200, total
+    assert not found, found

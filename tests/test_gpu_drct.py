@@ -129,6 +129,29 @@ def test_c5_window64_attention_geometry_matches_oracle():
     assert rel_err(out, ref) < 1e-3, rel_err(out, ref)
 
 
+def test_c5_bf16_qkv_from_the_gemm_matches_fp32_staging(monkeypatch):
+    """64 x 64 windows, bf16: the QKV GEMM writes q | k | v as the bf16 operands of the attention's MFMAs (q scaled, padding
+    zeroed, V's ones column set) and the attention stages them as they are.  Against the same kernel staging fp32 q | k | v
+    itself (SRAD_ATTN_F32IN=1) only the odd bf16 rounding can differ (the scale is computed on the host in one, on the
+    device in the other), and against the CPU oracle it meets the bf16 bar; shifted blocks included (two windows)."""
+    from oracle import sr_ref as R
+    from srad_amd import spec as S
+    cfg = S.DRCTConfig(in_chans=1, img_size=256, window_size=64, upscale=4, n_rdg=1)
+    sd = S.synth_state(S.drct_spec(cfg), seed=64, gain=1.0, cfg=cfg)
+    x = S.synth_image("c5", (1, 1, 64, 128), seed=3)
+    with torch.no_grad():
+        ref = R.drct_forward(sd, torch.from_numpy(x), cfg).numpy()
+        m = build(cfg, sd, "bf16")
+        new = m(torch.from_numpy(x).cuda()).cpu().numpy()
+        monkeypatch.setenv("SRAD_ATTN_F32IN", "1")
+        old = m(torch.from_numpy(x).cuda()).cpu().numpy()
+        monkeypatch.delenv("SRAD_ATTN_F32IN")
+    rng = float(ref.max() - ref.min())
+    print("bf16 q|k|v from the GEMM vs fp32 staging: max diff / range", np.abs(new - old).max() / rng, "; vs oracle", np.abs(new - ref).max() / rng)
+    assert np.abs(new - old).max() / rng < 2e-3
+    assert np.abs(new - ref).max() / rng < 1e-2
+
+
 def test_c5_full_shape_bf16_close_to_fp32_mode():
     """C5 at full size: DRCT-L (12 RDG), one 1024 px HR tile = LR [1, 1, 256, 256], window 64 (65536 tokens, 16
     windows of 4096).  No CPU reference at this size: the bf16 path must stay within the bf16 bar of the exact-fp32
