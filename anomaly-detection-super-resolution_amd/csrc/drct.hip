@@ -107,7 +107,14 @@ int forward_body(srad_drct* h, const float* x, int B, int H, int W, float* y, co
         // (64 x 64 windows, bf16: the GEMM leaves q | k | v as the bf16 operands the attention's MFMAs take)
         float qscale = 1.f;
         const bool qkv_bf16 = srad_window_attn_bf16_in(prec, c.window_size, sw.shift, d, sw.heads, &qscale);
-        {
+        if (qkv_bf16 && h->pt.frag_ptr(sw.qkv.w) && srad_ln_qkv_supported(prec, T, d, sw.heads) && getenv("SRAD_NO_LN_QKV") == nullptr) {
+          // one launch, 64 rows per workgroup against the whole weight (kernels_fused_attn.hip ln_qkv_kernel)
+          LnQkvParams q{};
+          q.x = cur; q.ldx = D; q.M = T; q.d = d; q.heads = sw.heads; q.ln_g = h->pt.fptr(sw.n1g); q.ln_b = h->pt.fptr(sw.n1b);
+          q.w_qkv = h->pt.frag_ptr(sw.qkv.w); q.b_qkv = h->pt.fptr(sw.qkv.b);
+          q.qkv_h = reinterpret_cast<__bf16*>(w.qkv); q.hdp = hdp_of(d, sw.heads); q.qscale = qscale;
+          SRAD_TRY(srad_launch_ln_qkv(q, s));
+        } else {
           const int hdp = hdp_of(d, sw.heads);
           GemmParams p = base_gemm(h, sw.qkv, cur, D, T, w.qkv, 3 * sw.heads * hdp);
           p.hsplit_hd = d / sw.heads; p.hsplit_hdp = hdp;      // head-padded q|k|v rows for the attention kernel

@@ -359,9 +359,195 @@ int launch_qa(const QkvAttnParams& p, hipStream_t stream) {
   return SRAD_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// LayerNorm1 + the qkv Linear for the 64 x 64-window attention (BASELINE config C5: 65536 tokens per tile), whose q | k | v
+// it leaves as the bf16 operands that kernel stages as they are: [T][3][heads][hdp], q times the attention's scale (incl.
+// log2 e), padding columns 0, column head_dim of the v slices 1.  The first half of qkv_attn_kernel without the
+// attention: 64 token rows per workgroup, normalised once into LDS, then EVERY head's [q | k | v] weight fragments
+// stream through the waves' registers (a wave owns 16 virtual columns of a head for all 64 rows) - a row tile meets the
+// whole 3 d x d weight, where the tiled GEMM launched one 64 x 64 tile per workgroup, each re-reading and re-normalising
+// its rows for 1.5 MFLOP (130 TFLOP/s at this size).
+// ------------------------------------------------------------------------------------------
+template <int HDT, int KC, int HEADS>
+__global__ __launch_bounds__(512) void ln_qkv_kernel(const LnQkvParams p) {
+  constexpr int KG = (KC + 7) / 8;
+  constexpr int LDX = KC * 32 + 8;
+  constexpr int HDP = 16 * HDT;
+  constexpr int NV = 3 * HDP;
+  constexpr int NS = (NV + 127) / 128;
+  constexpr int n_stages = NS * KG;                              // per head
+  constexpr int n_all = HEADS * n_stages;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* XN = reinterpret_cast<__bf16*>(smem);                 // [64][LDX]
+  float* v_g = reinterpret_cast<float*>(XN + 64 * LDX);         // [320] gamma
+  float* v_b = v_g + 320;                                       // [320] beta
+  float* v_bias = v_b + 320;                                    // [HEADS][3][HDP] bias (0 in padding)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int d = p.d, hd = d / HEADS, hdp = p.hdp;
+  const int m0 = blockIdx.x * 64;
+  const int xrow = tid >> 3, col4 = tid & 7;
+
+  constexpr int NSETS = 3;
+  u32x4 w_reg[NSETS][8];
+  auto load_w = [&](auto S, u32x4 (&reg)[8]) __attribute__((always_inline)) {
+    constexpr int sa = decltype(S)::value < n_all - 1 ? decltype(S)::value : n_all - 1;
+    constexpr int hh = sa / n_stages, sc = sa - hh * n_stages;
+    constexpr int st = sc / KG, kg = sc - st * KG;
+    constexpr int nch = KC - kg * 8 < 8 ? KC - kg * 8 : 8;
+    const char* const Wh = reinterpret_cast<const char*>(p.w_qkv) + (size_t)hh * (NV / 16) * KC * 1024;
+    const bool live = (st * 8 + wave_s) * 16 < NV;
+    const char* base = live ? Wh + ((size_t)(st * 8 + wave) * KC + kg * 8) * 1024 + fr * 64 + fq * 16 : Wh;
+    const int step = live ? 1024 : 0;
+#pragma unroll
+    for (int cc = 0; cc < nch; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + cc * step);
+  };
+
+  // loads in the order their data is needed: the rows, the vectors, the first weight stage
+  f32x4 a_reg[KC];
+  {
+    const char* src = reinterpret_cast<const char*>(p.x) + (size_t)(m0 + xrow) * p.ldx * 4;
+#pragma unroll
+    for (int j = 0; j < KC; ++j) a_reg[j] = *reinterpret_cast<const f32x4*>(src + (unsigned)min(j * 32 + col4 * 4, d - 4) * 4u);
+  }
+  typedef const float __attribute__((address_space(1)))* gfloat_p;
+  constexpr int NBIAS = HEADS * 3 * HDP;                          // <= 768
+  float gq = 0.f, bq = 0.f, biasq[2];
+  {
+    const int e = min(tid, d - 1);
+    if (tid < 320) { gq = ((gfloat_p)p.ln_g)[e]; bq = ((gfloat_p)p.ln_b)[e]; }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int idx = min(tid + 512 * q, NBIAS - 1);
+      const int slice = idx / HDP, c = idx - slice * HDP, hh = slice / 3, which = slice - 3 * hh;
+      biasq[q] = ((gfloat_p)p.b_qkv)[which * d + hh * hd + min(c, hd - 1)];
+      if (c >= hd) biasq[q] = 0.f;
+    }
+  }
+  load_w(std::integral_constant<int, 0>{}, w_reg[0]);
+  if (tid < 320) { v_g[tid] = tid < d ? gq : 0.f; v_b[tid] = tid < d ? bq : 0.f; }
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+    if (tid + 512 * q < NBIAS) v_bias[tid + 512 * q] = biasq[q];
+
+  // LayerNorm1 from the registers (the 8 lanes of a row hold all its columns) -> bf16 -> XN
+  {
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      const bool in = j * 32 + col4 * 4 < d;
+      const f32x4 v = in ? a_reg[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+      ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    { s = srad_row8_sum(s); ss = srad_row8_sum(ss); }
+    const float mu = s / (float)d;
+    const float rstd = rsqrtf(fmaxf(ss / (float)d - mu * mu, 0.f) + 1e-5f);
+    __syncthreads();                                              // gamma / beta / bias staged
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      const int c = j * 32 + col4 * 4;
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(v_g + min(c, 316));
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(v_b + min(c, 316));
+      const f32x4 v = c < d ? (a_reg[j] - mu) * rstd * g4 + b4 : f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x4 hh;
+      hh[0] = (__bf16)v[0]; hh[1] = (__bf16)v[1]; hh[2] = (__bf16)v[2]; hh[3] = (__bf16)v[3];
+      *reinterpret_cast<bf16x4*>(XN + xrow * LDX + c) = hh;
+    }
+  }
+  static_for<1, NSETS>([&](auto Q) { load_w(Q, w_reg[decltype(Q)::value]); });
+  __syncthreads();                                                // the normalised rows are in LDS
+
+  // q|k|v = xn . W^T, head after head: 128 virtual columns per stage, transposed result (lane: token fr of row tile t, 4 columns)
+  f32x4 acc[4];
+  const int ldq = 3 * HEADS * hdp;
+  static_for<0, n_all>([&](auto S) {
+    constexpr int sa = decltype(S)::value;
+    constexpr int hh = sa / n_stages, s = sa - hh * n_stages;
+    constexpr int st = s / KG, kg = s - st * KG;
+    u32x4 (&reg)[8] = w_reg[sa % NSETS];
+    constexpr int nch = KC - kg * 8 < 8 ? KC - kg * 8 : 8;
+    const bool live = (st * 8 + wave_s) * 16 < NV;
+    if constexpr (kg == 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (live) {
+      const __bf16* ar = XN + fr * LDX + kg * 256 + 8 * fq;
+#pragma unroll
+      for (int cc = 0; cc < nch; ++cc) {
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, reg[cc]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + t * 16 * LDX + cc * 32);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    load_w(std::integral_constant<int, sa + NSETS>{}, reg);
+    if constexpr (kg == KG - 1) {
+      if (live) {
+        const int vc = (st * 8 + wave) * 16 + 4 * fq;             // virtual column of element 0
+        const int which = vc / HDP, c = vc - which * HDP;         // HDP % 16 == 0: the wave's 16 columns stay in one slice
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(v_bias + (hh * 3 + which) * HDP + c);
+        if (c < hdp) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            f32x4 v = acc[t] + bias;
+            if (which == 0) v = v * p.qscale;
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (__bf16)(c + e < hd ? v[e] : ((which == 2 && c + e == hd) ? 1.f : 0.f));
+            *reinterpret_cast<bf16x4*>(p.qkv_h + (size_t)(m0 + t * 16 + fr) * ldq + (which * HEADS + hh) * hdp + c) = o;
+          }
+        }
+      }
+    }
+  });
+}
+
+template <int HDT, int KC, int HEADS>
+int launch_ln_qkv(const LnQkvParams& p, hipStream_t stream) {
+  constexpr size_t lds = (size_t)64 * (KC * 32 + 8) * 2 + (size_t)(640 + HEADS * 3 * 16 * HDT) * sizeof(float);
+  auto kern = ln_qkv_kernel<HDT, KC, HEADS>;
+  static bool configured = false;
+  if (!configured) {
+    SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  SradProfScope prof(stream, SRAD_K_LN_QKV, 2.0 * p.M * 3.0 * p.d * p.d, 4.0 * p.M * p.d + 2.0 * p.M * 3.0 * p.d + 2.0 * 3.0 * p.d * p.d);
+  hipLaunchKernelGGL(kern, dim3(p.M / 64), dim3(512), lds, stream, p);
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}
+
 // (head tiles, k chunks) of DRCT-L's five Swin blocks: d = 180/212/244/276/308, heads 6/4/2/6/4
 #define SRAD_QA_CFGS(X) X(2, 6) X(4, 7) X(8, 8) X(3, 9) X(5, 10)
+#define SRAD_LQ_CFGS(X) X(2, 6, 6) X(4, 7, 4) X(8, 8, 2) X(3, 9, 6) X(5, 10, 4)
 }  // namespace
+
+bool srad_ln_qkv_supported(int prec, int M, int d, int heads) {
+  if (prec != SRAD_PREC_BF16 || M <= 0 || M % 64 || d % 4 || d > 320 || d < 32 || heads < 1 || d % heads) return false;
+  const int hdt = (d / heads + 15) / 16, kc = (d + 31) / 32;
+#define X(a, b, c) if (hdt == a && kc == b && heads == c) return true;
+  SRAD_LQ_CFGS(X)
+#undef X
+  return false;
+}
+
+int srad_launch_ln_qkv(const LnQkvParams& p, hipStream_t stream) {
+  SRAD_REQUIRE(srad_ln_qkv_supported(SRAD_PREC_BF16, p.M, p.d, p.heads), "ln_qkv: unsupported shape M=%d d=%d heads=%d", p.M, p.d, p.heads);
+  SRAD_REQUIRE(p.x && p.ln_g && p.ln_b && p.w_qkv && p.b_qkv && p.qkv_h, "ln_qkv: null argument");
+  SRAD_REQUIRE((p.ldx & 3) == 0 && ((uintptr_t)p.x & 15) == 0 && ((uintptr_t)p.qkv_h & 7) == 0 && p.hdp % 4 == 0 && p.hdp >= p.d / p.heads &&
+                   p.hdp <= 16 * ((p.d / p.heads + 15) / 16),
+               "ln_qkv: x rows must be float4-addressable, the head slots 4-column multiples within the head's 16-column tiles");
+  const int hdt = (p.d / p.heads + 15) / 16, kc = (p.d + 31) / 32;
+#define X(a, b, c) if (hdt == a && kc == b && p.heads == c) return launch_ln_qkv<a, b, c>(p, stream);
+  SRAD_LQ_CFGS(X)
+#undef X
+  return srad_set_error(SRAD_ERR_ARG, "ln_qkv: no kernel instance for d=%d heads=%d", p.d, p.heads);
+}
 
 bool srad_qkv_attn_supported(int prec, int ws, int H, int W, int d, int heads) {
   if (prec != SRAD_PREC_BF16 || ws != 8 || H % 8 || W % 8 || d % 4 || d > 320 || d < 32 || heads < 1 || d % heads) return false;

@@ -221,6 +221,17 @@ struct QkvAttnParams {
   unsigned long long* stamps;              // diagnostic build: [workgroup][8 waves][16] s_memtime stamps, else null
 };
 bool srad_qkv_attn_supported(int prec, int ws, int H, int W, int d, int heads);
+// LayerNorm1 + qkv Linear -> bf16 head-split q | k | v for the 64 x 64-window attention (kernels_fused_attn.hip ln_qkv_kernel)
+struct LnQkvParams {
+  const float* x; int ldx;                 // block input rows [M][ldx] (columns [0, d) are read)
+  int M, d, heads;                         // M % 64 == 0
+  const float *ln_g, *ln_b;
+  const void* w_qkv; const float* b_qkv;   // per-head fragment pack (srad_launch_pack_qkv_frag), bias [3d]
+  __bf16* qkv_h; int hdp;                  // out: [M][3][heads][hdp] as the attention's MFMA operands (see AttnParams::qkv_h)
+  float qscale;                            // factor of the q slices (srad_window_attn_bf16_in)
+};
+bool srad_ln_qkv_supported(int prec, int M, int d, int heads);
+int srad_launch_ln_qkv(const LnQkvParams& p, hipStream_t stream);
 int srad_launch_qkv_attn(const QkvAttnParams& p, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------
@@ -400,7 +411,7 @@ int srad_launch_nhwc_to_nchw(const float* x, int ldx, float* y, int B, int C, in
 enum {
   SRAD_K_GEMM_BN64 = 0, SRAD_K_GEMM_BN32, SRAD_K_GEMM_BN16, SRAD_K_ATTN, SRAD_K_LAYERNORM,
   SRAD_K_LAYOUT, SRAD_K_PACK, SRAD_K_SCORE, SRAD_K_MISC, SRAD_K_MLP_BLOCK, SRAD_K_QKV_ATTN,
-  SRAD_K_WGRAD, SRAD_K_ATTN_BWD, SRAD_K_LN_BWD, SRAD_K_OPTIM, SRAD_K_WGRAD_REDUCE, SRAD_K_MLP_BWD, SRAD_K_COUNT
+  SRAD_K_WGRAD, SRAD_K_ATTN_BWD, SRAD_K_LN_BWD, SRAD_K_OPTIM, SRAD_K_WGRAD_REDUCE, SRAD_K_MLP_BWD, SRAD_K_LN_QKV, SRAD_K_COUNT
 };
 struct SradProfScope {
   hipStream_t s; int active;
