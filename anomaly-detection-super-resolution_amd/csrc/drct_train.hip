@@ -130,8 +130,7 @@ BlockPlan plan_block(const srad_drct* h, const SwinW& sw, int H, int W, int T, i
   b.yh_qkv = b.xh && b.fuse_qkv;
   b.attn_h = b.xh && b.fuse_proj && b.yh_qkv && srad_mlp_bwd_bf16_out(T) && hd <= 32 && hd % 2 == 0 && c.window_size == 8 &&
              getenv("SRAD_ATTN_BWD_F32IO") == nullptr;
-  // (the bf16-output mlp_bwd writes dO as bf16 too, which only the all-bf16 attention backward reads)
-  b.yh_dh = b.xh && b.fuse_mlp && srad_mlp_bwd_bf16_out(T) && (b.attn_h || !b.fuse_proj);
+  b.yh_dh = b.xh && b.fuse_mlp && srad_mlp_bwd_bf16_out(T);    // (dO: bf16 per head for the all-bf16 attention backward, else fp32)
   b.yh_dx2 = b.yh_dh && b.fuse_adj;
   return b;
 }
@@ -540,7 +539,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
           else { mb.dA = gn; mb.ld_dA = D; }
         }
         if (fuse_proj) { mb.w_projt = h->ts.tarena + h->ts.tf_off[sw.proj.w]; mb.rs1 = ks1; mb.rps = HW; mb.dO = w.dO; }
-        if (fuse_proj && yh_dh) { mb.dO_h = reinterpret_cast<__bf16*>(w.dO); mb.dO_heads = sw.heads; mb.dO_hp = attn_hp(sw); }
+        if (fuse_proj && attn_h) { mb.dO_h = reinterpret_cast<__bf16*>(w.dO); mb.dO_heads = sw.heads; mb.dO_hp = attn_hp(sw); }
         if (yh_dx1) mb.dx1s_h = dx1s_h;
         SRAD_TRY(srad_launch_mlp_bwd(mb, wq, s));
       } else {

@@ -419,9 +419,9 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
       load_wp(std::integral_constant<int, s + NSETS>{}, reg);
       if constexpr (kg == KGD - 1) {
         const int c4 = col4_of(g);
-        if constexpr (HOUT) {
-          // bf16, one hp-wide slot per head (what the attention backward stages with 16-byte loads); the head dim is even,
-          // so the column pairs (c4, c4 + 1) and (c4 + 2, c4 + 3) never straddle a head
+        if (HOUT && p.dO_h) {
+          // bf16, one hp-wide slot per head (what the all-bf16 attention backward stages with 16-byte loads); the head dim is
+          // even, so the column pairs (c4, c4 + 1) and (c4 + 2, c4 + 3) never straddle a head
           if (c4 < d) {
             const int hdo = d / p.dO_heads;
             const int h0 = c4 / hdo, h1 = (c4 + 2) / hdo;
@@ -620,9 +620,10 @@ int launch_bwd(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream) {
   if (p.dh_h) {                                  // bf16 outputs for the weight gradients: the 32-row instances (srad_mlp_bwd_bf16_out)
     SRAD_REQUIRE(srad_mlp_bwd_bf16_out(p.M) && (KCA == 0 || p.dx2s_h) && p.hpre_h && ((uintptr_t)p.hpre_h & 7) == 0,
                  "mlp_bwd: bf16 outputs need M >= 8192, M %% 32 == 0, the fc1 pre-activation as bf16 (and the dx2 copy with the adjust prologue)");
-    SRAD_REQUIRE(!p.w_projt || (p.dO_h && p.dO_heads > 0 && p.d % p.dO_heads == 0 && (p.d / p.dO_heads) % 2 == 0 && p.dO_hp % 8 == 0 &&
-                                p.dO_hp >= p.d / p.dO_heads),
-                 "mlp_bwd: the bf16-output instances write dO per head ([M][heads][hp], even head dim, hp %% 8 == 0)");
+    SRAD_REQUIRE(!p.w_projt || (p.dO_h ? (p.dO_heads > 0 && p.d % p.dO_heads == 0 && (p.d / p.dO_heads) % 2 == 0 && p.dO_hp % 8 == 0 &&
+                                          p.dO_hp >= p.d / p.dO_heads)
+                                       : p.dO != nullptr),
+                 "mlp_bwd: dO goes out as fp32 [M][d], or as bf16 per head ([M][heads][hp], even head dim, hp %% 8 == 0)");
     return launch_bwd_fm<32, GD, KCD, GM, KCM, KCA, true>(p, q, stream);
   }
   if (p.M >= 8192 && p.M % 32 == 0) return launch_bwd_fm<32, GD, KCD, GM, KCM, KCA>(p, q, stream);
