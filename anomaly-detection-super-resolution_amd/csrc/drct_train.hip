@@ -128,7 +128,7 @@ BlockPlan plan_block(const srad_drct* h, const SwinW& sw, int H, int W, int T, i
   b.fuse_adj = b.fuse_mlp && tf(sw.adjust.w) && srad_mlp_bwd_supported(prec, T, d, sw.hidden, KA);
   b.fuse_qkv = fused_bwd && tf(sw.qkv.w) && srad_lin_ln_bwd_supported(prec, T, 3 * d, d);
   b.yh_qkv = b.xh && b.fuse_qkv;
-  b.attn_h = b.xh && b.fuse_proj && b.yh_qkv && srad_mlp_bwd_bf16_out(T) && hd <= 32 && hd % 2 == 0 && c.window_size == 8 &&
+  b.attn_h = b.xh && b.fuse_proj && b.yh_qkv && srad_mlp_bwd_bf16_out(T) && hd <= 128 && c.window_size == 8 &&
              getenv("SRAD_ATTN_BWD_F32IO") == nullptr;
   b.yh_dh = b.xh && b.fuse_mlp && srad_mlp_bwd_bf16_out(T);    // (dO: bf16 per head for the all-bf16 attention backward, else fp32)
   b.yh_dx2 = b.yh_dh && b.fuse_adj;

@@ -1228,30 +1228,36 @@ __global__ __launch_bounds__(256) void window_attn_bwd_bf16_kernel(const AttnBwd
 }
 
 // ------------------------------------------------------------------------------------------
-// All-bf16 form of the same backward for head dims <= 32 (DRCT-L: 30), the training step's case: q (already scaled and
-// rounded, exactly the operand the forward's MFMA took) | k | v and dO arrive as bf16 in per-head slots of hp columns, so a
-// thread stages its share with four 16-byte loads issued before anything else (it derives its row's token itself), and
-// dq | dk | dv leave as bf16.  There is one 32-column chunk, so the second operands of the three pass-B products are
-// fetched (transposing LDS reads) right after pass A and the staging tiles are dead from then on: the fp32 dS copy the
-// bias-table gradient sums is laid over them.  That brings the workgroup to 48.5 KB of LDS - three per CU, which for the
-// 768 (window, head) pairs of the 8-image training batch is ONE resident round on 256 CUs instead of one and a half.
+// All-bf16 form of the same backward, the training step's case: q (already scaled and rounded, exactly the operand the
+// forward's MFMA took) | k | v and dO arrive as bf16 in per-head slots of hp columns, so a thread stages its share of a
+// 32-column chunk with four 16-byte loads issued before anything else (it derives its row's token itself), and dq | dk | dv
+// leave as bf16.  NCH = 32-column chunks of the head dim (1 .. 4).  With ONE chunk (head dim <= 32, DRCT-L's 30) the second
+// operands of the three pass-B products are fetched (transposing LDS reads) right after pass A and the staging tiles are
+// dead from then on: the fp32 dS copy the bias-table gradient sums is laid over them.  That brings the workgroup to 48.5 KB
+// of LDS - three per CU, which for the 768 (window, head) pairs of the 8-image training batch is ONE resident round on
+// 256 CUs instead of one and a half.  With more chunks pass B stages them again and the dS copy has its own 17 KB.
 // ------------------------------------------------------------------------------------------
-constexpr size_t AG_LDS = (size_t)(4 * 64 * AH_HS + 3 * 64 * AH_PS) * sizeof(__bf16) + 256 * sizeof(float) + 2 * 64 * sizeof(int);
+template <int NCH> constexpr size_t ag_lds_bytes() {
+  return (size_t)(4 * 64 * AH_HS + 3 * 64 * AH_PS) * sizeof(__bf16) + 256 * sizeof(float) + 2 * 64 * sizeof(int) +
+         (NCH > 1 ? (size_t)64 * 68 * sizeof(float) : 0);
+}
 static_assert((size_t)64 * 68 * sizeof(float) <= (size_t)4 * 64 * AH_HS * sizeof(__bf16), "the fp32 dS copy must fit in the staging tiles");
 
+template <int NCH>
 __global__ __launch_bounds__(256) void window_attn_bwd_h_kernel(const AttnBwdParams p, float* __restrict__ tpart) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __bf16* Qs = reinterpret_cast<__bf16*>(smem);          // [64][AH_HS] q * scale
+  __bf16* Qs = reinterpret_cast<__bf16*>(smem);          // [64][AH_HS] q * scale (32-column chunk)
   __bf16* Ks = Qs + 64 * AH_HS;
   __bf16* Vs = Ks + 64 * AH_HS;
   __bf16* Gs = Vs + 64 * AH_HS;                          // dO
-  float* Df = reinterpret_cast<float*>(smem);            // [64][68] fp32 dS, over Qs .. Gs once pass A is done with them
   __bf16* Dm = Gs + 64 * AH_HS;                          // [query][key] dS
   __bf16* DmT = Dm + 64 * AH_PS;                         // [key][query] dS
   __bf16* PmT = DmT + 64 * AH_PS;                        // [key][query] P
   float* tbl = reinterpret_cast<float*>(PmT + 64 * AH_PS);   // [225] (256 reserved)
   int* tok = reinterpret_cast<int*>(tbl + 256);
   int* inf = tok + 64;
+  // [64][68] fp32 dS: over Qs .. Gs once pass A is done with them (one chunk), else behind everything
+  float* Df = NCH == 1 ? reinterpret_cast<float*>(smem) : reinterpret_cast<float*>(inf + 64);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
@@ -1279,62 +1285,76 @@ __global__ __launch_bounds__(256) void window_attn_bwd_h_kernel(const AttnBwdPar
     info = ((rh * 3 + rw) << 16) | (py << 8) | px;
   };
 
-  // ---- staging: thread = (row tid / 4, 8 columns), everything in flight before the first LDS store ----
+  // ---- staging: thread = (row tid / 4, 8 columns of the chunk), everything in flight before the first LDS store ----
+  const int srow = tid >> 2, scl = (tid & 3) * 8;
+  int stok, sinf;
+  geometry(srow, stok, sinf);
+  const __bf16* const qrow = p.qkv_h + (size_t)stok * (3 * heads * hp) + h * hp;
+  const __bf16* const grow = p.dout_h + (size_t)stok * (heads * hp) + h * hp;
+  u32x4 sq, sk, sv, sg;
+  auto load_chunk = [&](int ch, bool need_v) __attribute__((always_inline)) {
+    const int off = min(ch * 32 + scl, hp - 8);
+    sq = *reinterpret_cast<const u32x4*>(qrow + off);
+    sk = *reinterpret_cast<const u32x4*>(qrow + heads * hp + off);
+    if (need_v) sv = *reinterpret_cast<const u32x4*>(qrow + 2 * heads * hp + off);
+    sg = *reinterpret_cast<const u32x4*>(grow + off);
+  };
+  auto store_chunk = [&](int ch, bool need_v) __attribute__((always_inline)) {
+    auto put = [&](__bf16* tile, const u32x4& raw) {        // columns at or beyond the head dim are zero in LDS
+      bf16x8 v = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = ch * 32 + scl + e < hd ? v[e] : (__bf16)0.f;
+      *reinterpret_cast<bf16x8*>(tile + srow * AH_HS + scl) = v;
+    };
+    put(Qs, sq); put(Ks, sk); if (need_v) put(Vs, sv); put(Gs, sg);
+  };
+  load_chunk(0, true);
   {
-    const int srow = tid >> 2, scl = (tid & 3) * 8;
-    int stok, sinf;
-    geometry(srow, stok, sinf);
-    const int off = min(scl, hp - 8);
-    const __bf16* qb = p.qkv_h + (size_t)stok * (3 * heads * hp) + h * hp + off;
-    const u32x4 q4 = *reinterpret_cast<const u32x4*>(qb);
-    const u32x4 k4 = *reinterpret_cast<const u32x4*>(qb + heads * hp);
-    const u32x4 v4 = *reinterpret_cast<const u32x4*>(qb + 2 * heads * hp);
-    const u32x4 g4 = *reinterpret_cast<const u32x4*>(p.dout_h + (size_t)stok * (heads * hp) + h * hp + off);
     const float tv = p.table[(size_t)min(tid, tw * tw - 1) * heads + h];
     if ((tid & 3) == 0) { tok[srow] = stok; inf[srow] = sinf; }
     tbl[tid] = tv;
-    auto put = [&](__bf16* tile, const u32x4& raw) {       // columns at or beyond the head dim are zero in LDS
-      bf16x8 v = __builtin_bit_cast(bf16x8, raw);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = scl + e < hd ? v[e] : (__bf16)0.f;
-      *reinterpret_cast<bf16x8*>(tile + srow * AH_HS + scl) = v;
-    };
-    put(Qs, q4); put(Ks, k4); put(Vs, v4); put(Gs, g4);
   }
+  store_chunk(0, true);
   __syncthreads();
 
   // ---- pass A: S = q k^T, dP = dO v^T (row = 16 wave + 4 fq + e, key = 16 j + fr) ----
   f32x4 s[4], dp[4];
-  {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { s[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    if (ch + 1 < NCH) load_chunk(ch + 1, true);             // the next chunk's rows are in flight over this chunk's MFMAs
     const bf16x8 a = *reinterpret_cast<const bf16x8*>(Qs + (wave * 16 + fr) * AH_HS + 8 * fq);
     const bf16x8 g = *reinterpret_cast<const bf16x8*>(Gs + (wave * 16 + fr) * AH_HS + 8 * fq);
-    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bf16x8 kb = *reinterpret_cast<const bf16x8*>(Ks + (j * 16 + fr) * AH_HS + 8 * fq);
       const bf16x8 vb = *reinterpret_cast<const bf16x8*>(Vs + (j * 16 + fr) * AH_HS + 8 * fq);
-      s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, kb, z4, 0, 0, 0);
-      dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g, vb, z4, 0, 0, 0);
+      s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, kb, s[j], 0, 0, 0);
+      dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g, vb, dp[j], 0, 0, 0);
     }
+    if (ch + 1 < NCH) { __syncthreads(); store_chunk(ch + 1, true); __syncthreads(); }
   }
   // second operands of pass B: B[k = token kk + 8 fq + t][j = column 16 jt + fr] of the row-major tiles
   typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-  bf16x8 bK[2][2], bQ[2][2], bG[2][2];
-  {
-    const int tq = fr >> 2, tp = fr & 3;
-    auto tr8 = [&](const __bf16* tile, int kk, int jt) -> bf16x8 {
-      const __bf16* r0 = tile + (kk + 8 * fq + tq) * AH_HS + jt * 16 + 4 * tp;
-      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0));
-      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0 + 4 * AH_HS));
-      bf16x8 o;
+  const int tq = fr >> 2, tp = fr & 3;
+  auto tr8 = [&](const __bf16* tile, int kk, int jt) __attribute__((always_inline)) -> bf16x8 {
+    const __bf16* r0 = tile + (kk + 8 * fq + tq) * AH_HS + jt * 16 + 4 * tp;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0 + 4 * AH_HS));
+    bf16x8 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
-      return o;
-    };
+    for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
+    return o;
+  };
+  bf16x8 bK[2][2], bQ[2][2], bG[2][2];
+  if constexpr (NCH == 1) {
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt) { bK[k2][jt] = tr8(Ks, 32 * k2, jt); bQ[k2][jt] = tr8(Qs, 32 * k2, jt); bG[k2][jt] = tr8(Gs, 32 * k2, jt); }
+  } else {
+    load_chunk(0, false);                                   // pass B walks the chunks again (k, q, dO): chunk 0 in flight over the softmax
   }
 
   // ---- softmax and dS in registers (their LDS reads are tbl / inf only) ----
@@ -1371,7 +1391,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_h_kernel(const AttnBwdPar
       for (int j = 0; j < 4; ++j) { pr[j][e] = s[j][e]; dsr[j][e] = s[j][e] * (dp[j][e] - dl); }
     }
   }
-  __syncthreads();                                       // every wave has read the staging tiles: Df may overwrite them
+  __syncthreads();                                       // every wave has read the staging tiles: Df (one chunk) / chunk 0 may overwrite them
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int row = wave * 16 + fq * 4 + e;
@@ -1390,10 +1410,19 @@ __global__ __launch_bounds__(256) void window_attn_bwd_h_kernel(const AttnBwdPar
     *reinterpret_cast<bf16x4*>(PmT + (j * 16 + fr) * AH_PS + wave * 16 + 4 * fq) = ph;
     *reinterpret_cast<bf16x4*>(DmT + (j * 16 + fr) * AH_PS + wave * 16 + 4 * fq) = dh;
   }
+  if constexpr (NCH > 1) store_chunk(0, false);
   __syncthreads();
 
-  // ---- pass B: dq = dS k, dk = dS^T q, dv = P^T dO ----
-  {
+  // ---- pass B: dq = dS k, dk = dS^T q, dv = P^T dO, 32 columns at a time ----
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    if constexpr (NCH > 1) {
+      if (ch + 1 < NCH) load_chunk(ch + 1, false);
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) { bK[k2][jt] = tr8(Ks, 32 * k2, jt); bQ[k2][jt] = tr8(Qs, 32 * k2, jt); bG[k2][jt] = tr8(Gs, 32 * k2, jt); }
+    }
     f32x4 dq[2], dk[2], dv[2];
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) { dq[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[jt] = dq[jt]; dv[jt] = dq[jt]; }
@@ -1414,13 +1443,16 @@ __global__ __launch_bounds__(256) void window_attn_bwd_h_kernel(const AttnBwdPar
       __bf16* dst = p.dqkv_h + (size_t)tok[wave * 16 + fq * 4 + e] * (3 * d) + h * hd;
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt) {
-        const int c = jt * 16 + fr;
+        const int c = ch * 32 + jt * 16 + fr;
         if (c < hd) {
           dst[c] = (__bf16)(dq[jt][e] * scale);
           dst[d + c] = (__bf16)dk[jt][e];
           dst[2 * d + c] = (__bf16)dv[jt][e];
         }
       }
+    }
+    if constexpr (NCH > 1) {
+      if (ch + 1 < NCH) { __syncthreads(); store_chunk(ch + 1, false); __syncthreads(); }
     }
   }
   if (tid < tw * tw) {                                   // bias-table gradient row of this (window, head), fp32
@@ -1639,16 +1671,23 @@ int srad_launch_window_attn_bwd(int prec, const AttnBwdParams& p, WgradQueue& q,
   SradProfScope prof(stream, SRAD_K_ATTN_BWD, 10.0 * T * 64 * p.d, 4.0 * T * 8 * p.d);
   if (prec == SRAD_PREC_BF16 && p.qkv_h) {
     const int hd = p.d / p.heads;
-    SRAD_REQUIRE(p.dout_h && p.dqkv_h && hd <= 32 && p.hp_h % 8 == 0 && p.hp_h >= hd && p.hp_h <= 32 &&
+    SRAD_REQUIRE(p.dout_h && p.dqkv_h && hd <= 128 && p.hp_h % 8 == 0 && p.hp_h >= hd && p.hp_h <= 128 &&
                      (((uintptr_t)p.qkv_h | (uintptr_t)p.dout_h) & 15) == 0,
-                 "window_attn_bwd: the all-bf16 form takes head dims <= 32 in 16-byte aligned slots of hp columns, and writes bf16");
-    static bool configured_h = false;
-    if (!configured_h) {
-      SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_h_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)AG_LDS));
-      configured_h = true;
-    }
-    hipLaunchKernelGGL(window_attn_bwd_h_kernel, dim3(p.B * nW * p.heads), dim3(256), AG_LDS, stream, p, tpart);
+                 "window_attn_bwd: the all-bf16 form takes head dims <= 128 in 16-byte aligned slots of hp columns, and writes bf16");
+    auto go = [&](auto kern, size_t lds) -> int {
+      static bool configured = false;                  // (one per instantiation of this lambda = per kernel instance)
+      if (!configured) {
+        SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+      }
+      hipLaunchKernelGGL(kern, dim3(p.B * nW * p.heads), dim3(256), lds, stream, p, tpart);
+      return SRAD_OK;
+    };
+    const int nch = (hd + 31) / 32;
+    if (nch == 1) SRAD_TRY(go(window_attn_bwd_h_kernel<1>, ag_lds_bytes<1>()));
+    else if (nch == 2) SRAD_TRY(go(window_attn_bwd_h_kernel<2>, ag_lds_bytes<2>()));
+    else if (nch == 3) SRAD_TRY(go(window_attn_bwd_h_kernel<3>, ag_lds_bytes<3>()));
+    else SRAD_TRY(go(window_attn_bwd_h_kernel<4>, ag_lds_bytes<4>()));
   } else if (prec == SRAD_PREC_BF16) {
     static bool configured16 = false;
     if (!configured16) {

@@ -424,15 +424,28 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
           // even, so the column pairs (c4, c4 + 1) and (c4 + 2, c4 + 3) never straddle a head
           if (c4 < d) {
             const int hdo = d / p.dO_heads;
-            const int h0 = c4 / hdo, h1 = (c4 + 2) / hdo;
-            const int o0 = h0 * p.dO_hp + (c4 - h0 * hdo), o1 = h1 * p.dO_hp + (c4 + 2 - h1 * hdo);
             const int ldo = p.dO_heads * p.dO_hp;
+            if (hdo & 1) {                                       // odd head dim (53, 77): a pair can straddle two heads' slots
+              int o[4];
 #pragma unroll
-            for (int rt = 0; rt < NRT; ++rt) {
-              const f32x4 v = c[rt] * rs1v[rt];
-              __bf16* row = p.dO_h + (size_t)(m0 + rt * 16 + fr) * ldo;
-              *reinterpret_cast<bf16x2*>(row + o0) = bf16x2{(__bf16)v[0], (__bf16)v[1]};
-              *reinterpret_cast<bf16x2*>(row + o1) = bf16x2{(__bf16)v[2], (__bf16)v[3]};
+              for (int e = 0; e < 4; ++e) { const int hh = (c4 + e) / hdo; o[e] = hh * p.dO_hp + (c4 + e - hh * hdo); }
+#pragma unroll
+              for (int rt = 0; rt < NRT; ++rt) {
+                const f32x4 v = c[rt] * rs1v[rt];
+                __bf16* row = p.dO_h + (size_t)(m0 + rt * 16 + fr) * ldo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) row[o[e]] = (__bf16)v[e];
+              }
+            } else {
+              const int h0 = c4 / hdo, h1 = (c4 + 2) / hdo;
+              const int o0 = h0 * p.dO_hp + (c4 - h0 * hdo), o1 = h1 * p.dO_hp + (c4 + 2 - h1 * hdo);
+#pragma unroll
+              for (int rt = 0; rt < NRT; ++rt) {
+                const f32x4 v = c[rt] * rs1v[rt];
+                __bf16* row = p.dO_h + (size_t)(m0 + rt * 16 + fr) * ldo;
+                *reinterpret_cast<bf16x2*>(row + o0) = bf16x2{(__bf16)v[0], (__bf16)v[1]};
+                *reinterpret_cast<bf16x2*>(row + o1) = bf16x2{(__bf16)v[2], (__bf16)v[3]};
+              }
             }
           }
         } else if (c4 < d) {
@@ -620,10 +633,10 @@ int launch_bwd(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream) {
   if (p.dh_h) {                                  // bf16 outputs for the weight gradients: the 32-row instances (srad_mlp_bwd_bf16_out)
     SRAD_REQUIRE(srad_mlp_bwd_bf16_out(p.M) && (KCA == 0 || p.dx2s_h) && p.hpre_h && ((uintptr_t)p.hpre_h & 7) == 0,
                  "mlp_bwd: bf16 outputs need M >= 8192, M %% 32 == 0, the fc1 pre-activation as bf16 (and the dx2 copy with the adjust prologue)");
-    SRAD_REQUIRE(!p.w_projt || (p.dO_h ? (p.dO_heads > 0 && p.d % p.dO_heads == 0 && (p.d / p.dO_heads) % 2 == 0 && p.dO_hp % 8 == 0 &&
+    SRAD_REQUIRE(!p.w_projt || (p.dO_h ? (p.dO_heads > 0 && p.d % p.dO_heads == 0 && p.dO_hp % 8 == 0 &&
                                           p.dO_hp >= p.d / p.dO_heads)
                                        : p.dO != nullptr),
-                 "mlp_bwd: dO goes out as fp32 [M][d], or as bf16 per head ([M][heads][hp], even head dim, hp %% 8 == 0)");
+                 "mlp_bwd: dO goes out as fp32 [M][d], or as bf16 per head ([M][heads][hp], hp %% 8 == 0)");
     return launch_bwd_fm<32, GD, KCD, GM, KCM, KCA, true>(p, q, stream);
   }
   if (p.M >= 8192 && p.M % 32 == 0) return launch_bwd_fm<32, GD, KCD, GM, KCM, KCA>(p, q, stream);

@@ -345,7 +345,7 @@ int srad_op_window_attn_bwd(int precision, const float* qkv, const float* dout, 
   return srad_wgrad_flush(q, reinterpret_cast<hipStream_t>(stream));
 }
 
-// The all-bf16 form (head dim <= 32): qkv_h [T][3][heads][hp] with q already scaled, dout_h [T][heads][hp] (padding columns
+// The all-bf16 form (head dim <= 128): qkv_h [T][3][heads][hp] with q already scaled, dout_h [T][heads][hp] (padding columns
 // are ignored), dqkv_h [T][3 d] - all bf16; table / dtable fp32.
 int srad_op_window_attn_bwd_h(const void* qkv_h, const void* dout_h, void* dqkv_h, const float* table, float* dtable,
                               int B, int H, int W, int ws, int shift, int d, int heads, int hp, void* workspace, void* stream) {

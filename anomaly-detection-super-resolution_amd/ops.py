@@ -194,7 +194,7 @@ def wgrad_linear_deferred(dy: torch.Tensor, x: torch.Tensor, row_scale: Optional
 
 def window_attention_bwd_bf16io(qkv: torch.Tensor, dout: torch.Tensor, table: torch.Tensor, B: int, H: int, W: int, ws: int,
                                 shift: int, heads: int, pad_fill: float = float("nan")):
-    """The training step's form of ``window_attention_bwd`` (head dim <= 32): the operands cross the boundary as bf16 in
+    """The training step's form of ``window_attention_bwd`` (head dim <= 128): the operands cross the boundary as bf16 in
     per-head slots of ``hp = ceil8(head dim)`` columns - q already scaled, as the fused forward saves it - and dq | dk | dv
     come back as bf16.  ``pad_fill`` goes into dO's padding columns, which the kernel must ignore."""
     _need_cuda(qkv, dout, table)

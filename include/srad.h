@@ -279,7 +279,7 @@ int srad_op_layernorm_bwd(const float* dxn, const float* x, int ldx, const float
 int srad_op_window_attn_bwd(int precision, const float* qkv, const float* dout, float* dqkv, const float* table,
                             float* dtable, int B, int H, int W, int ws, int shift, int d, int heads, int hdp,
                             void* workspace, void* stream);
-/* The all-bf16 form of the same backward, for head dims <= 32 (what the DRCT training step runs): qkv_h [T][3][heads][hp]
+/* The all-bf16 form of the same backward, for head dims <= 128 (what the DRCT training step runs): qkv_h [T][3][heads][hp]
  * bf16 with q ALREADY multiplied by head_dim^-0.5 (the forward's MFMA operand), dout_h [T][heads][hp] bf16 (columns at
  * or beyond the head dim are ignored), dqkv_h [T][3 d] bf16 out; hp % 8 == 0; table / dtable fp32. */
 int srad_op_window_attn_bwd_h(const void* qkv_h, const void* dout_h, void* dqkv_h, const float* table, float* dtable,

@@ -169,8 +169,8 @@ def test_layernorm_bwd(dev, rows, C):
 @pytest.mark.parametrize("d,heads,shift", [(180, 6, 0), (180, 6, 4), (212, 4, 4), (244, 2, 0), (276, 6, 4), (308, 4, 0), (32, 2, 3),
                                            (48, 2, 5), (64, 2, 0)])
 def test_window_attention_bwd(dev, d, heads, shift, prec):
-    if prec == "bf16io" and d // heads > 32:
-        pytest.skip("the all-bf16 kernel takes head dims <= 32")
+    if prec == "bf16io" and d // heads > 128:
+        pytest.skip("the all-bf16 kernel takes head dims <= 128")
     from oracle import sr_ref as R
     from srad_amd import ops
     B, H, W, ws = 2, 16, 24, 8
