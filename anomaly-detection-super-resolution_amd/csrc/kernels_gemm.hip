@@ -531,7 +531,7 @@ int launch_cfg(const GemmParams& p, hipStream_t s) {
   const bool conv = p.ntaps == 9 || p.stride != 1;
   const bool special = p.ps == 2 || p.hsplit_hd > 0;
   if (conv) {
-    if constexpr (PREC == SRAD_PREC_BF16 && BM == 64 && (BN == 64 || BN == 80)) {
+    if constexpr (PREC == SRAD_PREC_BF16 && ((BM == 64 && (BN == 64 || BN == 80)) || (BM == 128 && BN == 80))) {
       // 128-wide K stages here too: DRN's 80-channel 3x3 convs 185 -> 225 TFLOP/s
       return special ? launch_one<PREC, BM, BN, WMV, WNV, false, true, true, 4>(p, s)
                      : launch_one<PREC, BM, BN, WMV, WNV, false, true, false, 4>(p, s);
@@ -567,6 +567,11 @@ int launch_prec(const GemmParams& p, hipStream_t s) {
   }
   if (p.N <= 32) return launch_cfg<PREC, 32, 32, 2, 2>(p, s);
   // N = 65..80 (DRN's 80-channel RCAB convolutions): one 80-wide tile instead of a full and a mostly empty 64-wide one
+  if constexpr (PREC == SRAD_PREC_BF16) {
+    // ... and 128 rows per workgroup once that still gives every CU one (C3: 32768 pixels -> 256 workgroups in ONE round; the
+    // kernel is a chain of load -> LDS -> MFMA stages per workgroup, so twice the rows per stage cost little more per stage)
+    if (!p.ln_g && p.N > 64 && p.N <= 80 && tiles(128, 80) >= 256 && getenv("SRAD_GEMM_NO_BM128") == nullptr) return launch_cfg<PREC, 128, 80, 4, 1>(p, s);
+  }
   if (!p.ln_g && p.N > 64 && p.N <= 80 && tiles(64, 80) >= 384) return launch_cfg<PREC, 64, 80, 4, 1>(p, s);
   if (tiles(64, 64) >= 384) return launch_cfg<PREC, 64, 64, 2, 2>(p, s);
   if (tiles(32, 64) >= 384) return launch_cfg<PREC, 32, 64, 2, 2>(p, s);
