@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void pool_dot_kernel(const float* __restrict__
 }
 
 constexpr int DRN_POOL_CHUNKS = 32;
+constexpr int DRN_POOL_MAXCHUNKS = 256;   // partial rows per image when the conv's epilogue writes them (one per row tile)
 
 // channel-attention gate: sigmoid(W2 relu(W1 mean + b1) + b2), one workgroup per image (drn.py:128-139); sums the
 // pool_dot partial rows first and (training) keeps the pooled sums
@@ -209,6 +210,14 @@ __global__ __launch_bounds__(256) void ca_scale_add_kernel(const float* __restri
   }
 }
 
+// can the conv's epilogue write the pool's partial rows (GemmParams::pool_part)?  Rows per image then, else 0
+inline int pool_rows_per_image(int prec, const GemmParams& p, int hw) {
+  static const bool off = getenv("SRAD_DRN_NO_POOL_FUSE") != nullptr;
+  const int bm = srad_gemm_tile_rows(prec, p);
+  if (off || bm < 64 || hw % bm != 0 || hw / bm > DRN_POOL_MAXCHUNKS) return 0;
+  return hw / bm;
+}
+
 inline int ca_slices(int hw) { return hw >= 128 * 128 ? 128 : (hw >= 1024 ? 64 : (hw >= 64 ? 8 : 1)); }
 
 inline int grid1d(size_t total) {
@@ -303,7 +312,7 @@ DrnWs plan_ws(const srad_drn* h, int B, int H, int W, void* base, size_t cap) {
   }
   w.ups = bp.take(umax);
   w.timg = bp.take(T0 * SRAD_IMG_CPAD);
-  w.pool = bp.take((size_t)B * 32 * top);
+  w.pool = bp.take((size_t)B * DRN_POOL_MAXCHUNKS * top);
   w.gate = bp.take((size_t)B * top);
   w.bytes = bp.used;
   return w;
@@ -373,18 +382,22 @@ int forward_body(srad_drn* h, const float* x, int B, int H, int W, float* const*
         p.act = SRAD_ACT_RELU;
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
-      {  // conv                                                 (drn.py:147-150)
+      int nchunk = DRN_POOL_CHUNKS;
+      {  // conv; its epilogue also leaves the global average pool's partial sums, one row per row tile  (drn.py:147-150, 127)
         GemmParams p = conv_params(h, r.c1, w.rt, ch, B, Hl, Wl, 1, w.rr, ch, 0);
+        nchunk = pool_rows_per_image(prec, p, Hl * Wl);
+        if (nchunk > 0) p.pool_part = w.pool;
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
-      {  // global average pool (partial rows) + the gate       (drn.py:127-138)
+      if (nchunk == 0) {  // global average pool (partial rows) as a pass of its own                          (drn.py:127-138)
+        nchunk = DRN_POOL_CHUNKS;
         SradProfScope prof(s, SRAD_K_MISC, 1.0 * T * ch + 4.0 * B * ch * (ch / 16), 4.0 * T * ch);
         hipLaunchKernelGGL(pool_dot_kernel, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, (const float*)nullptr, w.rr, w.pool, Hl * Wl, ch,
                            DRN_POOL_CHUNKS);
       }
       {  // the gate, and res = body(x) * gate + x               (drn.py:128-139, 156-157)
         SradProfScope prof(s, SRAD_K_MISC, 2.0 * T * ch, 12.0 * T * ch);
-        hipLaunchKernelGGL(ca_scale_add_kernel, dim3(ca_slices(Hl * Wl), B), dim3(256), 0, s, w.pool, DRN_POOL_CHUNKS,
+        hipLaunchKernelGGL(ca_scale_add_kernel, dim3(ca_slices(Hl * Wl), B), dim3(256), 0, s, w.pool, nchunk,
                            1.0f / (float)(Hl * Wl), ch, ch / 16, h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2),
                            (float*)nullptr, (float*)nullptr, w.rr, xin, ldin, cur, Hl * Wl);
       }
@@ -855,7 +868,7 @@ DrnTrainWs plan_train_ws(const srad_drn* h, int B, int H, int W, void* base, siz
   w.zup = bp.take(T0 * F);
   w.dtimg = bp.take(T0 * SRAD_IMG_CPAD);
   w.dup0 = bp.take(T0 * SRAD_IMG_CPAD);
-  w.ppart = bp.take((size_t)B * DRN_POOL_CHUNKS * top);
+  w.ppart = bp.take((size_t)B * DRN_POOL_MAXCHUNKS * top);
   w.dpool = bp.take((size_t)B * top);
   w.bytes = bp.used;
   return w;
@@ -986,13 +999,19 @@ int srad_drn_forward_train(srad_drn_t* h, const float* x, int B, int H, int W, f
         p.act = SRAD_ACT_RELU;
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
+      int nchunk = DRN_POOL_CHUNKS;
       {
         GemmParams p = conv_params(h, r.c1, sv.t, ch, B, Hl, Wl, 1, sv.r, ch, 0);
+        nchunk = pool_rows_per_image(prec, p, Hl * Wl);      // the pool's partial rows from the conv's epilogue when the tiles allow
+        if (nchunk > 0) p.pool_part = w.ppart;
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
-      hipLaunchKernelGGL(pool_dot_kernel, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, (const float*)nullptr, sv.r, w.ppart, Hl * Wl, ch,
-                         DRN_POOL_CHUNKS);
-      hipLaunchKernelGGL(ca_scale_add_kernel, dim3(ca_slices(Hl * Wl), B), dim3(256), 0, s, w.ppart, DRN_POOL_CHUNKS,
+      if (nchunk == 0) {
+        nchunk = DRN_POOL_CHUNKS;
+        hipLaunchKernelGGL(pool_dot_kernel, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, (const float*)nullptr, sv.r, w.ppart, Hl * Wl, ch,
+                           DRN_POOL_CHUNKS);
+      }
+      hipLaunchKernelGGL(ca_scale_add_kernel, dim3(ca_slices(Hl * Wl), B), dim3(256), 0, s, w.ppart, nchunk,
                          1.0f / (float)(Hl * Wl), ch, ch / 16, h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2),
                          sv.gate, sv.pool, sv.r, xin, ldin, sv.xo, Hl * Wl);
       SRAD_CHECK_HIP(hipGetLastError());

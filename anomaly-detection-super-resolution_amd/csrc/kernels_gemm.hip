@@ -385,6 +385,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       }
     }
   }
+  float csum[NT];                                     // pool_part: this lane's column sums over its rows of the tile
+#pragma unroll
+  for (int j = 0; j < NT; ++j) csum[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -413,6 +416,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
           else if (p.rmode == SRAD_RMODE_DGELU) v *= dgelu_erf(r);
           else v *= r > 0.f ? 1.f : p.slope;
         }
+        csum[j] += m_ok ? v : 0.f;
         if (m_ok && ncol[j] < p.N) {
           if constexpr (SPECIAL) {
             if (p.Yh) {                                    // head-split bf16 output for the window attention (see GemmParams::Yh)
@@ -428,6 +432,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
           p.Y[yrow + ycol[j]] = v;
         }
       }
+    }
+  }
+  if (p.pool_part) {                                  // kernel-uniform: the tile's column sums, waves combined in fixed order
+    float* const red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { csum[j] += __shfl_xor(csum[j], 16); csum[j] += __shfl_xor(csum[j], 32); }
+    __syncthreads();                                  // every wave is done with the staging tiles
+    if (fq == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) red[(wave / WAVES_N) * BN + wn0 + j * 16 + fr] = csum[j];
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES_M; ++w) t += red[w * BN + tid];
+      p.pool_part[(size_t)m_tile * p.N + n0 + tid] = t;
     }
   }
 }
@@ -579,6 +600,19 @@ int launch_prec(const GemmParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+int srad_gemm_tile_rows(int prec, const GemmParams& p) {      // keep in step with launch_prec
+  auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  if (!p.ln_g) {
+    if (p.N <= 16 && tiles(128, 16) >= 384) return 128;
+    if (p.N <= 32 && tiles(128, 32) >= 384) return 128;
+  }
+  if (p.N <= 32) return 32;
+  if (prec == SRAD_PREC_BF16 && !p.ln_g && p.N > 64 && p.N <= 80 && tiles(128, 80) >= 256 && getenv("SRAD_GEMM_NO_BM128") == nullptr) return 128;
+  if (!p.ln_g && p.N > 64 && p.N <= 80 && tiles(64, 80) >= 384) return 64;
+  if (tiles(64, 64) >= 384) return 64;
+  return 32;
+}
 
 int srad_launch_gemm(int prec, const GemmParams& p, hipStream_t stream) {
   SRAD_REQUIRE(p.M > 0 && p.N > 0 && p.Cin > 0, "gemm: empty problem M=%d N=%d Cin=%d", p.M, p.N, p.Cin);

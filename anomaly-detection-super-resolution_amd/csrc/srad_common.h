@@ -122,6 +122,10 @@ struct GemmParams {
   // (same element offsets), the q slices (heads [0, hsplit_heads)) times hsplit_qscale before rounding, and each slice's
   // padding columns written too: 0, except 1 in column hsplit_hd of the v slices (P.V then also sums the probabilities)
   __bf16* Yh = nullptr; int hsplit_heads = 0; float hsplit_qscale = 1.f;
+  // optional second output: pool_part[m_tile][n] = sum of the tile's rows of Y (column sums per workgroup, plain stores,
+  // fixed order) - the global average pool of DRN's channel attention without a pass of its own; an image must be a whole
+  // number of row tiles (srad_gemm_tile_rows)
+  float* pool_part = nullptr;
   // ---- training extensions (all off when zero) ----
   int rmode;                 // how R enters: 0 v = act(acc)*alpha*rs + R (residual); 1 v = acc*alpha*rs * gelu'(R);
                              //               2 v = acc*alpha*rs * (R > 0 ? 1 : slope)   (backward through an activation)
@@ -132,6 +136,7 @@ struct GemmParams {
 enum { SRAD_RMODE_ADD = 0, SRAD_RMODE_DGELU = 1, SRAD_RMODE_DLRELU = 2 };
 
 int srad_launch_gemm(int prec, const GemmParams& p, hipStream_t stream);
+int srad_gemm_tile_rows(int prec, const GemmParams& p);     // rows per workgroup tile srad_launch_gemm will pick for p
 
 // Packed weight geometry shared by the packer and the GEMM
 static inline int srad_cp(int cin) { return srad_round_up(cin, 32); }

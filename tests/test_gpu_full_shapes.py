@@ -29,9 +29,14 @@ def test_c3_drn_full_shape_bf16_vs_fp32_mode_and_batch_slot_invariance():
             psnr = 10 * np.log10(255.0 ** 2 / mse)
             print("C3 output", tuple(a.shape), "bf16 vs fp32 mode: psnr(255)", round(psnr, 1), "max abs", float((a - b).abs().max()))
             assert psnr > 45.0
-        # batch-slot invariance: no cross-image term (the channel-attention pooling is per image)
+        # batch-slot invariance: no cross-image term (the channel-attention pooling is per image).  Not bit-exact: the pool's
+        # partial sums come out of the conv's epilogue, one row per row tile, and the tile height follows the batch size, so
+        # the summation order of the per-image means differs in the last bits (a cross-image term would be whole units of 255)
         alone = m16(x[5:6])
-        assert all(torch.equal(alone[j][0], o16[j][5]) for j in range(3))
+        for j in range(3):
+            dif = (alone[j][0] - o16[j][5]).abs()
+            print("C3 batch-slot invariance, output", j, "max abs", float(dif.max()), "mean abs", float(dif.mean()))
+            assert float(dif.max()) < 0.1 and float(dif.mean()) < 0.005
         again = m16(x)
         assert all(torch.equal(again[j], o16[j]) for j in range(3))                    # bit-reproducible
 
