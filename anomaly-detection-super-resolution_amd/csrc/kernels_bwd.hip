@@ -52,13 +52,17 @@ constexpr int LNB_CP = SRAD_LNB_CP;                  // columns of a dgamma | db
 // XH / YH (FULL only): X / dY are stored as bf16 - half the operand bytes and prefetch registers; the 8 rows x 4 columns a
 // lane holds are transposed into the four 8-row MFMA operands with v_perm_b32 instead of being converted.  A bf16 dY is
 // already multiplied by its DropPath factor (its producer did that), so no per-step factor either.
-template <int PREC, bool CONV, bool FULL = false, bool XH = false, bool YH = false>
+// LDS2: the waves' tiles are summed pairwise through TWO tile slots instead of four (waves 2, 3 store, waves 0, 1 add and
+// store, then one sum of two): 36 KB instead of 70 KB, two barriers instead of one - for the all-bf16 kernel, whose
+// registers allow three workgroups per CU.  PF2: two register sets of operand rows (the next step in flight during this one's
+// MFMAs); the all-bf16 kernel at three waves per SIMD runs with one.
+template <int PREC, bool CONV, bool FULL = false, bool XH = false, bool YH = false, bool LDS2 = false, bool PF2 = (SRAD_WGRAD_PREFETCH != 0)>
 __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int ksplit, const int tn, const int tc,
                                            float* __restrict__ part, const int L) {
   static_assert(!(XH || YH) || (!CONV && PREC == SRAD_PREC_BF16), "bf16 operand storage: Linear layers, bf16 MFMA path");
   extern __shared__ __attribute__((aligned(16))) float wsm[];     // [4 waves][64][68] + [4][64] bias + flag
   constexpr int TST = 68;
-  float* const dbs = wsm + 4 * 64 * TST;
+  float* const dbs = wsm + (LDS2 ? 2 : 4) * 64 * TST;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (linear id L runs on XCD L % 8).  With the row
@@ -92,10 +96,11 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int kspli
 
   // every load is unconditional on a clamped address; masking happens on the registers afterwards.
   // The next step's loads are issued before this step's MFMAs (two register sets).
-  f32x4 av[1 + SRAD_WGRAD_PREFETCH][YH ? 1 : RL], bv[1 + SRAD_WGRAD_PREFETCH][XH ? 1 : RL];
-  u32x2 avh[1 + SRAD_WGRAD_PREFETCH][YH ? RL : 1], bvh[1 + SRAD_WGRAD_PREFETCH][XH ? RL : 1];   // bf16 storage: 4 values = 8 bytes per row
+  constexpr int NSET = PF2 ? 2 : 1;
+  f32x4 av[NSET][YH ? 1 : RL], bv[NSET][XH ? 1 : RL];
+  u32x2 avh[NSET][YH ? RL : 1], bvh[NSET][XH ? RL : 1];   // bf16 storage: 4 values = 8 bytes per row
   unsigned okm[2];                    // bit t: a row valid, bit 8 + t: b row valid
-  float rs[1 + SRAD_WGRAD_PREFETCH][FULL ? 1 : RL];
+  float rs[NSET][FULL ? 1 : RL];
   auto load_step = [&](int m0, auto set_c) {
     constexpr int set = decltype(set_c)::value;
     if constexpr (FULL) {
@@ -228,33 +233,52 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int kspli
     using S1 = std::integral_constant<int, 1>;
     constexpr int ST = 4 * KR;
     int m0 = mb + wave * KR;
-#if SRAD_WGRAD_PREFETCH
-    if (m0 < me) load_step(m0, S0{});
-    while (m0 < me) {
-      if (m0 + ST < me) load_step(m0 + ST, S1{});
-      compute_step(S0{});
-      m0 += ST;
-      if (m0 >= me) break;
-      if (m0 + ST < me) load_step(m0 + ST, S0{});
-      compute_step(S1{});
-      m0 += ST;
+    if constexpr (PF2) {
+      if (m0 < me) load_step(m0, S0{});
+      while (m0 < me) {
+        if (m0 + ST < me) load_step(m0 + ST, S1{});
+        compute_step(S0{});
+        m0 += ST;
+        if (m0 >= me) break;
+        if (m0 + ST < me) load_step(m0 + ST, S0{});
+        compute_step(S1{});
+        m0 += ST;
+      }
+    } else {
+      (void)sizeof(S1);
+      for (; m0 < me; m0 += ST) { load_step(m0, S0{}); compute_step(S0{}); }
     }
-#else
-    (void)sizeof(S1);
-    for (; m0 < me; m0 += ST) { load_step(m0, S0{}); compute_step(S0{}); }
-#endif
   }
 
   // ---- the four waves' partial tiles through LDS (plain 16-byte stores): lane (fq, fr) element e of
   //      acc[en][ec] is (n = 16 fq + 4 e + en, c = 4 fr + ec) ----
   {
-    float* const mine = wsm + wave * 64 * TST;
+    float* const mine = wsm + (LDS2 ? (wave & 1) : wave) * 64 * TST;
+    auto put_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int en = 0; en < 4; ++en)
+      for (int en = 0; en < 4; ++en)
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        *reinterpret_cast<f32x4*>(mine + (16 * fq + 4 * e + en) * TST + 4 * fr) =
-            f32x4{acc[en][0][e], acc[en][1][e], acc[en][2][e], acc[en][3][e]};
+        for (int e = 0; e < 4; ++e)
+          *reinterpret_cast<f32x4*>(mine + (16 * fq + 4 * e + en) * TST + 4 * fr) =
+              f32x4{acc[en][0][e], acc[en][1][e], acc[en][2][e], acc[en][3][e]};
+    };
+    if constexpr (LDS2) {
+      if (wave >= 2) put_tile();
+      __syncthreads();
+      if (wave < 2) {
+#pragma unroll
+        for (int en = 0; en < 4; ++en)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(mine + (16 * fq + 4 * e + en) * TST + 4 * fr);
+#pragma unroll
+            for (int ec = 0; ec < 4; ++ec) acc[en][ec][e] += o[ec];
+          }
+        put_tile();                       // its own slot again: no other wave touches it before the barrier below
+      }
+    } else {
+      put_tile();
+    }
     // bias partial: sum over the four row groups fq, then lanes fq == 0 hold n = 4 fr + e
 #pragma unroll
     for (int e = 0; e < 4; ++e) { bsum[e] += __shfl_xor(bsum[e], 16); bsum[e] += __shfl_xor(bsum[e], 32); }
@@ -268,8 +292,11 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int kspli
   for (int j = 0; j < 4; ++j) {
     const int e4 = tid + 256 * j, nl = e4 >> 4, cl = (e4 & 15) * 4;
     const float* q = wsm + nl * TST + cl;
-    v[j] = (*reinterpret_cast<const f32x4*>(q) + *reinterpret_cast<const f32x4*>(q + 64 * TST)) +
-           (*reinterpret_cast<const f32x4*>(q + 2 * 64 * TST) + *reinterpret_cast<const f32x4*>(q + 3 * 64 * TST));
+    if constexpr (LDS2)
+      v[j] = *reinterpret_cast<const f32x4*>(q) + *reinterpret_cast<const f32x4*>(q + 64 * TST);
+    else
+      v[j] = (*reinterpret_cast<const f32x4*>(q) + *reinterpret_cast<const f32x4*>(q + 64 * TST)) +
+             (*reinterpret_cast<const f32x4*>(q + 2 * 64 * TST) + *reinterpret_cast<const f32x4*>(q + 3 * 64 * TST));
   }
   float vb = 0.f;
   if (tid < 64) vb = (dbs[tid] + dbs[64 + tid]) + (dbs[128 + tid] + dbs[192 + tid]);
@@ -475,6 +502,19 @@ __global__ __launch_bounds__(256, FULL ? 2 : 1) void wgrad_multi_kernel(const Wg
   wgrad_body<PREC, false, FULL>(mp.p[i], mp.ksplit[i], mp.tn[i], mp.tc[i], mp.part[i], L);
 }
 
+// The same for a launch whose layers ALL have both operands stored as bf16 (the training step's blocks 1-4 of every RDG):
+// only that body, so the kernel's register allocation is that body's, and with the two-slot cross-wave sum (36 KB of LDS)
+// four workgroups fit a CU: with ONE register set of operand rows it needs 128 VGPRs (four waves per SIMD cover each other's loads).
+__global__ __launch_bounds__(256, 4) void wgrad_multi_hh_kernel(const WgradMulti mp) {
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < SRAD_WGRAD_MULTI; ++k)
+    if (k < mp.count && (int)blockIdx.x >= mp.blk0[k]) i = k;
+  const int L = blockIdx.x - mp.blk0[i];
+  if (L >= mp.nblk[i]) return;
+  wgrad_body<SRAD_PREC_BF16, false, true, true, true, true, false>(mp.p[i], mp.ksplit[i], mp.tn[i], mp.tc[i], mp.part[i], L);
+}
+
 // One workgroup per QUARTER of a 64 x 64 output tile of one of the batch's layers (16 rows n, one float4 per
 // thread): dW += alpha * sum_k partial[k], k in fixed order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceBatch b) {
@@ -605,6 +645,7 @@ int plan_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s, WgradPlan& pl
 }
 
 constexpr size_t WG_LDS = (size_t)(4 * 64 * 68 + 4 * 64) * sizeof(float);
+constexpr size_t WG_LDS2 = (size_t)(2 * 64 * 68 + 4 * 64) * sizeof(float);   // wgrad_body<.., LDS2 = true>
 
 // 80 -> 80 channels, stride 1, bf16: one 80 x 80 tile per tap
 int launch_wgrad80(const WgradParams& p, WgradQueue& q, hipStream_t s) {
@@ -1575,10 +1616,22 @@ int srad_wgrad_launch_deferred(int prec, WgradQueue& q, hipStream_t stream) {
     for (int i = 0; i < m.count; ++i)
       SRAD_REQUIRE(!(m.p[i].x_bf16 || m.p[i].dy_bf16) || (prec == SRAD_PREC_BF16 && (!m.p[i].dy_bf16 || m.p[i].x_bf16)),
                    "wgrad: bf16 operand storage needs the bf16 MFMA path, dY only together with X");
-    const int rc = prec != SRAD_PREC_BF16 ? launch(wgrad_multi_kernel<SRAD_PREC_F32, false>)
-                   : full                 ? launch(wgrad_multi_kernel<SRAD_PREC_BF16, true>)
-                                          : launch(wgrad_multi_kernel<SRAD_PREC_BF16, false>);
-    if (rc) return rc;
+    bool all_hh = full;                                // every layer with both operands as bf16: the lean kernel
+    for (int i = 0; i < m.count && all_hh; ++i) all_hh = m.p[i].x_bf16 && m.p[i].dy_bf16;
+    static const bool no_hh = getenv("SRAD_WGRAD_NO_HH") != nullptr;
+    if (all_hh && !no_hh) {
+      static bool configured_hh = false;
+      if (!configured_hh) {
+        SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_multi_hh_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS2));
+        configured_hh = true;
+      }
+      hipLaunchKernelGGL(wgrad_multi_hh_kernel, dim3(total), dim3(256), WG_LDS2, stream, m);
+    } else {
+      const int rc = prec != SRAD_PREC_BF16 ? launch(wgrad_multi_kernel<SRAD_PREC_F32, false>)
+                     : full                 ? launch(wgrad_multi_kernel<SRAD_PREC_BF16, true>)
+                                            : launch(wgrad_multi_kernel<SRAD_PREC_BF16, false>);
+      if (rc) return rc;
+    }
     SRAD_CHECK_HIP(hipGetLastError());
   }
   m.count = 0; q.multi_flops = 0; q.multi_bytes = 0;
