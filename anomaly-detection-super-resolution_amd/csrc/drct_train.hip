@@ -490,6 +490,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       float *dx2 = w.dx2[set], *dx1 = w.dx1[set], *dh = w.dh[set], *dqkv = w.dqkv[set];
       // with the adjust prologue fused the dx2 buffer only holds the bf16 copy (its first half): dx1 * rs1 as bf16 goes behind it
       const bool yh_dx1 = yh_dx2 && fuse_proj;
+      __bf16* const dA5_h = reinterpret_cast<__bf16*>(dh) + (size_t)T * sw.hidden;     // second half of the dh buffer (dh itself is bf16 then)
       __bf16* const dx1s_h = reinterpret_cast<__bf16*>(dx2) + (size_t)T * d;
       // ---- adjust_k: 1x1 conv (+ LeakyReLU 0.2 | * 0.2)                        (drct.py:389-393)
       // ---- MLP branch: x2 = x1 + rs2 * fc2(gelu(fc1(LN2(x1))))                 (drct.py:510, 184-190)
@@ -503,6 +504,9 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
       {
         WgradParams g = wgrad_of(h, sw.adjust, G, dA, ldA, 0, sv.x2, d, T);
         g.alpha = aalpha; g.x_bf16 = xh; g.dy_bf16 = yh_dx2 && k < 4;      // (mlp_bwd writes w.dA as bf16 then)
+        if (yh_dx2 && k == 4) {   // adjust5: mlp_bwd leaves a bf16 copy of its incoming gradient (the RDG's input gradient, fp32, ld D)
+          g.dY = reinterpret_cast<const float*>(dA5_h); g.ldy = KA; g.dy_bf16 = 1;      // behind the bf16 dh: every layer of the launch is bf16
+        }
         SRAD_TRY(srad_launch_wgrad_deferred(prec, g, wq, side));
         if (!fuse_adj) {
           GemmParams p = dgrad_gemm(h, sw.adjust, dA, ldA, T, dx2, d);
@@ -536,7 +540,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
             mb.dA = gc + d; mb.ld_dA = D; mb.y_act = cur + d; mb.ld_y = D; mb.dA_out = w.dA[set];
             if (yh_dx2) mb.dA_out_h = reinterpret_cast<__bf16*>(w.dA[set]);       // the adjust weight gradient takes it as bf16
           }
-          else { mb.dA = gn; mb.ld_dA = D; }
+          else { mb.dA = gn; mb.ld_dA = D; if (yh_dx2) mb.dA_out_h = dA5_h; }
         }
         if (fuse_proj) { mb.w_projt = h->ts.tarena + h->ts.tf_off[sw.proj.w]; mb.rs1 = ks1; mb.rps = HW; mb.dO = w.dO; }
         if (fuse_proj && attn_h) { mb.dO_h = reinterpret_cast<__bf16*>(w.dO); mb.dO_heads = sw.heads; mb.dO_hp = attn_hp(sw); }
