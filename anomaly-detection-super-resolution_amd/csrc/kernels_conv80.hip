@@ -1,0 +1,218 @@
+// kernels_conv80.hip - the 80 -> 80 channel 3x3 convolution of DRN-L's RCAB chains (reference src/drn.py:143-158: 160 of
+// them per forward, most of the model's FLOPs) as a weight-resident, persistent kernel for gfx950.
+//
+// The tiled GEMM (kernels_gemm.hip) gives every 128-pixel tile its own workgroup, which streams the whole 115 KB weight and
+// nine shifted copies of its input rows through six load -> LDS -> barrier -> MFMA stages: 41 us per launch, 230 TFLOP/s.
+// Here a workgroup keeps the WHOLE weight in LDS (80 rows x 736 k as bf16, 119 KB) for its lifetime and walks pixel tiles of
+// 4 rows x 32 columns: a tile's input halo (6 x 34 pixels x 80 channels) is fetched once - each input pixel once, not once
+// per tap - rounded to bf16 into a 36 KB LDS tile, and all nine taps read it through shifted addresses.  The next tile's
+// halo is in flight in registers while the current one is multiplied.  K runs over (tap, channel) = 720 values in 32-wide
+// chunks; a chunk may straddle two taps, which only changes the pixel offset per lane group (a lane's eight k values never
+// straddle: 8 divides 80).  MFMA operands are swapped (A = weight fragment, B = activation fragment), so a lane ends with four
+// consecutive output channels of one pixel: bias / residual / output are float4.
+// Same arithmetic as the GEMM path (bf16 operands, fp32 accumulation); the summation order over k differs.
+#include "srad_common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int C80_K = 736;                // 9 taps x 80 channels = 720, padded to 23 chunks of 32 (the weight rows are zero there)
+constexpr int C80_WLD = C80_K + 8;        // LDS row stride of the weight (elements): 1488 B, rows land on distinct bank groups
+constexpr int C80_PLD = 88;               // LDS pixel stride of the halo tile (elements): 176 B
+constexpr int C80_TH = 4, C80_TW = 32;    // output tile: 4 rows x 32 columns = 128 pixels; wave w owns row w
+constexpr int C80_HH = C80_TH + 2, C80_HW = C80_TW + 2;
+constexpr int C80_HCH = C80_HH * C80_HW * 20;      // float4 chunks of a halo tile (20 per pixel)
+constexpr int C80_NT = 512;                         // threads: wave = (tile row, half of the output channels)
+constexpr int C80_NL = (C80_HCH + C80_NT - 1) / C80_NT;      // per thread
+constexpr size_t C80_LDS = (size_t)(80 * C80_WLD + C80_HH * C80_HW * C80_PLD) * sizeof(__bf16) + 4 * 80 * sizeof(float);
+
+__global__ __launch_bounds__(C80_NT) void conv80_kernel(const GemmParams p, const int ntiles, const int tiles_x, const int tiles_per_img) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* const Ws = reinterpret_cast<__bf16*>(smem);                       // [80][C80_WLD]
+  __bf16* const Hs = Ws + 80 * C80_WLD;                                     // [6 * 34][C80_PLD]
+  float* const red = reinterpret_cast<float*>(Hs + C80_HH * C80_HW * C80_PLD);   // [4][80] pool partials
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int H = p.Hi, W = p.Wi;
+
+  // ---- halo of tile t -> registers (clamped addresses, zero outside the image) ----
+  f32x4 hreg[C80_NL];
+  unsigned hok = 0u;
+  auto load_halo = [&](int t) __attribute__((always_inline)) {
+    const int b = t / tiles_per_img, tl = t - b * tiles_per_img;
+    const int ty = tl / tiles_x, tx = tl - ty * tiles_x;
+    const int y0 = ty * C80_TH - 1, x0 = tx * C80_TW - 1;
+    hok = 0u;
+#pragma unroll
+    for (int i = 0; i < C80_NL; ++i) {
+      const int idx = min(tid + C80_NT * i, C80_HCH - 1);
+      const int hp = idx / 20, c4 = idx - hp * 20;
+      const int hy = hp / C80_HW, hx = hp - hy * C80_HW;
+      const int yy = y0 + hy, xx = x0 + hx;
+      const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+      hreg[i] = *reinterpret_cast<const f32x4*>(p.X + ((size_t)(b * H + yc) * W + xc) * p.ldx + 4 * c4);
+      hok |= in ? (1u << i) : 0u;
+    }
+  };
+  auto store_halo = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < C80_NL; ++i) {
+      const int idx = tid + C80_NT * i;
+      if (idx < C80_HCH) {
+        const int hp = idx / 20, c4 = idx - hp * 20;
+        const f32x4 v = (hok >> i) & 1u ? hreg[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x4 h;
+        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+        *reinterpret_cast<bf16x4*>(Hs + hp * C80_PLD + 4 * c4) = h;
+      }
+    }
+  };
+
+  int t = blockIdx.x;
+  load_halo(t);
+  // ---- the weight, once: global [Np][9][96] bf16 -> LDS [80][tap * 80 + ch | 16 zeros] ----
+  {
+    // 80 x 92 sixteen-byte pieces (90 real + 2 zero per row): all of a batch's loads in flight before its first LDS store
+    // (as a run-time loop each of the 29 rounds waited for its own load: 25 us per launch)
+    const u32x4* const wg = reinterpret_cast<const u32x4*>(p.Wp);
+    constexpr int NP = 80 * 92, NB = 15;
+#pragma unroll
+    for (int i0 = 0; i0 < (NP + C80_NT - 1) / C80_NT; i0 += NB) {
+      u32x4 wr[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int idx = min(tid + C80_NT * (i0 + i), NP - 1);
+        const int n = idx / 92, pc = min(idx - n * 92, 89);
+        const int tap = pc / 10, c8 = pc - tap * 10;
+        wr[i] = wg[(n * (9 * 96) + tap * 96 + c8 * 8) / 8];
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int idx = tid + C80_NT * (i0 + i);
+        const int n = idx / 92, pc = idx - n * 92;
+        if (idx < NP) *reinterpret_cast<u32x4*>(Ws + n * C80_WLD + pc * 8) = pc < 90 ? wr[i] : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  }
+  store_halo();
+  __syncthreads();
+
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int row = wave & 3, nh = wave >> 2;                   // this wave: tile row, and output channel tiles {0, 1, 2} or {3, 4}
+  // One tile: NTW channel tiles from nt0 on.  The k walk is incremental: a lane's first k of chunk kc is 32 kc + 8 fq, i.e.
+  // (tap, ch) advances by 32 channels per chunk and wraps into the next tap at 80.
+  auto tile = [&](auto NTW_c, const int nt0, const int t) __attribute__((always_inline)) {
+    constexpr int NTW = decltype(NTW_c)::value;
+    f32x4 acc[2][NTW];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) acc[rt][nt] = z4;
+    int ch = 8 * fq, dx = 0, rowoff = (row * C80_HW + fr) * C80_PLD;
+    const __bf16* const wrow = Ws + (nt0 * 16 + fr) * C80_WLD + 8 * fq;
+#pragma unroll
+    for (int kc = 0; kc < C80_K / 32; ++kc) {
+      int off = rowoff + dx * C80_PLD + ch;
+      if (kc == C80_K / 32 - 1 && fq >= 2) off = (row * C80_HW + fr) * C80_PLD;      // k >= 720: the weights are zero there, any valid address does
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(Hs + off);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Hs + off + 16 * C80_PLD);
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const bf16x8 w = *reinterpret_cast<const bf16x8*>(wrow + nt * 16 * C80_WLD + 32 * kc);
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a0, acc[0][nt], 0, 0, 0);
+        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a1, acc[1][nt], 0, 0, 0);
+      }
+      ch += 32;
+      if (ch >= 80) {
+        ch -= 80;
+        if (++dx == 3) { dx = 0; rowoff += C80_HW * C80_PLD; }
+      }
+    }
+    // ---- epilogue: + bias -> activation -> * alpha -> residual mode -> store (GemmParams semantics) ----
+    const int b = t / tiles_per_img, tl = t - b * tiles_per_img;
+    const int ty = tl / tiles_x, tx = tl - ty * tiles_x;
+    const int yy = ty * C80_TH + row;
+    f32x4 csum[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) csum[nt] = z4;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const size_t pix = (size_t)(b * H + yy) * W + tx * C80_TW + rt * 16 + fr;
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int c = (nt0 + nt) * 16 + 4 * fq;
+        f32x4 v = acc[rt][nt];
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + c);
+        if (p.act == SRAD_ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (p.act == SRAD_ACT_LRELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+        }
+        v = v * p.alpha;
+        if (p.R) {
+          const f32x4 r = *reinterpret_cast<const f32x4*>(p.R + pix * p.ldr + c);
+          if (p.rmode == SRAD_RMODE_ADD) v += r;
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= r[e] > 0.f ? 1.f : p.slope;
+          }
+        }
+        *reinterpret_cast<f32x4*>(p.Y + pix * p.ldy + p.yoff + c) = v;
+        csum[nt] += v;
+      }
+    }
+    if (p.pool_part) {                                        // the tile's column sums: 16 pixels per lane group, then the four rows
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) csum[nt][e] = srad_row16_sum(csum[nt][e]);
+      if (fr == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) *reinterpret_cast<f32x4*>(red + row * 80 + (nt0 + nt) * 16 + 4 * fq) = csum[nt];
+      }
+    }
+  };
+  while (true) {
+    const int tn = t + gridDim.x;
+    const bool more = tn < ntiles;
+    load_halo(more ? tn : t);                                 // (the last tile loads itself again: no load behind a branch)
+    if (nh == 0) tile(std::integral_constant<int, 3>{}, 0, t);
+    else tile(std::integral_constant<int, 2>{}, 3, t);
+    __syncthreads();                                          // everyone is done with the halo tile (and red is written)
+    if (p.pool_part && tid < 80) p.pool_part[(size_t)t * 80 + tid] = (red[tid] + red[80 + tid]) + (red[160 + tid] + red[240 + tid]);
+    if (!more) break;
+    store_halo();
+    t = tn;
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+bool srad_conv80_supported(int prec, const GemmParams& p) {
+  static const bool off = getenv("SRAD_NO_CONV80") != nullptr;
+  return !off && prec == SRAD_PREC_BF16 && p.ntaps == 9 && p.stride == 1 && p.Cin == 80 && p.N == 80 && !p.ln_g && p.ps == 0 &&
+         p.hsplit_hd == 0 && !p.row_scale && !p.Ypre && p.Hi == p.Ho && p.Wi == p.Wo && p.Hi % C80_TH == 0 && p.Wi % C80_TW == 0 &&
+         (!p.R || p.rmode == SRAD_RMODE_ADD || p.rmode == SRAD_RMODE_DLRELU) && (p.ldx & 3) == 0 && (p.ldy & 3) == 0 && (p.yoff & 3) == 0 &&
+         (!p.R || (p.ldr & 3) == 0) && (((uintptr_t)p.X | (uintptr_t)p.Y | (uintptr_t)p.R | (uintptr_t)p.bias | (uintptr_t)p.Wp) & 15) == 0 &&
+         p.M >= 128 * 64;                                        // small launches stay on the tiled GEMM (one tile per workgroup anyway)
+}
+
+int srad_launch_conv80(const GemmParams& p, hipStream_t stream) {
+  SRAD_REQUIRE(srad_conv80_supported(SRAD_PREC_BF16, p), "conv80: unsupported problem");
+  const int tiles_x = p.Wi / C80_TW, tiles_per_img = (p.Hi / C80_TH) * tiles_x;
+  const int B = p.M / (p.Hi * p.Wi), ntiles = B * tiles_per_img;
+  static bool configured = false;
+  if (!configured) {
+    SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv80_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C80_LDS));
+    configured = true;
+  }
+  const double K = 9.0 * 80;
+  SradProfScope prof(stream, SRAD_K_GEMM_BN64, 2.0 * p.M * 80 * K, 4.0 * p.M * 80 * (p.R ? 3 : 2) + 2.0 * 80 * K);
+  hipLaunchKernelGGL(conv80_kernel, dim3(ntiles < 256 ? ntiles : 256), dim3(C80_NT), C80_LDS, stream, p, ntiles, tiles_x, tiles_per_img);
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}

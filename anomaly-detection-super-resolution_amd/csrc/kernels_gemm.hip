@@ -602,6 +602,7 @@ int launch_prec(const GemmParams& p, hipStream_t s) {
 }  // namespace
 
 int srad_gemm_tile_rows(int prec, const GemmParams& p) {      // keep in step with launch_prec
+  if (srad_conv80_supported(prec, p)) return 128;              // 4 x 32-pixel tiles of conv80_kernel
   auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   if (!p.ln_g) {
     if (p.N <= 16 && tiles(128, 16) >= 384) return 128;
@@ -628,6 +629,7 @@ int srad_launch_gemm(int prec, const GemmParams& p, hipStream_t stream) {
                "gemm: activations need a channel count and row stride that are multiples of 4 floats (Cin=%d ldx=%d)", p.Cin, p.ldx);
   if (p.ntaps == 9 || p.stride != 1 || p.ps)
     SRAD_REQUIRE(p.Ho > 0 && p.Wo > 0 && p.M % (p.Ho * p.Wo) == 0, "gemm: M=%d not a multiple of Ho*Wo=%d*%d", p.M, p.Ho, p.Wo);
+  if (srad_conv80_supported(prec, p)) return srad_launch_conv80(p, stream);
   int rc = prec == SRAD_PREC_BF16 ? launch_prec<SRAD_PREC_BF16>(p, stream) : launch_prec<SRAD_PREC_F32>(p, stream);
   if (rc) return rc;
   SRAD_CHECK_HIP(hipGetLastError());

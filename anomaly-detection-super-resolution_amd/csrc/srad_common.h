@@ -137,6 +137,9 @@ enum { SRAD_RMODE_ADD = 0, SRAD_RMODE_DGELU = 1, SRAD_RMODE_DLRELU = 2 };
 
 int srad_launch_gemm(int prec, const GemmParams& p, hipStream_t stream);
 int srad_gemm_tile_rows(int prec, const GemmParams& p);     // rows per workgroup tile srad_launch_gemm will pick for p
+// DRN-L's 80 -> 80 channel 3x3 convolutions: weight-resident persistent kernel (kernels_conv80.hip); srad_launch_gemm routes to it
+bool srad_conv80_supported(int prec, const GemmParams& p);
+int srad_launch_conv80(const GemmParams& p, hipStream_t stream);
 
 // Packed weight geometry shared by the packer and the GEMM
 static inline int srad_cp(int cin) { return srad_round_up(cin, 32); }
