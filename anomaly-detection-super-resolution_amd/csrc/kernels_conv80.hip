@@ -16,6 +16,14 @@
 
 namespace {
 
+template <int B, int N, class F>
+__device__ __forceinline__ void c80_static_for(F&& f) {
+  if constexpr (B < N) {
+    f(std::integral_constant<int, B>{});
+    c80_static_for<B + 1, N>(f);
+  }
+}
+
 constexpr int C80_K = 736;                // 9 taps x 80 channels = 720, padded to 23 chunks of 32 (the weight rows are zero there)
 constexpr int C80_WLD = C80_K + 8;        // LDS row stride of the weight (elements): 1488 B, rows land on distinct bank groups
 constexpr int C80_PLD = 88;               // LDS pixel stride of the halo tile (elements): 176 B
@@ -111,24 +119,37 @@ __global__ __launch_bounds__(C80_NT) void conv80_kernel(const GemmParams p, cons
       for (int nt = 0; nt < NTW; ++nt) acc[rt][nt] = z4;
     int ch = 8 * fq, dx = 0, rowoff = (row * C80_HW + fr) * C80_PLD;
     const __bf16* const wrow = Ws + (nt0 * 16 + fr) * C80_WLD + 8 * fq;
+    // fragments of chunk kc + DEPTH are requested before chunk kc is multiplied (three register sets): with two waves per SIMD
+    // and the compiler's one-chunk look-ahead the waves spent 59 % of their time parked on LDS latency (SQ_WAIT_ANY)
+    constexpr int NCH = C80_K / 32, DEPTH = 2;
+    bf16x8 fa[DEPTH + 1][2], fw[DEPTH + 1][NTW];
+    auto fetch = [&](auto KC) __attribute__((always_inline)) {
+      constexpr int kc = decltype(KC)::value;
+      if constexpr (kc < NCH) {
+        constexpr int st = kc % (DEPTH + 1);
+        int off = rowoff + dx * C80_PLD + ch;
+        if (kc == NCH - 1 && fq >= 2) off = (row * C80_HW + fr) * C80_PLD;      // k >= 720: the weights are zero there, any valid address does
+        fa[st][0] = *reinterpret_cast<const bf16x8*>(Hs + off);
+        fa[st][1] = *reinterpret_cast<const bf16x8*>(Hs + off + 16 * C80_PLD);
 #pragma unroll
-    for (int kc = 0; kc < C80_K / 32; ++kc) {
-      int off = rowoff + dx * C80_PLD + ch;
-      if (kc == C80_K / 32 - 1 && fq >= 2) off = (row * C80_HW + fr) * C80_PLD;      // k >= 720: the weights are zero there, any valid address does
-      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(Hs + off);
-      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Hs + off + 16 * C80_PLD);
+        for (int nt = 0; nt < NTW; ++nt) fw[st][nt] = *reinterpret_cast<const bf16x8*>(wrow + nt * 16 * C80_WLD + 32 * kc);
+        ch += 32;
+        if (ch >= 80) {
+          ch -= 80;
+          if (++dx == 3) { dx = 0; rowoff += C80_HW * C80_PLD; }
+        }
+      }
+    };
+    c80_static_for<0, DEPTH>([&](auto K) { fetch(K); });
+    c80_static_for<0, NCH>([&](auto K) {
+      constexpr int kc = decltype(K)::value, st = kc % (DEPTH + 1);
+      fetch(std::integral_constant<int, kc + DEPTH>{});
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
-        const bf16x8 w = *reinterpret_cast<const bf16x8*>(wrow + nt * 16 * C80_WLD + 32 * kc);
-        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a0, acc[0][nt], 0, 0, 0);
-        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a1, acc[1][nt], 0, 0, 0);
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[st][nt], fa[st][0], acc[0][nt], 0, 0, 0);
+        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[st][nt], fa[st][1], acc[1][nt], 0, 0, 0);
       }
-      ch += 32;
-      if (ch >= 80) {
-        ch -= 80;
-        if (++dx == 3) { dx = 0; rowoff += C80_HW * C80_PLD; }
-      }
-    }
+    });
     // ---- epilogue: + bias -> activation -> * alpha -> residual mode -> store (GemmParams semantics) ----
     const int b = t / tiles_per_img, tl = t - b * tiles_per_img;
     const int ty = tl / tiles_x, tx = tl - ty * tiles_x;

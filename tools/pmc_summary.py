@@ -53,7 +53,7 @@ def classify(name: str) -> str:
         return {"64": "gemm_bn64", "32": "gemm_bn32", "16": "gemm_bn16"}.get(args[2], "gemm")
     for key, cls in (("mlp_block_kernel", "mlp_block"), ("qkv_attn_kernel", "qkv_attn"), ("swin_block_kernel", "swin_block"),
                      ("window_attn_bwd", "window_attn_bwd"), ("window_attn_kernel", "window_attn"), ("layernorm_kernel", "layernorm"),
-                     ("wgrad_multi_kernel", "wgrad"), ("wgrad_kernel", "wgrad"), ("wgrad_reduce_kernel", "wgrad_reduce"),
+                     ("wgrad_multi", "wgrad"), ("conv80_kernel", "conv80"), ("wgrad_kernel", "wgrad"), ("wgrad_reduce_kernel", "wgrad_reduce"),
                      ("ln_bwd_kernel", "layernorm_bwd"), ("mlp_bwd_kernel", "mlp_bwd"), ("lin_ln_bwd_kernel", "lin_ln_bwd"),
                      ("sat_", "scorer"), ("ssim_eval", "scorer")):
         if key in name:
