@@ -377,14 +377,19 @@ int forward_body(srad_drn* h, const float* x, int B, int H, int W, float* const*
     float* nxt = w.rb;
     for (int b = 0; b < c.n_blocks; ++b) {
       const RcabW& r = h->rcab[idx][b];
+      bool t_bf16 = false;      // the ReLU output between the two convolutions as bf16 (only the second conv reads it) when both take conv80
       {  // conv + ReLU                                         (drn.py:147-150)
         GemmParams p = conv_params(h, r.c0, xin, ldin, B, Hl, Wl, 1, w.rt, ch, 0);
         p.act = SRAD_ACT_RELU;
+        GemmParams q = conv_params(h, r.c1, w.rt, ch, B, Hl, Wl, 1, w.rr, ch, 0);
+        t_bf16 = srad_conv80_supported(prec, p) && srad_conv80_supported(prec, q) && getenv("SRAD_DRN_T_F32") == nullptr;
+        if (t_bf16) p.Yh = reinterpret_cast<__bf16*>(w.rt);
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
       int nchunk = DRN_POOL_CHUNKS;
       {  // conv; its epilogue also leaves the global average pool's partial sums, one row per row tile  (drn.py:147-150, 127)
         GemmParams p = conv_params(h, r.c1, w.rt, ch, B, Hl, Wl, 1, w.rr, ch, 0);
+        if (t_bf16) p.Xh = reinterpret_cast<const __bf16*>(w.rt);
         nchunk = pool_rows_per_image(prec, p, Hl * Wl);
         if (nchunk > 0) p.pool_part = w.pool;
         SRAD_TRY(srad_launch_gemm(prec, p, s));

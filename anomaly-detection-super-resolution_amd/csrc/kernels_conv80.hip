@@ -34,6 +34,7 @@ constexpr int C80_NT = 512;                         // threads: wave = (tile row
 constexpr int C80_NL = (C80_HCH + C80_NT - 1) / C80_NT;      // per thread
 constexpr size_t C80_LDS = (size_t)(80 * C80_WLD + C80_HH * C80_HW * C80_PLD) * sizeof(__bf16) + 4 * 80 * sizeof(float);
 
+template <bool XH>
 __global__ __launch_bounds__(C80_NT) void conv80_kernel(const GemmParams p, const int ntiles, const int tiles_x, const int tiles_per_img) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* const Ws = reinterpret_cast<__bf16*>(smem);                       // [80][C80_WLD]
@@ -44,7 +45,8 @@ __global__ __launch_bounds__(C80_NT) void conv80_kernel(const GemmParams p, cons
   const int H = p.Hi, W = p.Wi;
 
   // ---- halo of tile t -> registers (clamped addresses, zero outside the image) ----
-  f32x4 hreg[C80_NL];
+  typedef typename std::conditional<XH, u32x2, f32x4>::type hreg_t;       // four channels of a halo pixel
+  hreg_t hreg[C80_NL];
   unsigned hok = 0u;
   auto load_halo = [&](int t) __attribute__((always_inline)) {
     const int b = t / tiles_per_img, tl = t - b * tiles_per_img;
@@ -59,7 +61,9 @@ __global__ __launch_bounds__(C80_NT) void conv80_kernel(const GemmParams p, cons
       const int yy = y0 + hy, xx = x0 + hx;
       const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
       const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
-      hreg[i] = *reinterpret_cast<const f32x4*>(p.X + ((size_t)(b * H + yc) * W + xc) * p.ldx + 4 * c4);
+      const size_t off = ((size_t)(b * H + yc) * W + xc) * p.ldx + 4 * c4;
+      if constexpr (XH) hreg[i] = *reinterpret_cast<const u32x2*>(p.Xh + off);
+      else hreg[i] = *reinterpret_cast<const f32x4*>(p.X + off);
       hok |= in ? (1u << i) : 0u;
     }
   };
@@ -69,10 +73,14 @@ __global__ __launch_bounds__(C80_NT) void conv80_kernel(const GemmParams p, cons
       const int idx = tid + C80_NT * i;
       if (idx < C80_HCH) {
         const int hp = idx / 20, c4 = idx - hp * 20;
-        const f32x4 v = (hok >> i) & 1u ? hreg[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-        bf16x4 h;
-        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-        *reinterpret_cast<bf16x4*>(Hs + hp * C80_PLD + 4 * c4) = h;
+        if constexpr (XH) {
+          *reinterpret_cast<u32x2*>(Hs + hp * C80_PLD + 4 * c4) = (hok >> i) & 1u ? hreg[i] : u32x2{0u, 0u};
+        } else {
+          const f32x4 v = (hok >> i) & 1u ? hreg[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+          bf16x4 h;
+          h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+          *reinterpret_cast<bf16x4*>(Hs + hp * C80_PLD + 4 * c4) = h;
+        }
       }
     }
   };
@@ -181,7 +189,13 @@ __global__ __launch_bounds__(C80_NT) void conv80_kernel(const GemmParams p, cons
             for (int e = 0; e < 4; ++e) v[e] *= r[e] > 0.f ? 1.f : p.slope;
           }
         }
-        *reinterpret_cast<f32x4*>(p.Y + pix * p.ldy + p.yoff + c) = v;
+        if (p.Yh) {
+          bf16x4 h;
+          h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+          *reinterpret_cast<bf16x4*>(p.Yh + pix * p.ldy + p.yoff + c) = h;
+        } else {
+          *reinterpret_cast<f32x4*>(p.Y + pix * p.ldy + p.yoff + c) = v;
+        }
         csum[nt] += v;
       }
     }
@@ -219,6 +233,7 @@ bool srad_conv80_supported(int prec, const GemmParams& p) {
          p.hsplit_hd == 0 && !p.row_scale && !p.Ypre && p.Hi == p.Ho && p.Wi == p.Wo && p.Hi % C80_TH == 0 && p.Wi % C80_TW == 0 &&
          (!p.R || p.rmode == SRAD_RMODE_ADD || p.rmode == SRAD_RMODE_DLRELU) && (p.ldx & 3) == 0 && (p.ldy & 3) == 0 && (p.yoff & 3) == 0 &&
          (!p.R || (p.ldr & 3) == 0) && (((uintptr_t)p.X | (uintptr_t)p.Y | (uintptr_t)p.R | (uintptr_t)p.bias | (uintptr_t)p.Wp) & 15) == 0 &&
+         (((uintptr_t)p.Xh | (uintptr_t)p.Yh) & 7) == 0 &&
          p.M >= 128 * 64;                                        // small launches stay on the tiled GEMM (one tile per workgroup anyway)
 }
 
@@ -228,12 +243,14 @@ int srad_launch_conv80(const GemmParams& p, hipStream_t stream) {
   const int B = p.M / (p.Hi * p.Wi), ntiles = B * tiles_per_img;
   static bool configured = false;
   if (!configured) {
-    SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv80_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C80_LDS));
+    SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv80_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C80_LDS));
+    SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv80_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C80_LDS));
     configured = true;
   }
   const double K = 9.0 * 80;
   SradProfScope prof(stream, SRAD_K_GEMM_BN64, 2.0 * p.M * 80 * K, 4.0 * p.M * 80 * (p.R ? 3 : 2) + 2.0 * 80 * K);
-  hipLaunchKernelGGL(conv80_kernel, dim3(ntiles < 256 ? ntiles : 256), dim3(C80_NT), C80_LDS, stream, p, ntiles, tiles_x, tiles_per_img);
+  if (p.Xh) hipLaunchKernelGGL(conv80_kernel<true>, dim3(ntiles < 256 ? ntiles : 256), dim3(C80_NT), C80_LDS, stream, p, ntiles, tiles_x, tiles_per_img);
+  else hipLaunchKernelGGL(conv80_kernel<false>, dim3(ntiles < 256 ? ntiles : 256), dim3(C80_NT), C80_LDS, stream, p, ntiles, tiles_x, tiles_per_img);
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
 }

@@ -126,6 +126,9 @@ struct GemmParams {
   // fixed order) - the global average pool of DRN's channel attention without a pass of its own; an image must be a whole
   // number of row tiles (srad_gemm_tile_rows)
   float* pool_part = nullptr;
+  // conv80 only (srad_conv80_supported): the input as bf16 (same ldx, in elements) / the output as bf16 through Yh without
+  // hsplit - the ReLU output between an RCAB's two convolutions, which only the second one reads
+  const __bf16* Xh = nullptr;
   // ---- training extensions (all off when zero) ----
   int rmode;                 // how R enters: 0 v = act(acc)*alpha*rs + R (residual); 1 v = acc*alpha*rs * gelu'(R);
                              //               2 v = acc*alpha*rs * (R > 0 ? 1 : slope)   (backward through an activation)
