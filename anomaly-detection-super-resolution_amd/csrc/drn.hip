@@ -155,6 +155,7 @@ __global__ void scale_add_kernel(const float* __restrict__ r, const float* __res
 // rows - cheaper than a launch boundary, and the lone one-workgroup-per-image gate kernel took 12 us) and then streams
 // its slice of the image: out = r * gate[b] + x.  grid = (slices per image, B); the slice-0 workgroups also write the gate
 // and the pooled sums when the caller keeps them (training).
+template <bool RH>      // RH: r is a bf16 array (the eval path's conv80 wrote it so; half the bytes of this bandwidth-bound pass's largest read)
 __global__ __launch_bounds__(256) void ca_scale_add_kernel(const float* __restrict__ part, int nchunk, float inv_hw, int C, int Cr,
                                                            const float* __restrict__ w1, const float* __restrict__ b1,
                                                            const float* __restrict__ w2, const float* __restrict__ b2,
@@ -204,7 +205,13 @@ __global__ __launch_bounds__(256) void ca_scale_add_kernel(const float* __restri
   for (int i = tid; i < (p1 - p0) * c4n; i += 256) {
     const int pl = i / c4n, c = (i - pl * c4n) * 4;
     const size_t pix = base + p0 + pl;
-    const f32x4 rv = *reinterpret_cast<const f32x4*>(r + pix * C + c);
+    f32x4 rv;
+    if constexpr (RH) {
+      const bf16x4 rh = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(r) + pix * C + c);
+      rv = f32x4{(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
+    } else {
+      rv = *reinterpret_cast<const f32x4*>(r + pix * C + c);
+    }
     const f32x4 xv = *reinterpret_cast<const f32x4*>(x + pix * ldx + c);
     *reinterpret_cast<f32x4*>(y + pix * C + c) = rv * *reinterpret_cast<const f32x4*>(gt + c) + xv;
   }
@@ -387,11 +394,14 @@ int forward_body(srad_drn* h, const float* x, int B, int H, int W, float* const*
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
       int nchunk = DRN_POOL_CHUNKS;
+      bool nchunk_fused = false;
       {  // conv; its epilogue also leaves the global average pool's partial sums, one row per row tile  (drn.py:147-150, 127)
         GemmParams p = conv_params(h, r.c1, w.rt, ch, B, Hl, Wl, 1, w.rr, ch, 0);
-        if (t_bf16) p.Xh = reinterpret_cast<const __bf16*>(w.rt);
+        if (t_bf16) { p.Xh = reinterpret_cast<const __bf16*>(w.rt); p.Yh = reinterpret_cast<__bf16*>(w.rr); }   // r as bf16 too: the pool sums come from the fp32 values in the epilogue
         nchunk = pool_rows_per_image(prec, p, Hl * Wl);
+        nchunk_fused = nchunk > 0;
         if (nchunk > 0) p.pool_part = w.pool;
+        else p.Yh = nullptr;                                      // the separate pooling pass reads r as fp32
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
       if (nchunk == 0) {  // global average pool (partial rows) as a pass of its own                          (drn.py:127-138)
@@ -402,9 +412,14 @@ int forward_body(srad_drn* h, const float* x, int B, int H, int W, float* const*
       }
       {  // the gate, and res = body(x) * gate + x               (drn.py:128-139, 156-157)
         SradProfScope prof(s, SRAD_K_MISC, 2.0 * T * ch, 12.0 * T * ch);
-        hipLaunchKernelGGL(ca_scale_add_kernel, dim3(ca_slices(Hl * Wl), B), dim3(256), 0, s, w.pool, nchunk,
-                           1.0f / (float)(Hl * Wl), ch, ch / 16, h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2),
-                           (float*)nullptr, (float*)nullptr, w.rr, xin, ldin, cur, Hl * Wl);
+        if (t_bf16 && nchunk_fused)
+          hipLaunchKernelGGL(ca_scale_add_kernel<true>, dim3(ca_slices(Hl * Wl), B), dim3(256), 0, s, w.pool, nchunk,
+                             1.0f / (float)(Hl * Wl), ch, ch / 16, h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2),
+                             (float*)nullptr, (float*)nullptr, w.rr, xin, ldin, cur, Hl * Wl);
+        else
+          hipLaunchKernelGGL(ca_scale_add_kernel<false>, dim3(ca_slices(Hl * Wl), B), dim3(256), 0, s, w.pool, nchunk,
+                             1.0f / (float)(Hl * Wl), ch, ch / 16, h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2),
+                             (float*)nullptr, (float*)nullptr, w.rr, xin, ldin, cur, Hl * Wl);
       }
       SRAD_CHECK_HIP(hipGetLastError());
       xin = cur; ldin = ch;
@@ -1016,7 +1031,7 @@ int srad_drn_forward_train(srad_drn_t* h, const float* x, int B, int H, int W, f
         hipLaunchKernelGGL(pool_dot_kernel, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, (const float*)nullptr, sv.r, w.ppart, Hl * Wl, ch,
                            DRN_POOL_CHUNKS);
       }
-      hipLaunchKernelGGL(ca_scale_add_kernel, dim3(ca_slices(Hl * Wl), B), dim3(256), 0, s, w.ppart, nchunk,
+      hipLaunchKernelGGL(ca_scale_add_kernel<false>, dim3(ca_slices(Hl * Wl), B), dim3(256), 0, s, w.ppart, nchunk,
                          1.0f / (float)(Hl * Wl), ch, ch / 16, h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2),
                          sv.gate, sv.pool, sv.r, xin, ldin, sv.xo, Hl * Wl);
       SRAD_CHECK_HIP(hipGetLastError());
