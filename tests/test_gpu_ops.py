@@ -69,6 +69,36 @@ def test_conv3x3(dev, prec, B, H, W, Cin, Cout, stride):
     assert _rel(y, ref.permute(0, 2, 3, 1).reshape(-1, Cout)) < TOL[prec]
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (3, 64, 96), (8, 128, 64), (1, 128, 128)])
+@pytest.mark.parametrize("mode", ["relu", "residual", "offset_out"])
+def test_conv3x3_80_channels_weight_resident_kernel(dev, B, H, W, mode):
+    """DRN-L's 80 -> 80 channel 3x3 convolution at sizes that take the weight-resident persistent kernel (bf16,
+    kernels_conv80.hip; >= 8192 pixels, H % 4 == 0, W % 32 == 0): 128 - 512 tiles (one to two per workgroup), image borders,
+    bias + ReLU, bias + residual, and writing into a column range of a wider output buffer - against torch's conv2d on
+    bf16-rounded operands (fp32 accumulation on both sides: only the summation order differs)."""
+    from srad_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(B * H + W)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    x = bf(torch.randn(B, 80, H, W, generator=g)).to(dev)
+    w = bf(torch.randn(80, 80, 3, 3, generator=g) / math.sqrt(9 * 80)).to(dev)
+    b = torch.randn(80, generator=g).to(dev)
+    xn = x.permute(0, 2, 3, 1).reshape(-1, 80).clone(memory_format=torch.contiguous_format)
+    conv = F.conv2d(x, w, b, padding=1).permute(0, 2, 3, 1).reshape(-1, 80)
+    if mode == "relu":
+        y = ops.gemm(xn, w, b, B=B, H=H, W=W, act=3, precision="bf16")
+        ref = F.relu(conv)
+    elif mode == "residual":
+        r = torch.randn(B * H * W, 80, generator=g).to(dev)
+        y = ops.gemm(xn, w, b, B=B, H=H, W=W, residual=r, precision="bf16")
+        ref = conv + r
+    else:
+        out = torch.full((B * H * W, 96), float("nan"), device=dev)
+        ops.gemm(xn, w, b, B=B, H=H, W=W, out=out, out_offset=8, precision="bf16")
+        assert torch.isnan(out[:, :8]).all() and torch.isnan(out[:, 88:]).all()
+        y, ref = out[:, 8:88], conv
+    assert _rel(y, ref) < 1e-4
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_conv_pixel_shuffle(dev, prec):
     from srad_amd import ops
