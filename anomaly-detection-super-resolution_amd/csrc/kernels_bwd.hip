@@ -1307,7 +1307,8 @@ __global__ __launch_bounds__(256) void window_attn_bwd_h_kernel(const AttnBwdPar
   int win, h;                                            // all heads of a window on one XCD (see the kernel above)
   {
     const int L = blockIdx.x, nwin = p.B * nW;
-    if ((nwin & 7) == 0) { const int slot = L >> 3; win = (slot / heads) * 8 + (L & 7); h = slot - (slot / heads) * heads; }
+    if ((nwin & 7) == 0 && !p.no_xcd_map) { const int slot = L >> 3; win = (L & 7) * (nwin >> 3) + slot / heads; h = slot - (slot / heads) * heads; }   // XCD k: window strip k (affinity with the row-tile kernels)
+    else if ((nwin & 7) == 0) { const int slot = L >> 3; win = (slot / heads) * 8 + (L & 7); h = slot - (slot / heads) * heads; }
     else { win = L / heads; h = L - win * heads; }
   }
   const int b = win / nW, widx = win - b * nW;

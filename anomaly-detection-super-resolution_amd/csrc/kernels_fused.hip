@@ -71,7 +71,10 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const int m0 = blockIdx.x * FM;
+  // XCD affinity (see qkv_attn_kernel): XCD k takes the row tiles of strip k of the token range
+  int tile_i = blockIdx.x;
+  if ((gridDim.x & 7) == 0 && !p.no_xcd_map) tile_i = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int m0 = tile_i * FM;
   const int d = p.d, m = p.m, no = p.no;
   const int dbg = STAMP ? p.dbg : 0;                               // the switch-off experiments exist in the diagnostic build only
   // diagnostic build only (tools/stamp_bench.py): shader-clock stamps of every wave at the phase boundaries

@@ -70,7 +70,12 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
   stamp(0);
   // grid = (windows, heads): linear ids of one window's heads differ by a multiple of 8 when the window
   // count is, so they share an XCD and the window's x rows are fetched into one L2 only
-  const int h = blockIdx.y, win = blockIdx.x;
+  // XCD affinity with the kernels before and after (workgroup L runs on XCD L % 8, each XCD has its own L2): XCD k takes
+  // windows [k n/8, (k+1) n/8) - a contiguous strip of the images, the same strip whose token rows mlp_block gives XCD k -
+  // so the rows this workgroup gathers were mostly written into ITS L2 by the previous launch
+  const int h = blockIdx.y;
+  int win = blockIdx.x;
+  if ((gridDim.x & 7) == 0 && !p.no_xcd_map) win = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int ws = 8, nWx = p.W / ws, nW = (p.H / ws) * nWx;
   const int b = win / nW, widx = win - b * nW;
   const int wy = widx / nWx, wx = widx - wy * nWx;

@@ -178,7 +178,9 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const int m0 = blockIdx.x * FM;
+  int tile_i = blockIdx.x;                                      // XCD affinity with the neighbouring kernels (see qkv_attn_kernel)
+  if ((gridDim.x & 7) == 0 && !p.no_xcd_map) tile_i = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int m0 = tile_i * FM;
   const int d = p.d, m = p.m;
   constexpr int n_adj = KCA > 0 ? GD : 0, n_fc2 = GM * KGD, n_fc1 = GD * KGM, n_stages = n_adj + n_fc2 + n_fc1;
 
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
       rs1v[rt] = p.rs1 ? r : 1.f;
     }
   }
-  ln_bwd_tail<NRT, GD>(dxn, xv, r2, v_g, red, d, wave, fr, fq, p.dx1 + (size_t)m0 * d, d, part + (size_t)blockIdx.x * (2 * SRAD_LNB_CP),
+  ln_bwd_tail<NRT, GD>(dxn, xv, r2, v_g, red, d, wave, fr, fq, p.dx1 + (size_t)m0 * d, d, part + (size_t)tile_i * (2 * SRAD_LNB_CP),
                        p.w_projt ? A1 : nullptr, FB_LDA, (HOUT && p.w_projt && p.dx1s_h) ? p.dx1s_h + (size_t)m0 * d : nullptr, rs1v);
   if (p.w_projt) {
     __syncthreads();                                             // the dx1 tile is complete
@@ -475,7 +477,9 @@ __global__ __launch_bounds__(512) void lin_ln_bwd_kernel(const LinLnBwdParams p,
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const int m0 = blockIdx.x * FM;
+  int tile_i = blockIdx.x;                                      // XCD affinity with the neighbouring kernels (see qkv_attn_kernel)
+  if ((gridDim.x & 7) == 0 && !p.no_xcd_map) tile_i = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int m0 = tile_i * FM;
   const int d = p.d, K = p.K;
   constexpr int n_stages = GD * KG;
   const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(512) void lin_ln_bwd_kernel(const LinLnBwdParams p,
     }
   });
   ln_bwd_tail<NRT, GD>(dxn, xv, r2, v_g, red, d, wave, fr, fq, p.out + (size_t)m0 * p.ld_out, p.ld_out,
-                       part + (size_t)blockIdx.x * (2 * SRAD_LNB_CP));
+                       part + (size_t)tile_i * (2 * SRAD_LNB_CP));
 }
 
 template <int FM, int GD, int KC>

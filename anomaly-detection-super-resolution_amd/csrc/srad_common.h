@@ -202,6 +202,7 @@ struct MlpBlockParams {
   float* Y; int ldy, yoff;
   int dbg;                               // timing experiments only (tools/): 1 skip W loads, 2 skip MFMA, 4 skip GELU
   int fm;                                // token rows per workgroup: 0 = chosen from M, else 16 / 32 / 64
+  int no_xcd_map;                        // 1: plain workgroup -> row tile order (A/B of the XCD-affine mapping)
   unsigned long long* stamps;            // diagnostic build (16-row tiles): [workgroup][8 waves][16] s_memtime stamps, else null
   // ---- training (all optional): DropPath factors of the two residual branches and the tensors the backward needs ----
   const float *rs1, *rs2; int rps;       // per-sample factors (row m belongs to sample m / rps), null = 1
@@ -223,6 +224,7 @@ struct QkvAttnParams {
   const float* table;                      // [225][heads]
   float* out; int ld_out;                  // attention output [T][d] ...
   __bf16* out_h;                           // ... or, when set, as bf16 (same ld, in elements): the hand-off to mlp_block
+  int no_xcd_map;                          // 1: plain workgroup -> window order (A/B of the XCD-affine mapping)
   int B, H, W, shift, d, heads;
   // ---- training (optional): what the backward needs ----
   float* save_xn;                          // [T][d] LayerNorm1(x) (written by the head-0 workgroups)
@@ -350,6 +352,7 @@ struct MlpBwdParams {
   const float* rs1;                     // DropPath factor of the attention branch per sample (null = 1; rows per sample = rps)
   float* dO;                            // [M][d]
   __bf16* dx1s_h = nullptr;             // bf16-output instances: also dx1 times rs1 as bf16 [M][d] (proj's weight-gradient operand)
+  int no_xcd_map = 0;                   // 1: plain workgroup -> row tile order
   __bf16* dO_h = nullptr; int dO_heads = 0, dO_hp = 0;   // bf16-output instances: dO as [M][heads][hp] bf16 instead (column c -> head c / (d / heads))
 };
 bool srad_mlp_bwd_supported(int prec, int M, int d, int m, int KA);
@@ -366,6 +369,7 @@ struct LinLnBwdParams {
   const float* dres; int ld_dres;       // gradient arriving over the residual path
   float* out; int ld_out; int accumulate;
   float *dgamma, *dbeta;
+  int no_xcd_map = 0;   // 1: plain workgroup -> row tile order
 };
 bool srad_lin_ln_bwd_supported(int prec, int M, int K, int d);
 int srad_launch_lin_ln_bwd(const LinLnBwdParams& p, WgradQueue& q, hipStream_t stream);
@@ -384,6 +388,7 @@ struct AttnBwdParams {
   // all-bf16 form (window_attn_bwd_h_kernel; head dim <= 32): q (scaled) | k | v as the fused forward saved them,
   // [T][3][heads][hp_h], and dO as [T][heads][hp_h] (padding columns may hold anything); needs dqkv_h
   const __bf16* qkv_h = nullptr; const __bf16* dout_h = nullptr; int hp_h = 0;
+  int no_xcd_map = 0;        // 1: windows dealt round-robin over the XCDs (A/B of the strip mapping)
 };
 int srad_launch_window_attn_bwd(int prec, const AttnBwdParams& p, WgradQueue& q, hipStream_t stream);   // dtable via the queue
 
