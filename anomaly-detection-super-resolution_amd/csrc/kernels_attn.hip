@@ -78,12 +78,23 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
   const int fr = lane & 15, fq = lane >> 4;
   const int ws = p.ws, N = ws * ws, d = p.d, heads = p.heads, hd = d / heads, hdp = p.hdp;
   const int ldq = 3 * heads * hdp;
-  const int h = blockIdx.y;
   const int nWx = p.W / ws, nW = (p.H / ws) * nWx;
-  const int win = blockIdx.z;
+  int h = blockIdx.y, win = blockIdx.z, qchunk = blockIdx.x;
+  if constexpr (ROW64) {
+    // all query chunks of a (window, head) on ONE XCD (workgroup L runs on XCD L % 8): its 0.5 MB of K / V is then fetched into
+    // one L2 instead of all eight (a window's 32 workgroups were dealt over every XCD: 8x the L2 fills)
+    const int units = gridDim.y * gridDim.z, nq = gridDim.x;
+    if ((units & 7) == 0 && (nq & 7) == 0) {
+      const int L = blockIdx.x + nq * (blockIdx.y + gridDim.y * blockIdx.z);
+      const int s = L >> 3, u = (s / nq) * 8 + (L & 7);
+      qchunk = s - (s / nq) * nq;
+      win = u / (int)gridDim.y;
+      h = u - win * (int)gridDim.y;
+    }
+  }
   const int b = win / nW, widx = win - b * nW;
   const int wy = widx / nWx, wx = widx - wy * nWx;
-  const int q0 = blockIdx.x * BQ;
+  const int q0 = qchunk * BQ;
   constexpr float LOG2E = 1.4426950408889634f;
   const float scale = rsqrtf((float)hd) * (ROW64 ? LOG2E : 1.0f);
   const int tw = 2 * ws - 1;

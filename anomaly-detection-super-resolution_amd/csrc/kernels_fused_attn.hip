@@ -391,7 +391,9 @@ __global__ __launch_bounds__(512) void ln_qkv_kernel(const LnQkvParams p) {
   const int fr = lane & 15, fq = lane >> 4;
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const int d = p.d, hd = d / HEADS, hdp = p.hdp;
-  const int m0 = blockIdx.x * 64;
+  int tile_i = blockIdx.x;                                      // XCD affinity with mlp_block's row tiles (see qkv_attn_kernel)
+  if ((gridDim.x & 7) == 0) tile_i = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int m0 = tile_i * 64;
   const int xrow = tid >> 3, col4 = tid & 7;
 
   constexpr int NSETS = 3;
