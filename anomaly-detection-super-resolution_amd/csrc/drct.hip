@@ -101,7 +101,7 @@ int forward_body(srad_drct* h, const float* x, int B, int H, int W, float* y, co
         a.w_qkv = h->pt.frag_ptr(sw.qkv.w); a.b_qkv = h->pt.fptr(sw.qkv.b); a.table = h->pt.fptr(sw.table);
         a.out = w.attn; a.out_h = mlp_fused ? attn_h : nullptr; a.ld_out = d;
         a.B = B; a.H = H; a.W = W; a.shift = sw.shift; a.d = d; a.heads = sw.heads;
-        a.no_xcd_map = getenv("SRAD_NO_XCD_MAP") != nullptr;
+        a.no_xcd_map = srad_no_xcd_map();
         SRAD_TRY(srad_launch_qkv_attn(a, s));
       } else {
       // norm1 + qkv                                   (drct.py:477, 278)
@@ -144,7 +144,7 @@ int forward_body(srad_drct* h, const float* x, int B, int H, int W, float* y, co
         q.ln_g = h->pt.fptr(sw.n2g); q.ln_b = h->pt.fptr(sw.n2b); q.dbg = 0;
         if (k < 4) { q.act = SRAD_ACT_LRELU; q.slope = 0.2f; q.alpha = 1.f; q.R = nullptr; q.ldr = 0; q.Y = cur; q.ldy = D; q.yoff = d; }
         else { q.act = SRAD_ACT_NONE; q.slope = 0.f; q.alpha = 0.2f; q.R = cur; q.ldr = D; q.Y = nxt; q.ldy = D; q.yoff = 0; }
-        q.no_xcd_map = getenv("SRAD_NO_XCD_MAP") != nullptr;
+        q.no_xcd_map = srad_no_xcd_map();
         SRAD_TRY(srad_launch_mlp_block(q, s));
         continue;
       }

@@ -264,7 +264,7 @@ int srad_drct_forward_train(srad_drct_t* h, const float* x, int B, int H, int W,
         h->saved_h[bi] = (char)((bp.attn_h ? 1 : 0) | (bp.yh_dh ? 2 : 0));
         if (bp.attn_h) { a.save_qkv_h = reinterpret_cast<__bf16*>(sv.qkv); a.hp_h = attn_hp(sw); }   // as the MFMA took them
         else a.save_qkv = sv.qkv;
-        a.no_xcd_map = getenv("SRAD_NO_XCD_MAP") != nullptr;
+        a.no_xcd_map = srad_no_xcd_map();
         SRAD_TRY(srad_launch_qkv_attn(a, s));
         MlpBlockParams q{};
         q.attn_h = reinterpret_cast<const __bf16*>(sv.attn); q.ld_attn = d; q.shortcut = cur; q.ld_short = D;
@@ -280,7 +280,7 @@ int srad_drct_forward_train(srad_drct_t* h, const float* x, int B, int H, int W,
         q.save_xn2_h = reinterpret_cast<__bf16*>(sv.xn2); q.save_hact_h = reinterpret_cast<__bf16*>(sv.hact); q.save_x2_h = reinterpret_cast<__bf16*>(sv.x2);
         if (k < 4) { q.act = SRAD_ACT_LRELU; q.slope = 0.2f; q.alpha = 1.f; q.Y = cur; q.ldy = D; q.yoff = d; }
         else { q.act = SRAD_ACT_NONE; q.alpha = 0.2f; q.R = cur; q.ldr = D; q.Y = nxt; q.ldy = D; q.yoff = 0; }
-        q.no_xcd_map = getenv("SRAD_NO_XCD_MAP") != nullptr;
+        q.no_xcd_map = srad_no_xcd_map();
         SRAD_TRY(srad_launch_mlp_block(q, s));
         continue;
       }
@@ -547,7 +547,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
         if (fuse_proj) { mb.w_projt = h->ts.tarena + h->ts.tf_off[sw.proj.w]; mb.rs1 = ks1; mb.rps = HW; mb.dO = w.dO; }
         if (fuse_proj && attn_h) { mb.dO_h = reinterpret_cast<__bf16*>(w.dO); mb.dO_heads = sw.heads; mb.dO_hp = attn_hp(sw); }
         if (yh_dx1) mb.dx1s_h = dx1s_h;
-        mb.no_xcd_map = getenv("SRAD_NO_XCD_MAP") != nullptr;
+        mb.no_xcd_map = srad_no_xcd_map();
         SRAD_TRY(srad_launch_mlp_bwd(mb, wq, s));
       } else {
         {
@@ -586,7 +586,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
                         sw.shift, d, sw.heads, hdp};
         if (yh_qkv) a.dqkv_h = reinterpret_cast<__bf16*>(dqkv);
         if (attn_h) { a.qkv_h = reinterpret_cast<const __bf16*>(sv.qkv); a.dout_h = reinterpret_cast<const __bf16*>(w.dO); a.hp_h = attn_hp(sw); }
-        a.no_xcd_map = getenv("SRAD_NO_XCD_MAP") != nullptr;
+        a.no_xcd_map = srad_no_xcd_map();
         SRAD_TRY(srad_launch_window_attn_bwd(prec, a, wq, s));
       }
       {
@@ -601,7 +601,7 @@ int srad_drct_backward(srad_drct_t* h, const float* dy, int B, int H, int W, con
         lb.x = cur; lb.ldx = D; lb.ln_g = h->pt.fptr(sw.n1g); lb.dres = dx1; lb.ld_dres = d;
         lb.out = gc; lb.ld_out = D; lb.accumulate = 1;
         lb.dgamma = G + h->ts.flat_off[sw.n1g]; lb.dbeta = G + h->ts.flat_off[sw.n1b];
-        lb.no_xcd_map = getenv("SRAD_NO_XCD_MAP") != nullptr;
+        lb.no_xcd_map = srad_no_xcd_map();
         SRAD_TRY(srad_launch_lin_ln_bwd(lb, wq, s));
       } else {
         {

@@ -2,6 +2,7 @@
 // shift folded in, bicubic upsampling, channel-attention gate.  All are one pass over their
 // data with coalesced accesses; they are a few percent of the forward's time.
 #include "srad_common.h"
+#include <stdlib.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <vector>
@@ -35,6 +36,11 @@ const char* const kClassNames[SRAD_K_COUNT] = {"gemm_bn64", "gemm_bn32", "gemm_b
                                                "layout", "pack_weight", "score", "misc", "mlp_block", "qkv_attn",
                                                "wgrad", "window_attn_bwd", "layernorm_bwd", "optim", "wgrad_reduce", "mlp_bwd", "ln_qkv"};
 }  // namespace
+
+bool srad_no_xcd_map() {
+  static const bool off = getenv("SRAD_NO_XCD_MAP") != nullptr;
+  return off;
+}
 
 SradProfScope::SradProfScope(hipStream_t stream, int cls, double flops, double bytes) : s(stream), active(0) {
   if (!g_prof.enabled) return;

@@ -233,6 +233,7 @@ struct QkvAttnParams {
   __bf16* save_qkv_h; int hp_h;            // or [T][3][heads][hp_h] bf16 exactly as the attention used them (q scaled, padding 0), hp_h % 8 == 0
   unsigned long long* stamps;              // diagnostic build: [workgroup][8 waves][16] s_memtime stamps, else null
 };
+bool srad_no_xcd_map();     // SRAD_NO_XCD_MAP=1 (read once): plain workgroup order in the Swin-block kernels, for A/B runs
 bool srad_qkv_attn_supported(int prec, int ws, int H, int W, int d, int heads);
 // LayerNorm1 + qkv Linear -> bf16 head-split q | k | v for the 64 x 64-window attention (kernels_fused_attn.hip ln_qkv_kernel)
 struct LnQkvParams {
