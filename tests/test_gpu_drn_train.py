@@ -131,13 +131,16 @@ def test_cli_train_drn_writes_run_dir_with_dual_models(tmp_path):
     assert "scale: [2, 4]" in open(os.path.join(run, "config.txt")).read()
 
 
-def test_drn_bf16_gradients_close_to_fp32_mode():
+@pytest.mark.parametrize("lr_px", [16, 64])
+def test_drn_bf16_gradients_close_to_fp32_mode(lr_px):
     """bf16 mode of the DRN-L training step (incl. the 80 x 80-tile weight-gradient kernel of the 80-channel RCAB convolutions,
     which only exists in bf16) against the fp32 mode on the same weights and batch: cosine of the flat gradient and the
-    per-tensor relative L2 error of the RCAB convolution weights."""
+    per-tensor relative L2 error of the RCAB convolution weights.  At 64 px LR the 80-channel convolutions - forward, and the
+    data gradients with their ReLU' / skip-path epilogues - take the weight-resident kernel (kernels_conv80.hip), which the
+    fp32 mode never does."""
     from srad_amd.nets import DRN
     from srad_amd.train import drn_loss
-    cfg, sd, duals, lrs, hr, m32, dms = _setup(4, 3, 2, 20, 2, 16, 16)
+    cfg, sd, duals, lrs, hr, m32, dms = _setup(4, 3, 2, 20, 2, lr_px, lr_px)
     m16 = DRN(Opt(cfg, "bf16")).cuda()
     m16.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     m16.train()
