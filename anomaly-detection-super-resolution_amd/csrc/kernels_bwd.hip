@@ -11,6 +11,9 @@
 // transposed packed weight (srad_launch_pack_weight_transposed).
 #include "srad_common.h"
 #include <type_traits>
+#include <algorithm>
+#include <math.h>
+#include <stdint.h>
 #include <stdlib.h>
 
 namespace {
@@ -477,6 +480,149 @@ __global__ __launch_bounds__(256) void wgrad80_kernel(const WgradParams p, const
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight gradient of a 3x3, stride-1, C -> C channel convolution (C <= 80: DRN-L's 160 RCAB convolutions,
+// src/drn.py:143-158) with ALL NINE taps in one workgroup.  The per-tap kernels above read dY and X nine times (9 x 21 MB per
+// layer at 64 px, batch 8) in workgroups of four waves that live for four row steps: 38 us at 64 px, ~130 us at 128 px.
+// Here a workgroup stages R image rows of dY and the R + 2 halo rows of X ONCE, as bf16, in LDS ([pixel][channel], the
+// memory order) and wave t owns tap t's C x C accumulator: both MFMA operands are k-contiguous along the PIXEL axis, i.e.
+// transposed with respect to the tiles, so they come out of LDS with ds_read_tr16_b64, and a tap is a constant row offset
+// into the halo tile.  A workgroup walks `cpw` consecutive row chunks, so the partial tiles (9 C^2 floats per workgroup,
+// the cost of split-K here) are amortised over R x W x cpw pixels.  Bias sums: fp32, by the staging threads.
+// ------------------------------------------------------------------------------------------
+constexpr int WC9_THREADS = 576;
+template <int NT> struct Wc9 { static constexpr int HS = NT == 4 ? 72 : 16 * NT; };   // LDS row stride (bf16): conflict-free tr reads
+
+template <int NT>
+__global__ __launch_bounds__(WC9_THREADS) void wgrad_conv9_kernel(const WgradParams p, const int R, const int cpw, const int nchunks,
+                                                                  const int ksplit, float* __restrict__ part) {
+  constexpr int HS = Wc9<NT>::HS;
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  extern __shared__ __attribute__((aligned(16))) float wsm[];
+  const int C = p.N, c4n = C >> 2, W = p.Wo, H = p.Ho, W2 = W + 2;
+  const int PT = R * W, HT = (R + 2) * W2;
+  __bf16* const dYs = reinterpret_cast<__bf16*>(wsm);
+  __bf16* const Xs = dYs + (size_t)PT * HS;
+  const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4, tq = fr >> 2, tp = fr & 3;
+  const int ky = tap / 3, kx = tap - ky * 3;
+  const int ks = blockIdx.x;
+  const int cpi = (H + R - 1) / R;                             // chunks per image
+
+  // staging roles: thread (srow, sch) converts float4 sch of rows srow, srow + rpp, ...
+  const int rpp = WC9_THREADS / c4n;
+  const bool active = tid < rpp * c4n;
+  const int srow = active ? tid / c4n : 0, sch = active ? tid - srow * c4n : 0;
+  const float* const dYc = p.dY + p.ycol0 + 4 * sch;
+  const float* const Xc = p.X + 4 * sch;
+
+  f32x4 acc[NT][NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto to_h4 = [](const f32x4 v) __attribute__((always_inline)) -> bf16x4 {
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+    return o;
+  };
+  constexpr int UN = 4;
+  const int c_end = min(nchunks, (ks + 1) * cpw);
+  for (int chunk = ks * cpw; chunk < c_end; ++chunk) {
+    const int b = chunk / cpi, y0 = (chunk - b * cpi) * R;
+    const int pv = min(R, H - y0) * W;                          // real pixels of the chunk (rows past the image: zero)
+    const size_t m0 = ((size_t)b * H + y0) * W;
+    __syncthreads();                                            // the previous chunk's MFMAs have read the tiles
+    for (int base = srow; base < PT; base += UN * rpp) {
+      f32x4 v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int pl = base + u * rpp;
+        v[u] = *reinterpret_cast<const f32x4*>(dYc + (m0 + (size_t)min(pl, pv - 1)) * p.ldy);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int pl = base + u * rpp;
+        if (!(active && pl < pv)) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bsum += v[u];
+        if (active && pl < PT) *reinterpret_cast<bf16x4*>(dYs + (size_t)pl * HS + 4 * sch) = to_h4(v[u]);
+      }
+    }
+    for (int base = srow; base < HT; base += UN * rpp) {
+      f32x4 v[UN];
+      bool ok[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int hl = min(base + u * rpp, HT - 1);
+        const int hy = hl / W2, hx = hl - hy * W2;
+        const int iy = y0 - 1 + hy, ix = hx - 1;
+        ok[u] = active && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const size_t xr = ((size_t)b * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1);
+        v[u] = *reinterpret_cast<const f32x4*>(Xc + xr * p.ldx);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int hl = base + u * rpp;
+        if (!ok[u]) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (active && hl < HT) *reinterpret_cast<bf16x4*>(Xs + (size_t)hl * HS + 4 * sch) = to_h4(v[u]);
+      }
+    }
+    __syncthreads();
+    // ---- 32 pixels per step: lane (fq, fr) takes pixels 8 fq + 0..7 of the step, W % 32 == 0 keeps them in one image row ----
+    const __bf16* arow = dYs + (size_t)(8 * fq + tq) * HS + 4 * tp;
+    const __bf16* brow = Xs + (size_t)(ky * W2 + kx + 8 * fq + tq) * HS + 4 * tp;
+    int x0 = 0;
+    for (int kk = 0; kk < PT; kk += 32) {
+      bf16x8 ah[NT], bh[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(arow + 16 * t));
+        const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(arow + 16 * t + 4 * HS));
+        const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(brow + 16 * t));
+        const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(brow + 16 * t + 4 * HS));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ah[t][e] = alo[e]; ah[t][4 + e] = ahi[e]; bh[t][e] = blo[e]; bh[t][4 + e] = bhi[e]; }
+      }
+#pragma unroll
+      for (int en = 0; en < NT; ++en)
+#pragma unroll
+        for (int ec = 0; ec < NT; ++ec)
+          acc[en][ec] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[en], bh[ec], acc[en][ec], 0, 0, 0);
+      arow += 32 * HS;
+      x0 += 32;
+      brow += 32 * HS;
+      if (x0 == W) { x0 = 0; brow += 2 * HS; }                  // next image row of the halo tile: skip its two border pixels
+    }
+  }
+  // ---- partial tile of this tap: lane (fq, fr) element e of acc[en][ec] is (n = 16 en + 4 fq + e, c = 16 ec + fr) ----
+  const int PART = C * C + C;
+  float* const mypart = part + ((size_t)tap * ksplit + ks) * PART;
+#pragma unroll
+  for (int en = 0; en < NT; ++en)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = 16 * en + 4 * fq + e;
+#pragma unroll
+      for (int ec = 0; ec < NT; ++ec) {
+        const int c = 16 * ec + fr;
+        if (n < C && c < C) mypart[n * C + c] = acc[en][ec][e];
+      }
+    }
+  // ---- bias sums: the staging threads' float4, summed over the rpp row phases in fixed order ----
+  __syncthreads();
+  f32x4* const bs = reinterpret_cast<f32x4*>(wsm);
+  if (active) bs[srow * c4n + sch] = bsum;
+  __syncthreads();
+  if (tid < c4n) {
+    f32x4 t = bs[tid];
+    for (int r = 1; r < rpp; ++r) t += bs[r * c4n + tid];
+    *reinterpret_cast<f32x4*>(part + (size_t)ks * PART + C * C + 4 * tid) = t;
+  }
+}
+
 template <int PREC, bool CONV>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p, const int ksplit, const int tn, const int tc,
                                                     float* __restrict__ part) {
@@ -544,31 +690,44 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceBatc
     }
     return;
   }
-  if (d.w80) {
-    // one 80 x 80 tile per tap (wgrad80_kernel): a quarter = 400 float4 of the row-major tile and 20 bias sums
-    const int tap = tile_id;
-    const float* const tb = d.part + (size_t)tap * d.ksplit * W80_PART;
-    for (int j = threadIdx.x; j < 400; j += 256) {
-      const int idx = quarter * 400 + j;
-      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      int k = 0;
-      for (; k + 8 <= d.ksplit; k += 8) {
-        f32x4 t[8];
+  if (d.wc) {
+    // one wc x wc tile per tap (wgrad80_kernel, wgrad_conv9_kernel): row-major + wc bias sums per partial.  d.tn reduce
+    // "tiles" (x 4 workgroups) per tap, d.tc float4 of the tile per workgroup (32 x 50 for 80 channels); the split-K partials
+    // are dealt over four thread groups and combined in fixed order.  Lanes d.tc and d.tc + 1 of the tap-0 workgroups take a
+    // float4 of the bias sums each.  (Four workgroups per tap - 36 for a whole 3x3 layer - with one thread group and 80 threads
+    // walking the bias sums took 36 us for 15 MB: 3.2 ms of a DRN-L training step's side stream.)
+    __shared__ f32x4 ph[4][64];
+    const int C = d.wc, cc4 = C * C / 4, c4n = C / 4, per = d.tc;
+    const int PART = C * C + C;
+    const int tap = tile_id / d.tn, sub = (tile_id - tap * d.tn) * 4 + quarter;
+    const float* const tb = d.part + (size_t)tap * d.ksplit * PART;
+    const int il = threadIdx.x & 63, phase = threadIdx.x >> 6;
+    const int bidx = sub * 2 + (il - per);                       // bias float4 of lanes per, per + 1
+    const bool is_w = il < per && sub * per + il < cc4;
+    const bool is_b = il >= per && il < per + 2 && tap == 0 && bidx < c4n && d.db != nullptr;
+    const int idx = is_w ? sub * per + il : (is_b ? cc4 + bidx : 0);
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    int k = phase;
+    for (; k + 28 < d.ksplit; k += 32) {                        // 8 loads in flight
+      f32x4 t[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4*>(tb + (size_t)(k + u) * W80_PART + 4 * idx);
+      for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4*>(tb + (size_t)(k + 4 * u) * PART + 4 * idx);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v += t[u];
-      }
-      for (; k < d.ksplit; ++k) v += *reinterpret_cast<const f32x4*>(tb + (size_t)k * W80_PART + 4 * idx);
-      const int n = idx / 20, c4 = (idx - n * 20) * 4;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) d.dW[((size_t)n * 80 + c4 + e) * d.ntaps + tap] += v[e] * d.alpha;
+      for (int u = 0; u < 8; ++u) v += t[u];
     }
-    if (d.db != nullptr && tap == 0 && threadIdx.x < 20) {
-      const int n = quarter * 20 + threadIdx.x;
-      float vb = 0.f;
-      for (int kk = 0; kk < d.ksplit; ++kk) vb += tb[(size_t)kk * W80_PART + 6400 + n];
-      d.db[n] += vb * d.alpha;
+    for (; k < d.ksplit; k += 4) v += *reinterpret_cast<const f32x4*>(tb + (size_t)k * PART + 4 * idx);
+    ph[phase][il] = v;
+    __syncthreads();
+    if (threadIdx.x < 64 && (is_w || is_b)) {
+      const f32x4 t = (ph[0][il] + ph[1][il]) + (ph[2][il] + ph[3][il]);
+      if (is_w) {
+        const int n = idx / c4n, c0 = (idx - n * c4n) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d.dW[((size_t)n * C + c0 + e) * d.ntaps + tap] += t[e] * d.alpha;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d.db[4 * bidx + e] += t[e] * d.alpha;
+      }
     }
     return;
   }
@@ -638,7 +797,7 @@ int plan_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s, WgradPlan& pl
     q.used += need;
     WgradReduceItem& it = q.batch.it[q.batch.count++];
     it.dW = p.dW; it.db = p.db; it.part = pl.part; it.n_real = p.n_real; it.cin_real = p.cin_real; it.ntaps = p.ntaps;
-    it.tn = pl.tn; it.tc = pl.tc; it.ksplit = (int)ksplit; it.tile0 = q.tiles; it.alpha = p.alpha; it.w80 = 0;
+    it.tn = pl.tn; it.tc = pl.tc; it.ksplit = (int)ksplit; it.tile0 = q.tiles; it.alpha = p.alpha; it.wc = 0;
     q.tiles += (int)pl.tiles;
   }
   return SRAD_OK;
@@ -646,6 +805,15 @@ int plan_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s, WgradPlan& pl
 
 constexpr size_t WG_LDS = (size_t)(4 * 64 * 68 + 4 * 64) * sizeof(float);
 constexpr size_t WG_LDS2 = (size_t)(2 * 64 * 68 + 4 * 64) * sizeof(float);   // wgrad_body<.., LDS2 = true>
+
+// reduce geometry of a layer whose partials are one C x C tile per tap (see wgrad_reduce_kernel): reduce tiles to add to the queue
+static int square_reduce_tiles(WgradReduceItem& it, const int C) {
+  const int cc4 = C * C / 4;
+  it.wc = C;
+  it.tn = (cc4 + 199) / 200;                      // x 4 workgroups per tap, <= 50 float4 each
+  it.tc = (cc4 + 4 * it.tn - 1) / (4 * it.tn);
+  return it.ntaps * it.tn;
+}
 
 // 80 -> 80 channels, stride 1, bf16: one 80 x 80 tile per tap
 int launch_wgrad80(const WgradParams& p, WgradQueue& q, hipStream_t s) {
@@ -671,8 +839,8 @@ int launch_wgrad80(const WgradParams& p, WgradQueue& q, hipStream_t s) {
     q.used += need;
     WgradReduceItem& it = q.batch.it[q.batch.count++];
     it.dW = p.dW; it.db = p.db; it.part = part; it.n_real = 80; it.cin_real = 80; it.ntaps = p.ntaps;
-    it.tn = it.tc = 1; it.ksplit = (int)ksplit; it.tile0 = q.tiles; it.alpha = p.alpha; it.w80 = 1;
-    q.tiles += p.ntaps;
+    it.ksplit = (int)ksplit; it.tile0 = q.tiles; it.alpha = p.alpha;
+    q.tiles += square_reduce_tiles(it, 80);
   }
   SradProfScope prof(s, SRAD_K_WGRAD, 2.0 * p.M * 80.0 * 80.0 * p.ntaps, 4.0 * p.M * 160.0 + 8.0 * 6400.0 * p.ntaps);
   auto launch = [&](auto kern) -> int {
@@ -690,8 +858,79 @@ int launch_wgrad80(const WgradParams& p, WgradQueue& q, hipStream_t s) {
   return SRAD_OK;
 }
 
+// 3x3 stride-1 C -> C convolution, all nine taps per workgroup (wgrad_conv9_kernel); false: not this layer's kernel
+static bool conv9_geometry(const WgradParams& p, int& R, size_t& lds) {
+  if (p.ntaps != 9 || p.stride != 1 || p.N != p.Cin || p.n_real != p.N || p.cin_real != p.Cin || p.N > 80 || (p.N & 3) || p.row_scale ||
+      p.x_bf16 || p.dy_bf16 || p.Hi != p.Ho || p.Wi != p.Wo || (p.Wo & 31) || (p.ldy & 3) || (p.ldx & 3) || (p.ycol0 & 3) ||
+      (size_t)p.M < 8192 || getenv("SRAD_NO_WGRAD_CONV9") != nullptr)
+    return false;
+  if ((reinterpret_cast<uintptr_t>(p.dY) | reinterpret_cast<uintptr_t>(p.X)) & 15) return false;
+  const int nt = (p.N + 15) / 16, hs = nt == 4 ? 72 : 16 * nt;
+  auto bytes = [&](int r) { return ((size_t)r * p.Wo + (size_t)(r + 2) * (p.Wo + 2)) * hs * sizeof(__bf16); };
+  R = 0;
+  for (int pass = 0; pass < 2 && !R; ++pass)                 // rows per chunk: as many as fit, whole chunks per image if possible
+    for (int r = 8; r >= 1; --r)
+      if (r * p.Wo <= 512 && bytes(r) <= (size_t)144 * 1024 && (pass == 1 || p.Ho % r == 0)) { R = r; break; }
+  if (!R) return false;
+  lds = bytes(R);
+  if (lds < (size_t)WC9_THREADS * sizeof(f32x4)) lds = (size_t)WC9_THREADS * sizeof(f32x4);   // the bias-sum exchange
+  return true;
+}
+
+int launch_wgrad_conv9(const WgradParams& p, WgradQueue& q, hipStream_t s, const int R, const size_t lds) {
+  const int C = p.N, nt = (C + 15) / 16;
+  const int B = p.M / (p.Ho * p.Wo);
+  const int nchunks = B * ((p.Ho + R - 1) / R);
+  // workgroups: a chunk costs ~5 us of MFMA time, a workgroup's partial tiles 9 C^2 floats written and read again:
+  // ~6.5 sqrt(chunks) workgroups balance the two (64 for 128 chunks, 128 for 512)
+  int ksplit = (int)(6.5 * sqrt((double)nchunks) + 0.5);
+  if (const char* e = getenv("SRAD_WGRAD_KSPLIT")) ksplit = atoi(e) > 0 ? atoi(e) : ksplit;   // tools/: timing experiments
+  ksplit = std::max(1, std::min(std::min(ksplit, 256), nchunks));
+  const int cpw = (nchunks + ksplit - 1) / ksplit;
+  ksplit = (nchunks + cpw - 1) / cpw;
+  const size_t PART = (size_t)C * C + C;
+  const size_t need = 9 * (size_t)ksplit * PART;
+  SRAD_REQUIRE(q.ws && need <= q.ws_floats, "wgrad: split-K workspace too small (%zu floats needed, %zu given)", need, q.ws_floats);
+  if (q.batch.count == SRAD_WGRAD_BATCH || q.used + need > q.ws_floats) {
+    SRAD_REQUIRE(q.multi.count == 0, "wgrad: split-K workspace too small for the deferred layers");
+    SRAD_TRY(srad_wgrad_flush(q, s));
+  }
+  float* const part = q.ws + q.used;
+  q.used += need;
+  WgradReduceItem& it = q.batch.it[q.batch.count++];
+  it.dW = p.dW; it.db = p.db; it.part = part; it.n_real = C; it.cin_real = C; it.ntaps = 9;
+  it.ksplit = ksplit; it.tile0 = q.tiles; it.alpha = p.alpha;
+  q.tiles += square_reduce_tiles(it, C);
+  SradProfScope prof(s, SRAD_K_WGRAD, 2.0 * p.M * C * C * 9.0, 4.0 * p.M * 2.0 * C + 8.0 * 9.0 * PART * ksplit);
+  auto launch = [&](auto kern, bool& configured) -> int {
+    if (!configured) {
+      SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)ksplit), dim3(WC9_THREADS), lds, s, p, R, cpw, nchunks, ksplit, part);
+    return SRAD_OK;
+  };
+  static bool cfg[6] = {false, false, false, false, false, false};
+  int rc = SRAD_OK;
+  switch (nt) {
+    case 1: rc = launch(wgrad_conv9_kernel<1>, cfg[1]); break;
+    case 2: rc = launch(wgrad_conv9_kernel<2>, cfg[2]); break;
+    case 3: rc = launch(wgrad_conv9_kernel<3>, cfg[3]); break;
+    case 4: rc = launch(wgrad_conv9_kernel<4>, cfg[4]); break;
+    default: rc = launch(wgrad_conv9_kernel<5>, cfg[5]); break;
+  }
+  if (rc) return rc;
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}
+
 template <int PREC>
 int launch_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s) {
+  if (PREC == SRAD_PREC_BF16) {
+    int R = 0;
+    size_t lds = 0;
+    if (conv9_geometry(p, R, lds)) return launch_wgrad_conv9(p, q, s, R, lds);
+  }
   if (PREC == SRAD_PREC_BF16 && p.N == 80 && p.Cin == 80 && p.n_real == 80 && p.cin_real == 80 && p.stride == 1 && !p.row_scale &&
       (p.ntaps == 1 || (p.Hi == p.Ho && p.Wi == p.Wo)) && getenv("SRAD_NO_WGRAD80") == nullptr)
     return launch_wgrad80(p, q, s);
@@ -1663,7 +1902,7 @@ static int queue_colsum(WgradQueue& q, float* dst, const float* part, int ncols,
   if (q.batch.count == SRAD_WGRAD_BATCH) SRAD_TRY(srad_wgrad_flush(q, stream));
   WgradReduceItem& it = q.batch.it[q.batch.count++];
   it.dW = dst; it.db = nullptr; it.part = part; it.n_real = ncols; it.cin_real = row_stride; it.ntaps = 0;   // ntaps 0: column sums
-  it.tn = it.tc = 1; it.ksplit = rows; it.tile0 = q.tiles; it.alpha = alpha; it.w80 = 0;
+  it.tn = it.tc = 1; it.ksplit = rows; it.tile0 = q.tiles; it.alpha = alpha; it.wc = 0;
   q.tiles += (ncols + 63) / 64;
   return SRAD_OK;
 }

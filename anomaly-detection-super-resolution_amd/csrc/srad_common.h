@@ -275,7 +275,8 @@ struct WgradReduceItem {
   float* dW; float* db; const float* part;
   int n_real, cin_real, ntaps, tn, tc, ksplit, tile0;
   float alpha;
-  int w80;                       // 1: one 80 x 80 partial tile per tap (wgrad80_kernel), row-major + 80 bias sums
+  int wc;                        // C > 0: one C x C partial tile per tap (wgrad80_kernel, wgrad_conv9_kernel), row-major + C bias sums;
+                                 // then tn = reduce tiles per tap, tc = float4 per reduce workgroup
 };
 struct WgradReduceBatch { WgradReduceItem it[SRAD_WGRAD_BATCH]; int count; };
 #define SRAD_WGRAD_MULTI 5

@@ -83,7 +83,10 @@ def test_wgrad_linear_deferred(dev, storage, M, N, K):
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(2, 32, 32, 180, 64, 1), (1, 17, 23, 4, 180, 1), (2, 16, 12, 64, 4, 1),
                                                    (1, 32, 32, 20, 20, 2), (1, 15, 11, 40, 80, 2),
-                                                   (2, 64, 64, 80, 80, 1), (1, 17, 23, 80, 80, 1)])      # 80 -> 80: the 80-wide tile kernel (bf16)
+                                                   (2, 64, 64, 80, 80, 1), (1, 17, 23, 80, 80, 1),       # 80 -> 80: the 80-wide tile kernel (bf16)
+                                                   # C -> C, W % 32 == 0, >= 8192 pixels: the nine-taps-per-workgroup kernel (bf16)
+                                                   (3, 64, 64, 80, 80, 1), (2, 64, 64, 40, 40, 1), (1, 96, 96, 20, 20, 1),
+                                                   (1, 70, 128, 64, 64, 1), (1, 67, 128, 80, 80, 1), (2, 64, 64, 12, 12, 1)])
 def test_wgrad_conv3x3(dev, prec, B, H, W, Cin, Cout, stride):
     from srad_amd import ops
     g = torch.Generator().manual_seed(B * H + Cin)
