@@ -484,135 +484,180 @@ __global__ __launch_bounds__(256) void wgrad80_kernel(const WgradParams p, const
 // Weight gradient of a 3x3, stride-1, C -> C channel convolution (C <= 80: DRN-L's 160 RCAB convolutions,
 // src/drn.py:143-158) with ALL NINE taps in one workgroup.  The per-tap kernels above read dY and X nine times (9 x 21 MB per
 // layer at 64 px, batch 8) in workgroups of four waves that live for four row steps: 38 us at 64 px, ~130 us at 128 px.
-// Here a workgroup stages R image rows of dY and the R + 2 halo rows of X ONCE, as bf16, in LDS ([pixel][channel], the
-// memory order) and wave t owns tap t's C x C accumulator: both MFMA operands are k-contiguous along the PIXEL axis, i.e.
-// transposed with respect to the tiles, so they come out of LDS with ds_read_tr16_b64, and a tap is a constant row offset
-// into the halo tile.  A workgroup walks `cpw` consecutive row chunks, so the partial tiles (9 C^2 floats per workgroup,
-// the cost of split-K here) are amortised over R x W x cpw pixels.  Bias sums: fp32, by the staging threads.
+// Here a workgroup stages a 4 x 32 pixel tile of dY and its 6 x 34 halo tile of X ONCE, as bf16, in LDS ([pixel][channel],
+// the memory order).  Both MFMA operands are k-contiguous along the PIXEL axis, i.e. transposed with respect to the tiles,
+// so they come out of LDS with ds_read_tr16_b64, and a tap is a constant row offset into the halo tile.  Wave t of eight
+// owns tap t's C x C accumulator; the ninth tap's (C/16)^2 MFMA tiles are dealt over the eight waves (tile w, w + 8, ..).
+// Eight waves = two per SIMD = 256 registers each: the NEXT tile's rows are requested before this tile's MFMAs and wait in
+// registers (the first version staged and computed in turns with nine waves and 168 registers: 7 us of load round trips and
+// 4.6 us of MFMAs per 256 pixels); they are converted into the other LDS buffer afterwards, one barrier per tile.
+// A workgroup walks `cpw` consecutive tiles, so the partial tiles (9 C^2 floats per workgroup, the cost of split-K here)
+// are amortised.  Bias sums: fp32, by the staging threads.
 // ------------------------------------------------------------------------------------------
-constexpr int WC9_THREADS = 576;
-template <int NT> struct Wc9 { static constexpr int HS = NT == 4 ? 72 : 16 * NT; };   // LDS row stride (bf16): conflict-free tr reads
+constexpr int WC9_THREADS = 512, WC9_TW = 32, WC9_TR = 4, WC9_PT = WC9_TW * WC9_TR, WC9_HW = WC9_TW + 2, WC9_HT = (WC9_TR + 2) * WC9_HW;
+template <int NT> struct Wc9 {
+  static constexpr int HS = NT == 4 ? 72 : 16 * NT;            // LDS row stride (bf16): conflict-free transposing reads
+  static constexpr size_t LDS = (size_t)2 * (WC9_PT + WC9_HT) * HS * sizeof(__bf16) > (size_t)WC9_THREADS * 16
+                                    ? (size_t)2 * (WC9_PT + WC9_HT) * HS * sizeof(__bf16) : (size_t)WC9_THREADS * 16;
+};
 
 template <int NT>
-__global__ __launch_bounds__(WC9_THREADS) void wgrad_conv9_kernel(const WgradParams p, const int R, const int cpw, const int nchunks,
+__global__ __launch_bounds__(WC9_THREADS) void wgrad_conv9_kernel(const WgradParams p, const int cpw, const int nchunks,
                                                                   const int ksplit, float* __restrict__ part) {
-  constexpr int HS = Wc9<NT>::HS;
+  constexpr int HS = Wc9<NT>::HS, PT = WC9_PT, HT = WC9_HT, HW = WC9_HW;
+  constexpr int RPP_MIN = WC9_THREADS / (4 * NT);              // staged rows per pass, at least (C <= 16 NT)
+  constexpr int NY = (PT + RPP_MIN - 1) / RPP_MIN, NX = (HT + RPP_MIN - 1) / RPP_MIN;
+  constexpr int EX = (NT * NT + 7) / 8;                        // MFMA tiles of the ninth tap per wave
   typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
   extern __shared__ __attribute__((aligned(16))) float wsm[];
-  const int C = p.N, c4n = C >> 2, W = p.Wo, H = p.Ho, W2 = W + 2;
-  const int PT = R * W, HT = (R + 2) * W2;
-  __bf16* const dYs = reinterpret_cast<__bf16*>(wsm);
-  __bf16* const Xs = dYs + (size_t)PT * HS;
-  const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6;
+  const int C = p.N, c4n = C >> 2, W = p.Wo, H = p.Ho;
+  __bf16* const lds0 = reinterpret_cast<__bf16*>(wsm);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4, tq = fr >> 2, tp = fr & 3;
-  const int ky = tap / 3, kx = tap - ky * 3;
+  const int ky = wave / 3, kx = wave - ky * 3;
   const int ks = blockIdx.x;
-  const int cpi = (H + R - 1) / R;                             // chunks per image
+  const int tiles_x = W / WC9_TW;
+  const int cpi = ((H + WC9_TR - 1) / WC9_TR) * tiles_x;       // tiles per image
 
-  // staging roles: thread (srow, sch) converts float4 sch of rows srow, srow + rpp, ...
+  // staging roles: thread (srow, sch) converts float4 sch of tile rows srow, srow + rpp, ...
   const int rpp = WC9_THREADS / c4n;
   const bool active = tid < rpp * c4n;
   const int srow = active ? tid / c4n : 0, sch = active ? tid - srow * c4n : 0;
-  const float* const dYc = p.dY + p.ycol0 + 4 * sch;
-  const float* const Xc = p.X + 4 * sch;
+  const float* const dYb = p.dY + p.ycol0;
+  const float* const Xb = p.X;
 
-  f32x4 acc[NT][NT];
+  f32x4 acc[NT][NT], accx[EX];
 #pragma unroll
   for (int i = 0; i < NT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < EX; ++i) accx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
+  int xen[EX], xec[EX];                                        // this wave's tiles of tap 8 (clamped: the surplus ones are not stored)
+#pragma unroll
+  for (int i = 0; i < EX; ++i) {
+    const int t = min(wave + 8 * i, NT * NT - 1);
+    xen[i] = t / NT;
+    xec[i] = t - xen[i] * NT;
+  }
 
+  f32x4 vy[NY], vx[NX];
+  unsigned okm = 0u;                                           // bit i: vy[i] is a real pixel; bit 16 + i: vx[i] is inside the image
+  auto issue = [&](const int chunk) __attribute__((always_inline)) {
+    const int b = chunk / cpi, r = chunk - b * cpi;
+    const int ty = r / tiles_x, tx = r - ty * tiles_x;
+    const int y0 = ty * WC9_TR, x0 = tx * WC9_TW;
+    const unsigned img = (unsigned)b * H;
+    okm = 0u;
+    int sr = srow;
+    asm volatile("" : "+v"(sr));                                // keeps the per-row geometry out of registers between tiles (it was hoisted: 25 spilled)
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      const int row = min(sr + i * rpp, PT - 1);
+      const int y = y0 + (row >> 5), x = x0 + (row & 31);
+      if (active && sr + i * rpp < PT && y < H) okm |= 1u << i;
+      const unsigned off = ((img + min(y, H - 1)) * W + x) * p.ldy + 4 * sch;
+      vy[i] = *reinterpret_cast<const f32x4*>(dYb + off);
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int hl = min(sr + i * rpp, HT - 1);
+      const int hy = hl / HW, hx = hl - hy * HW;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      if (active && sr + i * rpp < HT && iy >= 0 && iy < H && ix >= 0 && ix < W) okm |= 1u << (16 + i);
+      const unsigned off = ((img + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)) * p.ldx + 4 * sch;
+      vx[i] = *reinterpret_cast<const f32x4*>(Xb + off);
+    }
+  };
   auto to_h4 = [](const f32x4 v) __attribute__((always_inline)) -> bf16x4 {
     bf16x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
     return o;
   };
-  constexpr int UN = 4;
-  const int c_end = min(nchunks, (ks + 1) * cpw);
-  for (int chunk = ks * cpw; chunk < c_end; ++chunk) {
-    const int b = chunk / cpi, y0 = (chunk - b * cpi) * R;
-    const int pv = min(R, H - y0) * W;                          // real pixels of the chunk (rows past the image: zero)
-    const size_t m0 = ((size_t)b * H + y0) * W;
-    __syncthreads();                                            // the previous chunk's MFMAs have read the tiles
-    for (int base = srow; base < PT; base += UN * rpp) {
-      f32x4 v[UN];
+  auto store = [&](__bf16* const buf) __attribute__((always_inline)) {
 #pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int pl = base + u * rpp;
-        v[u] = *reinterpret_cast<const f32x4*>(dYc + (m0 + (size_t)min(pl, pv - 1)) * p.ldy);
-      }
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int pl = base + u * rpp;
-        if (!(active && pl < pv)) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        bsum += v[u];
-        if (active && pl < PT) *reinterpret_cast<bf16x4*>(dYs + (size_t)pl * HS + 4 * sch) = to_h4(v[u]);
-      }
+    for (int i = 0; i < NY; ++i) {
+      const int row = srow + i * rpp;
+      const f32x4 v = ((okm >> i) & 1u) ? vy[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+      bsum += v;
+      if (active && row < PT) *reinterpret_cast<bf16x4*>(buf + row * HS + 4 * sch) = to_h4(v);
     }
-    for (int base = srow; base < HT; base += UN * rpp) {
-      f32x4 v[UN];
-      bool ok[UN];
 #pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int hl = min(base + u * rpp, HT - 1);
-        const int hy = hl / W2, hx = hl - hy * W2;
-        const int iy = y0 - 1 + hy, ix = hx - 1;
-        ok[u] = active && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        const size_t xr = ((size_t)b * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1);
-        v[u] = *reinterpret_cast<const f32x4*>(Xc + xr * p.ldx);
-      }
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int hl = base + u * rpp;
-        if (!ok[u]) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (active && hl < HT) *reinterpret_cast<bf16x4*>(Xs + (size_t)hl * HS + 4 * sch) = to_h4(v[u]);
-      }
+    for (int i = 0; i < NX; ++i) {
+      const int hl = srow + i * rpp;
+      const f32x4 v = ((okm >> (16 + i)) & 1u) ? vx[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (active && hl < HT) *reinterpret_cast<bf16x4*>(buf + (PT + hl) * HS + 4 * sch) = to_h4(v);
     }
+  };
+  auto tr8 = [&](const __bf16* r0) __attribute__((always_inline)) -> bf16x8 {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0 + 4 * HS));
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
+    return o;
+  };
+
+  const int c0 = ks * cpw, c_end = min(nchunks, c0 + cpw);
+  issue(c0);
+  store(lds0);
+  __syncthreads();
+  for (int c = c0; c < c_end; ++c) {
+    __bf16* const cur = lds0 + ((c - c0) & 1) * ((PT + HT) * HS);
+    __bf16* const nxt = lds0 + (((c - c0) & 1) ^ 1) * ((PT + HT) * HS);
+    issue(min(c + 1, c_end - 1));                              // unconditional (a load inside a branch costs a vmcnt(0) at the join)
+    // ---- one 32-pixel step per tile row: lane (fq, fr) takes pixels 8 fq + 0..7 of the row ----
+#pragma unroll 1
+    for (int s4 = 0; s4 < WC9_TR; ++s4) {
+      const __bf16* const arow = cur + (s4 * 32 + 8 * fq + tq) * HS + 4 * tp;
+      const __bf16* const brow = cur + (PT + (s4 + ky) * HW + kx + 8 * fq + tq) * HS + 4 * tp;
+      const __bf16* const b8row = cur + (PT + (s4 + 2) * HW + 2 + 8 * fq + tq) * HS + 4 * tp;
+      bf16x8 ah[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) ah[t] = tr8(arow + 16 * t);
+#pragma unroll
+      for (int ec = 0; ec < NT; ++ec) {                         // one X fragment at a time: registers are what bounds this kernel
+        const bf16x8 bh = tr8(brow + 16 * ec);
+#pragma unroll
+        for (int en = 0; en < NT; ++en) acc[en][ec] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[en], bh, acc[en][ec], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < EX; ++i)
+        accx[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(arow + 16 * xen[i]), tr8(b8row + 16 * xec[i]), accx[i], 0, 0, 0);
+    }
+    if (c + 1 < c_end) store(nxt);
     __syncthreads();
-    // ---- 32 pixels per step: lane (fq, fr) takes pixels 8 fq + 0..7 of the step, W % 32 == 0 keeps them in one image row ----
-    const __bf16* arow = dYs + (size_t)(8 * fq + tq) * HS + 4 * tp;
-    const __bf16* brow = Xs + (size_t)(ky * W2 + kx + 8 * fq + tq) * HS + 4 * tp;
-    int x0 = 0;
-    for (int kk = 0; kk < PT; kk += 32) {
-      bf16x8 ah[NT], bh[NT];
+  }
+  // ---- partial tiles: lane (fq, fr) element e of an MFMA tile (en, ec) is (n = 16 en + 4 fq + e, c = 16 ec + fr) ----
+  const int PART = C * C + C;
+  {
+    float* const mypart = part + ((size_t)wave * ksplit + ks) * PART;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(arow + 16 * t));
-        const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(arow + 16 * t + 4 * HS));
-        const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(brow + 16 * t));
-        const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(brow + 16 * t + 4 * HS));
+    for (int en = 0; en < NT; ++en)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { ah[t][e] = alo[e]; ah[t][4 + e] = ahi[e]; bh[t][e] = blo[e]; bh[t][4 + e] = bhi[e]; }
+      for (int e = 0; e < 4; ++e) {
+        const int n = 16 * en + 4 * fq + e;
+#pragma unroll
+        for (int ec = 0; ec < NT; ++ec) {
+          const int c = 16 * ec + fr;
+          if (n < C && c < C) mypart[n * C + c] = acc[en][ec][e];
+        }
       }
+    float* const part8 = part + ((size_t)8 * ksplit + ks) * PART;
 #pragma unroll
-      for (int en = 0; en < NT; ++en)
+    for (int i = 0; i < EX; ++i) {
+      if (wave + 8 * i < NT * NT) {
 #pragma unroll
-        for (int ec = 0; ec < NT; ++ec)
-          acc[en][ec] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[en], bh[ec], acc[en][ec], 0, 0, 0);
-      arow += 32 * HS;
-      x0 += 32;
-      brow += 32 * HS;
-      if (x0 == W) { x0 = 0; brow += 2 * HS; }                  // next image row of the halo tile: skip its two border pixels
+        for (int e = 0; e < 4; ++e) {
+          const int n = 16 * xen[i] + 4 * fq + e, c = 16 * xec[i] + fr;
+          if (n < C && c < C) part8[n * C + c] = accx[i][e];
+        }
+      }
     }
   }
-  // ---- partial tile of this tap: lane (fq, fr) element e of acc[en][ec] is (n = 16 en + 4 fq + e, c = 16 ec + fr) ----
-  const int PART = C * C + C;
-  float* const mypart = part + ((size_t)tap * ksplit + ks) * PART;
-#pragma unroll
-  for (int en = 0; en < NT; ++en)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int n = 16 * en + 4 * fq + e;
-#pragma unroll
-      for (int ec = 0; ec < NT; ++ec) {
-        const int c = 16 * ec + fr;
-        if (n < C && c < C) mypart[n * C + c] = acc[en][ec][e];
-      }
-    }
   // ---- bias sums: the staging threads' float4, summed over the rpp row phases in fixed order ----
-  __syncthreads();
   f32x4* const bs = reinterpret_cast<f32x4*>(wsm);
   if (active) bs[srow * c4n + sch] = bsum;
   __syncthreads();
@@ -859,31 +904,21 @@ int launch_wgrad80(const WgradParams& p, WgradQueue& q, hipStream_t s) {
 }
 
 // 3x3 stride-1 C -> C convolution, all nine taps per workgroup (wgrad_conv9_kernel); false: not this layer's kernel
-static bool conv9_geometry(const WgradParams& p, int& R, size_t& lds) {
+static bool conv9_supported(const WgradParams& p) {
   if (p.ntaps != 9 || p.stride != 1 || p.N != p.Cin || p.n_real != p.N || p.cin_real != p.Cin || p.N > 80 || (p.N & 3) || p.row_scale ||
-      p.x_bf16 || p.dy_bf16 || p.Hi != p.Ho || p.Wi != p.Wo || (p.Wo & 31) || (p.ldy & 3) || (p.ldx & 3) || (p.ycol0 & 3) ||
-      (size_t)p.M < 8192 || getenv("SRAD_NO_WGRAD_CONV9") != nullptr)
+      p.x_bf16 || p.dy_bf16 || p.Hi != p.Ho || p.Wi != p.Wo || (p.Wo % WC9_TW) || (p.ldy & 3) || (p.ldx & 3) || (p.ycol0 & 3) ||
+      (size_t)p.M < 8192 || (size_t)p.M * (size_t)std::max(p.ldy, p.ldx) >= ((size_t)1 << 31) || getenv("SRAD_NO_WGRAD_CONV9") != nullptr)
     return false;
-  if ((reinterpret_cast<uintptr_t>(p.dY) | reinterpret_cast<uintptr_t>(p.X)) & 15) return false;
-  const int nt = (p.N + 15) / 16, hs = nt == 4 ? 72 : 16 * nt;
-  auto bytes = [&](int r) { return ((size_t)r * p.Wo + (size_t)(r + 2) * (p.Wo + 2)) * hs * sizeof(__bf16); };
-  R = 0;
-  for (int pass = 0; pass < 2 && !R; ++pass)                 // rows per chunk: as many as fit, whole chunks per image if possible
-    for (int r = 8; r >= 1; --r)
-      if (r * p.Wo <= 512 && bytes(r) <= (size_t)144 * 1024 && (pass == 1 || p.Ho % r == 0)) { R = r; break; }
-  if (!R) return false;
-  lds = bytes(R);
-  if (lds < (size_t)WC9_THREADS * sizeof(f32x4)) lds = (size_t)WC9_THREADS * sizeof(f32x4);   // the bias-sum exchange
-  return true;
+  return ((reinterpret_cast<uintptr_t>(p.dY) | reinterpret_cast<uintptr_t>(p.X)) & 15) == 0;
 }
 
-int launch_wgrad_conv9(const WgradParams& p, WgradQueue& q, hipStream_t s, const int R, const size_t lds) {
+int launch_wgrad_conv9(const WgradParams& p, WgradQueue& q, hipStream_t s) {
   const int C = p.N, nt = (C + 15) / 16;
   const int B = p.M / (p.Ho * p.Wo);
-  const int nchunks = B * ((p.Ho + R - 1) / R);
-  // workgroups: a chunk costs ~5 us of MFMA time, a workgroup's partial tiles 9 C^2 floats written and read again:
-  // ~6.5 sqrt(chunks) workgroups balance the two (64 for 128 chunks, 128 for 512)
-  int ksplit = (int)(6.5 * sqrt((double)nchunks) + 0.5);
+  const int nchunks = B * ((p.Ho + WC9_TR - 1) / WC9_TR) * (p.Wo / WC9_TW);
+  // workgroups: a 128-pixel tile costs ~2 us, a workgroup ~6 us of ramp plus its partial tiles (9 C^2 floats written and
+  // read again): ~4 sqrt(tiles) workgroups balance the two (64 for 256 tiles, 128 for 1024)
+  int ksplit = (int)(4.0 * sqrt((double)nchunks) + 0.5);
   if (const char* e = getenv("SRAD_WGRAD_KSPLIT")) ksplit = atoi(e) > 0 ? atoi(e) : ksplit;   // tools/: timing experiments
   ksplit = std::max(1, std::min(std::min(ksplit, 256), nchunks));
   const int cpw = (nchunks + ksplit - 1) / ksplit;
@@ -902,22 +937,22 @@ int launch_wgrad_conv9(const WgradParams& p, WgradQueue& q, hipStream_t s, const
   it.ksplit = ksplit; it.tile0 = q.tiles; it.alpha = p.alpha;
   q.tiles += square_reduce_tiles(it, C);
   SradProfScope prof(s, SRAD_K_WGRAD, 2.0 * p.M * C * C * 9.0, 4.0 * p.M * 2.0 * C + 8.0 * 9.0 * PART * ksplit);
-  auto launch = [&](auto kern, bool& configured) -> int {
+  auto launch = [&](auto kern, const size_t lds, bool& configured) -> int {
     if (!configured) {
-      SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       configured = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)ksplit), dim3(WC9_THREADS), lds, s, p, R, cpw, nchunks, ksplit, part);
+    hipLaunchKernelGGL(kern, dim3((unsigned)ksplit), dim3(WC9_THREADS), lds, s, p, cpw, nchunks, ksplit, part);
     return SRAD_OK;
   };
   static bool cfg[6] = {false, false, false, false, false, false};
   int rc = SRAD_OK;
   switch (nt) {
-    case 1: rc = launch(wgrad_conv9_kernel<1>, cfg[1]); break;
-    case 2: rc = launch(wgrad_conv9_kernel<2>, cfg[2]); break;
-    case 3: rc = launch(wgrad_conv9_kernel<3>, cfg[3]); break;
-    case 4: rc = launch(wgrad_conv9_kernel<4>, cfg[4]); break;
-    default: rc = launch(wgrad_conv9_kernel<5>, cfg[5]); break;
+    case 1: rc = launch(wgrad_conv9_kernel<1>, Wc9<1>::LDS, cfg[1]); break;
+    case 2: rc = launch(wgrad_conv9_kernel<2>, Wc9<2>::LDS, cfg[2]); break;
+    case 3: rc = launch(wgrad_conv9_kernel<3>, Wc9<3>::LDS, cfg[3]); break;
+    case 4: rc = launch(wgrad_conv9_kernel<4>, Wc9<4>::LDS, cfg[4]); break;
+    default: rc = launch(wgrad_conv9_kernel<5>, Wc9<5>::LDS, cfg[5]); break;
   }
   if (rc) return rc;
   SRAD_CHECK_HIP(hipGetLastError());
@@ -926,11 +961,7 @@ int launch_wgrad_conv9(const WgradParams& p, WgradQueue& q, hipStream_t s, const
 
 template <int PREC>
 int launch_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s) {
-  if (PREC == SRAD_PREC_BF16) {
-    int R = 0;
-    size_t lds = 0;
-    if (conv9_geometry(p, R, lds)) return launch_wgrad_conv9(p, q, s, R, lds);
-  }
+  if (PREC == SRAD_PREC_BF16 && conv9_supported(p)) return launch_wgrad_conv9(p, q, s);
   if (PREC == SRAD_PREC_BF16 && p.N == 80 && p.Cin == 80 && p.n_real == 80 && p.cin_real == 80 && p.stride == 1 && !p.row_scale &&
       (p.ntaps == 1 || (p.Hi == p.Ho && p.Wi == p.Wo)) && getenv("SRAD_NO_WGRAD80") == nullptr)
     return launch_wgrad80(p, q, s);

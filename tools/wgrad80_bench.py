@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Stand-alone timing of the 3x3 convolution weight gradients of a DRN-L training step (batch 8, LR 64 px): 80 -> 80
-channels at 64 px, 40 -> 40 at 128 px, 20 -> 20 at 256 px.  HIP events around every launch (the library's profiler).
+"""Stand-alone timing of 3x3 convolution weight gradients at DRN-L training shapes (batch 8, LR 64 px): 80 -> 80
+channels at 64 and 128 px (the RCAB convolutions), 40 -> 40 at 128 px, 20 -> 20 at 256 px.  HIP events around every launch (the library's profiler).
 python tools/wgrad80_bench.py [--iters 20]"""
 import argparse
 import os
@@ -17,10 +17,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--ksplit", type=int, default=0, help="override the number of row splits (SRAD_WGRAD_KSPLIT)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     B = a.batch
-    for (C, px) in [(80, 64), (40, 128), (20, 256)]:
+    if a.ksplit:
+        os.environ["SRAD_WGRAD_KSPLIT"] = str(a.ksplit)
+    for (C, px) in [(80, 64), (80, 128), (40, 128), (20, 256)]:
         M = B * px * px
         x = torch.randn(M, C, device=dev)
         dy = torch.randn(M, C, device=dev)
