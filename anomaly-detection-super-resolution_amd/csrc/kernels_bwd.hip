@@ -505,24 +505,44 @@ template <int NT>
 __global__ __launch_bounds__(WC9_THREADS) void wgrad_conv9_kernel(const WgradParams p, const int cpw, const int nchunks,
                                                                   const int ksplit, float* __restrict__ part) {
   constexpr int HS = Wc9<NT>::HS, PT = WC9_PT, HT = WC9_HT, HW = WC9_HW;
-  constexpr int RPP_MIN = WC9_THREADS / (4 * NT);              // staged rows per pass, at least (C <= 16 NT)
-  constexpr int NY = (PT + RPP_MIN - 1) / RPP_MIN, NX = (HT + RPP_MIN - 1) / RPP_MIN;
+  constexpr int NQY_MIN = WC9_THREADS / (16 * NT);             // staging threads per (tile row, channel float4), at least (C <= 16 NT)
+  constexpr int NQX_MIN = WC9_THREADS / (24 * NT) < WC9_HW ? WC9_THREADS / (24 * NT) : WC9_HW;
+  constexpr int NY = (WC9_TW + NQY_MIN - 1) / NQY_MIN, NX = (WC9_HW + NQX_MIN - 1) / NQX_MIN;
   constexpr int EX = (NT * NT + 7) / 8;                        // MFMA tiles of the ninth tap per wave
   typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
   extern __shared__ __attribute__((aligned(16))) float wsm[];
   const int C = p.N, c4n = C >> 2, W = p.Wo, H = p.Ho;
   __bf16* const lds0 = reinterpret_cast<__bf16*>(wsm);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the tap geometry and the ninth tap's tile list live in SGPRs
   const int fr = lane & 15, fq = lane >> 4, tq = fr >> 2, tp = fr & 3;
   const int ky = wave / 3, kx = wave - ky * 3;
   const int ks = blockIdx.x;
   const int tiles_x = W / WC9_TW;
   const int cpi = ((H + WC9_TR - 1) / WC9_TR) * tiles_x;       // tiles per image
 
-  // staging roles: thread (srow, sch) converts float4 sch of tile rows srow, srow + rpp, ...
-  const int rpp = WC9_THREADS / c4n;
-  const bool active = tid < rpp * c4n;
-  const int srow = active ? tid / c4n : 0, sch = active ? tid - srow * c4n : 0;
+  // staging roles: a thread keeps ONE channel float4 (sch) and ONE row of the tile (dY: yy of 4, X: hy of 6) and walks the
+  // row's pixels with a constant stride (dY: x = qy + nqy i, X: hx = qx + nqx i): one multiply-add per load, no divisions
+  // (item = row-of-25 + i * 25 cost ~35 VALU instructions per load: 1 us per tile)
+  // The roles are derived again from the thread id wherever they are used (`roles`): kept in registers between the tiles they
+  // were what spilled.
+  const int nqy = WC9_THREADS / (4 * c4n), nqx = min(WC9_HW, WC9_THREADS / (6 * c4n));
+  struct Roles { int sch, yy, qy, hy, qx; };
+  auto roles = [&]() __attribute__((always_inline)) -> Roles {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    const int t2 = t / c4n;
+    const int h = t2 / 6;
+    return Roles{t - t2 * c4n, t2 & 3, t2 >> 2, t2 - h * 6, h};
+  };
+  unsigned st = 0u;                                            // items that exist: bit i: x < 32, bit 16 + i: hx < 34
+  {
+    const Roles ro = roles();
+#pragma unroll
+    for (int i = 0; i < NY; ++i) if (ro.qy < nqy && ro.qy + nqy * i < WC9_TW) st |= 1u << i;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) if (ro.qx < nqx && ro.qx + nqx * i < WC9_HW) st |= 1u << (16 + i);
+  }
   const float* const dYb = p.dY + p.ycol0;
   const float* const Xb = p.X;
 
@@ -549,24 +569,26 @@ __global__ __launch_bounds__(WC9_THREADS) void wgrad_conv9_kernel(const WgradPar
     const int ty = r / tiles_x, tx = r - ty * tiles_x;
     const int y0 = ty * WC9_TR, x0 = tx * WC9_TW;
     const unsigned img = (unsigned)b * H;
-    okm = 0u;
-    int sr = srow;
-    asm volatile("" : "+v"(sr));                                // keeps the per-row geometry out of registers between tiles (it was hoisted: 25 spilled)
+    const Roles ro = roles();
+    const int sch = ro.sch, qx = ro.qx;
+    const int y = y0 + ro.yy, iy = y0 - 1 + ro.hy;
+    okm = y < H ? (st & 0xffffu) : 0u;
+    const unsigned oy = ((img + min(y, H - 1)) * W + x0 + min(ro.qy, WC9_TW - 1)) * p.ldy + 4 * sch;
+    unsigned sy = (unsigned)nqy * p.ldy;
+    int nqx_o = nqx;
+    asm volatile("" : "+v"(sy), "+v"(nqx_o));                   // per-item offsets are recomputed, not kept in registers between tiles
 #pragma unroll
     for (int i = 0; i < NY; ++i) {
-      const int row = min(sr + i * rpp, PT - 1);
-      const int y = y0 + (row >> 5), x = x0 + (row & 31);
-      if (active && sr + i * rpp < PT && y < H) okm |= 1u << i;
-      const unsigned off = ((img + min(y, H - 1)) * W + x) * p.ldy + 4 * sch;
+      const unsigned off = ((st >> i) & 1u) ? oy + i * sy : oy;
       vy[i] = *reinterpret_cast<const f32x4*>(dYb + off);
     }
+    const unsigned rowx = (img + min(max(iy, 0), H - 1)) * W;
+    const bool rok = iy >= 0 && iy < H;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int hl = min(sr + i * rpp, HT - 1);
-      const int hy = hl / HW, hx = hl - hy * HW;
-      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-      if (active && sr + i * rpp < HT && iy >= 0 && iy < H && ix >= 0 && ix < W) okm |= 1u << (16 + i);
-      const unsigned off = ((img + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)) * p.ldx + 4 * sch;
+      const int ix = x0 - 1 + qx + nqx_o * i;
+      if (rok && (unsigned)ix < (unsigned)W) okm |= st & (1u << (16 + i));
+      const unsigned off = (rowx + min(max(ix, 0), W - 1)) * p.ldx + 4 * sch;
       vx[i] = *reinterpret_cast<const f32x4*>(Xb + off);
     }
   };
@@ -577,18 +599,21 @@ __global__ __launch_bounds__(WC9_THREADS) void wgrad_conv9_kernel(const WgradPar
     return o;
   };
   auto store = [&](__bf16* const buf) __attribute__((always_inline)) {
+    const Roles ro = roles();
+    __bf16* const yrow = buf + (ro.yy * WC9_TW + ro.qy) * HS + 4 * ro.sch;
+    __bf16* const xrow = buf + (PT + ro.hy * HW + ro.qx) * HS + 4 * ro.sch;
+    int ysl = nqy * HS, xsl = nqx * HS;
+    asm volatile("" : "+v"(ysl), "+v"(xsl));
 #pragma unroll
     for (int i = 0; i < NY; ++i) {
-      const int row = srow + i * rpp;
       const f32x4 v = ((okm >> i) & 1u) ? vy[i] : f32x4{0.f, 0.f, 0.f, 0.f};
       bsum += v;
-      if (active && row < PT) *reinterpret_cast<bf16x4*>(buf + row * HS + 4 * sch) = to_h4(v);
+      if ((st >> i) & 1u) *reinterpret_cast<bf16x4*>(yrow + i * ysl) = to_h4(v);
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int hl = srow + i * rpp;
       const f32x4 v = ((okm >> (16 + i)) & 1u) ? vx[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-      if (active && hl < HT) *reinterpret_cast<bf16x4*>(buf + (PT + hl) * HS + 4 * sch) = to_h4(v);
+      if ((st >> (16 + i)) & 1u) *reinterpret_cast<bf16x4*>(xrow + i * xsl) = to_h4(v);
     }
   };
   auto tr8 = [&](const __bf16* r0) __attribute__((always_inline)) -> bf16x8 {
@@ -630,41 +655,47 @@ __global__ __launch_bounds__(WC9_THREADS) void wgrad_conv9_kernel(const WgradPar
     if (c + 1 < c_end) store(nxt);
     __syncthreads();
   }
-  // ---- partial tiles: lane (fq, fr) element e of an MFMA tile (en, ec) is (n = 16 en + 4 fq + e, c = 16 ec + fr) ----
+  // ---- partial tiles: lane (fq, fr) element e of an MFMA tile (en, ec) is (n = 16 en + 4 fq + e, c = 16 ec + fr).
+  //      Everything the epilogue needs is derived again from the thread id: nothing of it occupies registers during the loop ----
+  int tid_e = threadIdx.x;
+  asm volatile("" : "+v"(tid_e));
+  const int wave_e = __builtin_amdgcn_readfirstlane(tid_e >> 6), fr_e = tid_e & 15, fq_e = (tid_e >> 4) & 3;
   const int PART = C * C + C;
   {
-    float* const mypart = part + ((size_t)wave * ksplit + ks) * PART;
+    float* const mypart = part + ((size_t)wave_e * ksplit + ks) * PART;
 #pragma unroll
     for (int en = 0; en < NT; ++en)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int n = 16 * en + 4 * fq + e;
+        const int n = 16 * en + 4 * fq_e + e;
 #pragma unroll
         for (int ec = 0; ec < NT; ++ec) {
-          const int c = 16 * ec + fr;
+          const int c = 16 * ec + fr_e;
           if (n < C && c < C) mypart[n * C + c] = acc[en][ec][e];
         }
       }
     float* const part8 = part + ((size_t)8 * ksplit + ks) * PART;
 #pragma unroll
     for (int i = 0; i < EX; ++i) {
-      if (wave + 8 * i < NT * NT) {
+      const int t = wave_e + 8 * i, ten = t / NT, tec = t - ten * NT;
+      if (t < NT * NT) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int n = 16 * xen[i] + 4 * fq + e, c = 16 * xec[i] + fr;
+          const int n = 16 * ten + 4 * fq_e + e, c = 16 * tec + fr_e;
           if (n < C && c < C) part8[n * C + c] = accx[i][e];
         }
       }
     }
   }
-  // ---- bias sums: the staging threads' float4, summed over the rpp row phases in fixed order ----
+  // ---- bias sums: the staging threads' float4, summed over the 4 nqy thread rows in fixed order ----
   f32x4* const bs = reinterpret_cast<f32x4*>(wsm);
-  if (active) bs[srow * c4n + sch] = bsum;
+  const int c4n_e = C >> 2, sch_e = tid_e % c4n_e, t2_e = tid_e / c4n_e, nqy_e = WC9_THREADS / (4 * c4n_e);
+  if ((t2_e >> 2) < nqy_e) bs[t2_e * c4n_e + sch_e] = bsum;
   __syncthreads();
-  if (tid < c4n) {
-    f32x4 t = bs[tid];
-    for (int r = 1; r < rpp; ++r) t += bs[r * c4n + tid];
-    *reinterpret_cast<f32x4*>(part + (size_t)ks * PART + C * C + 4 * tid) = t;
+  if (tid_e < c4n_e) {
+    f32x4 t = bs[tid_e];
+    for (int r = 1; r < 4 * nqy_e; ++r) t += bs[r * c4n_e + tid_e];
+    *reinterpret_cast<f32x4*>(part + (size_t)ks * PART + C * C + 4 * tid_e) = t;
   }
 }
 
@@ -918,7 +949,9 @@ int launch_wgrad_conv9(const WgradParams& p, WgradQueue& q, hipStream_t s) {
   const int nchunks = B * ((p.Ho + WC9_TR - 1) / WC9_TR) * (p.Wo / WC9_TW);
   // workgroups: a 128-pixel tile costs ~2 us, a workgroup ~6 us of ramp plus its partial tiles (9 C^2 floats written and
   // read again): ~4 sqrt(tiles) workgroups balance the two (64 for 256 tiles, 128 for 1024)
-  int ksplit = (int)(4.0 * sqrt((double)nchunks) + 0.5);
+  double kmul = 4.0;
+  if (const char* e = getenv("SRAD_CONV9_KMUL")) kmul = atof(e) > 0 ? atof(e) : kmul;          // tools/: timing experiments
+  int ksplit = (int)(kmul * sqrt((double)nchunks) + 0.5);
   if (const char* e = getenv("SRAD_WGRAD_KSPLIT")) ksplit = atoi(e) > 0 ? atoi(e) : ksplit;   // tools/: timing experiments
   ksplit = std::max(1, std::min(std::min(ksplit, 256), nchunks));
   const int cpw = (nchunks + ksplit - 1) / ksplit;

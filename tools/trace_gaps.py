@@ -40,14 +40,14 @@ def main():
                             "gap_time_over_10us": sum(g for g in pos if g > 10000) / 1e3}
     by_name = collections.defaultdict(lambda: [0, 0])
     for s, e, n, q in step:
-        k = n.split("(")[0].split("<")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+        k = n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0]
         by_name[k][0] += 1
         by_name[k][1] += e - s
     res["by_kernel_us"] = {k: {"launches": v[0], "total_us": v[1] / 1e3, "avg_us": v[1] / v[0] / 1e3}
                            for k, v in sorted(by_name.items(), key=lambda kv: -kv[1][1])}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: v for k, v in res.items() if k != "by_kernel_us"}, indent=1))
-    for k, v in list(res["by_kernel_us"].items())[:14]:
+    for k, v in list(res["by_kernel_us"].items())[:24]:
         print(f"  {k:40s} {v['launches']:4d} x {v['avg_us']:7.2f} us = {v['total_us'] / 1e3:6.3f} ms")
 
 
