@@ -100,6 +100,24 @@ class TensorAdam:
                                            self.betas[1], self.eps, self.weight_decay, self.step_count, float(grad_scale),
                                            L.current_stream_ptr()), "adam_step")
 
+    def hyper(self, grad_scale: float = 1.0) -> List[float]:
+        """[lr, 1 - beta1^t, sqrt(1 - beta2^t), grad_scale] of the NEXT step (as ``FusedAdam.hyper``)."""
+        t = self.step_count + 1
+        b1, b2 = (struct.unpack("f", struct.pack("f", b))[0] for b in self.betas)
+        return [float(self.param_groups[0]["lr"]), 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t), float(grad_scale)]
+
+    def step_dev(self, dev_hyper: torch.Tensor) -> None:
+        """``step()`` with the per-step scalars on the GPU (inside a captured hipGraph); the caller bumps ``step_count``."""
+        for p, (m, v) in zip(self.params, self.state):
+            if p.grad is None:
+                continue
+            g = p.grad.detach().float().contiguous()
+            if not p.data.is_contiguous():
+                raise RuntimeError("TensorAdam needs contiguous parameters")
+            L.check(L.lib().srad_adam_step_dev(L.dptr(p.data), L.dptr(g), L.dptr(m), L.dptr(v), p.numel(), self.betas[0],
+                                               self.betas[1], self.eps, self.weight_decay, L.dptr(dev_hyper),
+                                               L.current_stream_ptr()), "adam_step_dev")
+
     def state_dict(self):
         return {"step": self.step_count, "lr": self.param_groups[0]["lr"],
                 "exp_avg": [m for m, _ in self.state], "exp_avg_sq": [v for _, v in self.state]}
@@ -292,3 +310,69 @@ def drn_train_step(model, dual_models, lr_list, hr, optimizer, dual_optimizers, 
     for o in dual_optimizers:
         o.step(scale) if isinstance(o, TensorAdam) else o.step()
     return loss.detach()
+
+
+class GraphedDrnTrainStep:
+    """``drn_train_step`` for one GPU as ONE hipGraph (as ``GraphedTrainStep`` for DRCT): the ~1000 launches of a DRN-L step
+    with its dual models - zero_grad, re-pack, forward, the composite loss, autograd's chain through the dual models into the
+    engine's two-stream backward, Adam for the SR net and for every dual model - are captured once per batch shape and
+    replayed.  Per step only the input copies, one 16-byte copy of Adam's scalars per optimizer and the graph launch are
+    issued.  The dual optimizers must be ``TensorAdam`` (the engine's kernel, scalars on the GPU); with a ``GradReducer`` the
+    step runs eagerly (collectives are launched from the host inside the backward)."""
+
+    def __init__(self, model, dual_models, optimizer: FusedAdam, dual_optimizers, dual_weight: float = 0.1, loss_fn=None,
+                 warmup: int = 2):
+        for o in dual_optimizers:
+            if not isinstance(o, TensorAdam):
+                raise TypeError("GraphedDrnTrainStep needs TensorAdam dual optimizers (torch.optim steps read host scalars)")
+        self.model, self.duals, self.optimizer, self.dual_optimizers = model, list(dual_models), optimizer, list(dual_optimizers)
+        self.dual_weight, self.loss_fn, self.warmup = float(dual_weight), loss_fn, int(warmup)
+        self._graphs = {}
+        self._eager_calls = {}
+
+    def _body(self, lrs, hr, hypers):
+        self.optimizer.zero_grad()
+        for o in self.dual_optimizers:
+            o.zero_grad()
+        sr = self.model(lrs[0])
+        sr2lr = [self.duals[i](sr[i - len(self.duals)]) for i in range(len(self.duals))]
+        loss = drn_loss(sr, lrs, hr, sr2lr, self.dual_weight, self.loss_fn)
+        loss.backward()
+        self.optimizer.step_dev(hypers[0])
+        for o, h in zip(self.dual_optimizers, hypers[1:]):
+            o.step_dev(h)
+        return loss.detach()
+
+    def __call__(self, lr_list, hr: torch.Tensor) -> torch.Tensor:
+        m = self.model
+        key = (tuple(tuple(t.shape) for t in lr_list), tuple(hr.shape))
+        entry = self._graphs.get(key)
+        if entry is None:
+            n = self._eager_calls.get(key, 0)
+            if n < self.warmup:
+                self._eager_calls[key] = n + 1          # allocates workspaces, configures kernels, creates the side stream
+                return drn_train_step(m, self.duals, lr_list, hr, self.optimizer, self.dual_optimizers, self.dual_weight,
+                                      None, self.loss_fn)
+            s_lrs = [t.detach().float().contiguous().clone() for t in lr_list]
+            s_hr = hr.detach().float().contiguous().clone()
+            hypers = [torch.zeros(4, dtype=torch.float32, device=hr.device) for _ in range(1 + len(self.dual_optimizers))]
+            m.mark_params_dirty()                      # the capture starts with the re-pack of the parameters
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss = self._body(s_lrs, s_hr, hypers)
+            entry = (g, s_lrs, s_hr, loss, hypers)
+            self._graphs[key] = entry
+        g, s_lrs, s_hr, loss, hypers = entry
+        for a, b in zip(s_lrs, lr_list):
+            a.copy_(b, non_blocking=True)
+        s_hr.copy_(hr, non_blocking=True)
+        for o, h in zip([self.optimizer] + self.dual_optimizers, hypers):
+            v = o.hyper()
+            L.check(L.lib().srad_set4(L.dptr(h), v[0], v[1], v[2], v[3], L.current_stream_ptr()), "set4")
+        g.replay()
+        for o in [self.optimizer] + self.dual_optimizers:
+            o.step_count += 1
+        m.mark_params_dirty()                          # the replayed Adam changed the flat parameters
+        return loss.clone()
+

@@ -12,7 +12,7 @@ from tests.test_gpu_drn import Opt
 pytestmark = pytest.mark.gpu
 
 
-def _setup(scale, n_colors, n_blocks, n_feats, B, H, W, seed=31):
+def _setup(scale, n_colors, n_blocks, n_feats, B, H, W, seed=31, prec="fp32"):
     from srad_amd import spec as S
     from srad_amd.nets import DRN, DownBlock
     cfg = S.DRNConfig(n_colors=n_colors, scale=scale, n_blocks=n_blocks, n_feats=n_feats)
@@ -21,13 +21,13 @@ def _setup(scale, n_colors, n_blocks, n_feats, B, H, W, seed=31):
     x = S.synth_image("drn_tr", (B, n_colors, H, W), seed=5)
     lrs = [x] + [S.synth_image(f"drn_tr/lr{i}", (B, n_colors, H * 2 ** i, W * 2 ** i), seed=6 + i) for i in range(1, cfg.phase)]
     hr = S.synth_image("drn_tr/hr", (B, n_colors, H * scale, W * scale), seed=9)
-    m = DRN(Opt(cfg, "fp32")).cuda()
+    m = DRN(Opt(cfg, prec)).cuda()
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     m.train()
     m.enable_training()
     dms = []
     for d in duals:
-        dm = DownBlock(Opt(cfg, "fp32")).cuda()
+        dm = DownBlock(Opt(cfg, prec)).cuda()
         dm.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in d.items()})
         dms.append(dm)
     return cfg, sd, duals, lrs, hr, m, dms
@@ -83,6 +83,32 @@ def test_drn_train_steps_reduce_the_loss_and_eval_uses_new_weights():
     with torch.no_grad():
         y = m(lr_t[0])
     assert len(y) == 3 and bool(torch.isfinite(y[-1]).all())
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_graphed_drn_step_equals_the_eager_steps(prec):
+    """GraphedDrnTrainStep (one hipGraph per step: forward, composite loss, autograd through the dual models, two-stream
+    backward, Adam for the SR net and the dual models) against the same steps launched eagerly: same losses, same weights."""
+    from srad_amd.train import FusedAdam, GraphedDrnTrainStep, TensorAdam, drn_train_step
+    runs = []
+    for mode in ("eager", "graph"):
+        cfg, sd, duals, lrs, hr, m, dms = _setup(4, 3, 2, 20, 2, 16, 16, prec=prec)
+        opt = FusedAdam(m, lr=1e-4, weight_decay=1e-8)
+        dopts = [TensorAdam(dm.parameters(), lr=1e-4, weight_decay=1e-8) for dm in dms]
+        lr_t = [torch.from_numpy(a).cuda() for a in lrs]
+        hr_t = torch.from_numpy(hr).cuda()
+        step = (GraphedDrnTrainStep(m, dms, opt, dopts, warmup=2) if mode == "graph"
+                else (lambda a, b: drn_train_step(m, dms, a, b, opt, dopts)))
+        losses = [float(step([t + 0.5 * i for t in lr_t], hr_t)) for i in range(6)]       # a different batch every step
+        runs.append((losses, m.flat_params.clone(), [p.detach().clone() for dm in dms for p in dm.parameters()],
+                     opt.step_count, [o.step_count for o in dopts]))
+    (le, pe, de, se, sde), (lg, pg, dg, sg, sdg) = runs
+    print("eager", le, "graph", lg)
+    assert se == sg == 6 and sde == sdg
+    assert max(abs(a - b) / abs(a) for a, b in zip(le, lg)) < 1e-5
+    assert rel_err(pg.cpu().numpy(), pe.cpu().numpy()) < 1e-5
+    for a, b in zip(de, dg):
+        assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
 
 
 def test_drn_x8_preset_training_is_refused():

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--graph", action="store_true", help="time the step as one replayed hipGraph (train.GraphedDrnTrainStep)")
     a = ap.parse_args()
     o = Opt()
     o.precision = a.dtype
@@ -45,6 +46,20 @@ def main():
         loss = drn_train_step(m, duals, lrs, hr, opt, dopts)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
+    if a.graph:
+        from srad_amd.train import GraphedDrnTrainStep, TensorAdam
+        gopts = [TensorAdam(d.parameters(), lr=1e-4, weight_decay=1e-8) for d in duals]
+        gstep = GraphedDrnTrainStep(m, duals, opt, gopts, warmup=2)
+        for _ in range(4):
+            gstep(lrs, hr)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            loss = gstep(lrs, hr)
+        torch.cuda.synchronize()
+        print(json.dumps({"graphed_ms_per_step": round((time.perf_counter() - t0) / a.steps * 1e3, 2), "eager_ms_per_step": round(dt * 1e3, 2),
+                          "loss": float(loss)}))
+        return
     L.prof_enable(True)
     drn_train_step(m, duals, lrs, hr, opt, dopts)
     torch.cuda.synchronize()
