@@ -486,183 +486,204 @@ __global__ __launch_bounds__(256) void wgrad80_kernel(const WgradParams p, const
 // layer at 64 px, batch 8) in workgroups of four waves that live for four row steps: 38 us at 64 px, ~130 us at 128 px.
 // Here a workgroup stages a 4 x 32 pixel tile of dY and its 6 x 34 halo tile of X ONCE, as bf16, in LDS ([pixel][channel],
 // the memory order).  Both MFMA operands are k-contiguous along the PIXEL axis, i.e. transposed with respect to the tiles,
-// so they come out of LDS with ds_read_tr16_b64, and a tap is a constant row offset into the halo tile.  Wave t of eight
-// owns tap t's C x C accumulator; the ninth tap's (C/16)^2 MFMA tiles are dealt over the eight waves (tile w, w + 8, ..).
-// Eight waves = two per SIMD = 256 registers each: the NEXT tile's rows are requested before this tile's MFMAs and wait in
-// registers (the first version staged and computed in turns with nine waves and 168 registers: 7 us of load round trips and
-// 4.6 us of MFMAs per 256 pixels); they are converted into the other LDS buffer afterwards, one barrier per tile.
+// so they come out of LDS with ds_read_tr16_b64, and a tap is a constant row offset into the halo tile.  MFMA wave t of eight
+// owns tap t's C x C accumulator; the ninth tap's tiles are one tile COLUMN for each of the first C / 16 waves.
 // A workgroup walks `cpw` consecutive tiles, so the partial tiles (9 C^2 floats per workgroup, the cost of split-K here)
 // are amortised.  Bias sums: fp32, by the staging threads.
+// Versions measured on the way (80 channels, 64 / 128 px, alone on the chip; DESIGN.md 4b has the table): nine waves staging
+// and computing in turns 37 / 68 us; eight waves with the next tile prefetched into registers behind the MFMAs 31.4 / 52.7 us;
+// the staging on four loader waves of its own (this kernel) 29.3 / 45.3 us.
 // ------------------------------------------------------------------------------------------
-constexpr int WC9_THREADS = 512, WC9_TW = 32, WC9_TR = 4, WC9_PT = WC9_TW * WC9_TR, WC9_HW = WC9_TW + 2, WC9_HT = (WC9_TR + 2) * WC9_HW;
+constexpr int WC9_TW = 32, WC9_TR = 4, WC9_PT = WC9_TW * WC9_TR, WC9_HW = WC9_TW + 2, WC9_HT = (WC9_TR + 2) * WC9_HW;
 template <int NT> struct Wc9 {
-  static constexpr int HS = NT == 4 ? 72 : 16 * NT;            // LDS row stride (bf16): conflict-free transposing reads
-  static constexpr size_t LDS = (size_t)2 * (WC9_PT + WC9_HT) * HS * sizeof(__bf16) > (size_t)WC9_THREADS * 16
-                                    ? (size_t)2 * (WC9_PT + WC9_HT) * HS * sizeof(__bf16) : (size_t)WC9_THREADS * 16;
+  // LDS row stride (bf16): an odd multiple of 32 bytes.  A transposing read's 32 lanes (one phase of the 64 banks) then take
+  // EIGHT CONSECUTIVE pixel rows x 32 bytes = every bank once; which pixel stands for which k of the MFMA is free as long as
+  // dY and X agree, so lane (fq, tq) reads pixels 4 fq + tq and 16 + 4 fq + tq of a 32-pixel step.  (With pixels 8 fq + tq
+  // and + 4 - the operand layout read literally - rows 0-3 and 8-11 share a phase and collide for EVERY stride that is a
+  // multiple of 32 bytes: SQ_LDS_BANK_CONFLICT was 50 % of the LDS cycles, and LDS reads are what bounds this kernel.)
+  static constexpr int HS = NT == 2 ? 48 : NT == 4 ? 80 : 16 * NT;
+  static constexpr size_t LDS = (size_t)2 * (WC9_PT + WC9_HT) * HS * sizeof(__bf16);       // two tile buffers (>= the 4 KB bias exchange)
 };
 
+// Twelve waves: eight MFMA waves (accumulators and fragments only) and FOUR LOADER WAVES (waves 8 - 11), three per SIMD = 168
+// registers each.  The loader waves hold the next-but-one tile's rows in registers (28 float4 per thread) and convert the next
+// tile into the other LDS buffer WHILE the MFMA waves work on this one.  Both roles pass exactly one barrier per tile (and one
+// before and one after the loop); each role has a loop of its own so that the loaders' outstanding loads never meet a join.
+constexpr int WC9S_THREADS = 768, WC9S_LOADERS = 256;
+
 template <int NT>
-__global__ __launch_bounds__(WC9_THREADS) void wgrad_conv9_kernel(const WgradParams p, const int cpw, const int nchunks,
-                                                                  const int ksplit, float* __restrict__ part) {
+__global__ __launch_bounds__(WC9S_THREADS) void wgrad_conv9_kernel(const WgradParams p, const int cpw, const int nchunks,
+                                                                    const int ksplit, float* __restrict__ part) {
   constexpr int HS = Wc9<NT>::HS, PT = WC9_PT, HT = WC9_HT, HW = WC9_HW;
-  constexpr int NQY_MIN = WC9_THREADS / (16 * NT);             // staging threads per (tile row, channel float4), at least (C <= 16 NT)
-  constexpr int NQX_MIN = WC9_THREADS / (24 * NT) < WC9_HW ? WC9_THREADS / (24 * NT) : WC9_HW;
+  constexpr int ROWS_MIN = WC9S_LOADERS / (4 * NT);            // loader thread rows (threads / channel float4s), at least
+  constexpr int NQY_MIN = ROWS_MIN / 4, NQX_MIN = ROWS_MIN / 6 < WC9_HW ? ROWS_MIN / 6 : WC9_HW;
   constexpr int NY = (WC9_TW + NQY_MIN - 1) / NQY_MIN, NX = (WC9_HW + NQX_MIN - 1) / NQX_MIN;
-  constexpr int EX = (NT * NT + 7) / 8;                        // MFMA tiles of the ninth tap per wave
+  static_assert(NY + NX <= 32, "item masks are one 32-bit word");
+  constexpr int BUF = (PT + HT) * HS;
   typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
   extern __shared__ __attribute__((aligned(16))) float wsm[];
   const int C = p.N, c4n = C >> 2, W = p.Wo, H = p.Ho;
   __bf16* const lds0 = reinterpret_cast<__bf16*>(wsm);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the tap geometry and the ninth tap's tile list live in SGPRs
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ks = blockIdx.x;
+  const int c0 = ks * cpw, c_end = min(nchunks, c0 + cpw);
+  const int PART = C * C + C;
+  const int rows = WC9S_LOADERS / c4n, nqy = rows >> 2, nqx = min(WC9_HW, rows / 6);
+
+  if (wave >= 8) {
+    // =========================== loader waves ===========================
+    const int tiles_x = W / WC9_TW;
+    const int cpi = ((H + WC9_TR - 1) / WC9_TR) * tiles_x;
+    // a loader thread keeps ONE channel float4 (sch) and ONE row of the tile (dY: yy of 4, X: hy of 6) and walks the row's
+    // pixels with a constant stride; the roles are derived again from the thread id wherever they are used (see above)
+    struct Roles { int sch, t2, yy, qy, hy, qx; };
+    auto roles = [&]() __attribute__((always_inline)) -> Roles {
+      int t = threadIdx.x - 512;
+      asm volatile("" : "+v"(t));
+      const int t2 = t / c4n;
+      const int h = t2 / 6;
+      return Roles{t - t2 * c4n, t2, t2 & 3, t2 >> 2, t2 - h * 6, h};
+    };
+    unsigned st = 0u;                                          // items that exist: bit i: x < 32, bit NY + i: hx < 34
+    {
+      const Roles ro = roles();
+#pragma unroll
+      for (int i = 0; i < NY; ++i) if (ro.qy < nqy && ro.qy + nqy * i < WC9_TW) st |= 1u << i;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) if (ro.qx < nqx && ro.qx + nqx * i < WC9_HW) st |= 1u << (NY + i);
+    }
+    const float* const dYb = p.dY + p.ycol0;
+    const float* const Xb = p.X;
+    f32x4 vy[NY], vx[NX];
+    f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned okm = 0u;
+    auto issue = [&](const int chunk) __attribute__((always_inline)) {
+      const int b = chunk / cpi, r = chunk - b * cpi;
+      const int ty = r / tiles_x, tx = r - ty * tiles_x;
+      const int y0 = ty * WC9_TR, x0 = tx * WC9_TW;
+      const unsigned img = (unsigned)b * H;
+      const Roles ro = roles();
+      const int sch = ro.sch, qx = ro.qx;
+      const int y = y0 + ro.yy, iy = y0 - 1 + ro.hy;
+      okm = y < H ? (st & ((1u << NY) - 1u)) : 0u;
+      const unsigned oy = ((img + min(y, H - 1)) * W + x0 + min(ro.qy, WC9_TW - 1)) * p.ldy + 4 * sch;
+      unsigned sy = (unsigned)nqy * p.ldy;
+      int nqx_o = nqx;
+      asm volatile("" : "+v"(sy), "+v"(nqx_o));                 // per-item offsets are recomputed, not kept in registers between tiles
+#pragma unroll
+      for (int i = 0; i < NY; ++i) {
+        const unsigned off = ((st >> i) & 1u) ? oy + i * sy : oy;
+        vy[i] = *reinterpret_cast<const f32x4*>(dYb + off);
+      }
+      const unsigned rowx = (img + min(max(iy, 0), H - 1)) * W;
+      const bool rok = iy >= 0 && iy < H;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const int ix = x0 - 1 + qx + nqx_o * i;
+        if (rok && (unsigned)ix < (unsigned)W) okm |= st & (1u << (NY + i));
+        const unsigned off = (rowx + min(max(ix, 0), W - 1)) * p.ldx + 4 * sch;
+        vx[i] = *reinterpret_cast<const f32x4*>(Xb + off);
+      }
+    };
+    auto to_h4 = [](const f32x4 v) __attribute__((always_inline)) -> bf16x4 {
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+      return o;
+    };
+    auto store = [&](__bf16* const buf) __attribute__((always_inline)) {
+      const Roles ro = roles();
+      __bf16* const yrow = buf + (ro.yy * WC9_TW + ro.qy) * HS + 4 * ro.sch;
+      __bf16* const xrow = buf + (PT + ro.hy * HW + ro.qx) * HS + 4 * ro.sch;
+      int ysl = nqy * HS, xsl = nqx * HS;
+      asm volatile("" : "+v"(ysl), "+v"(xsl));
+#pragma unroll
+      for (int i = 0; i < NY; ++i) {
+        const f32x4 v = ((okm >> i) & 1u) ? vy[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        bsum += v;
+        if ((st >> i) & 1u) *reinterpret_cast<bf16x4*>(yrow + i * ysl) = to_h4(v);
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const f32x4 v = ((okm >> (NY + i)) & 1u) ? vx[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if ((st >> (NY + i)) & 1u) *reinterpret_cast<bf16x4*>(xrow + i * xsl) = to_h4(v);
+      }
+    };
+    issue(c0);
+    store(lds0);
+    issue(min(c0 + 1, c_end - 1));
+    __syncthreads();                                           // tile c0 is in buffer 0
+    for (int c = c0; c < c_end; ++c) {
+      if (c + 1 < c_end) store(lds0 + (((c + 1 - c0) & 1) ? BUF : 0));
+      issue(min(c + 2, c_end - 1));                            // unconditional: clamped re-reads at the end of the range
+      __syncthreads();
+    }
+    // bias sums: one float4 per loader thread, summed over the thread rows in fixed order by the first MFMA wave
+    f32x4* const bs = reinterpret_cast<f32x4*>(wsm);
+    {
+      const Roles ro = roles();
+      if (ro.qy < nqy) bs[ro.t2 * c4n + ro.sch] = bsum;
+    }
+    __syncthreads();
+    return;
+  }
+
+  // =========================== MFMA waves ===========================
+  const int lane = tid & 63;
   const int fr = lane & 15, fq = lane >> 4, tq = fr >> 2, tp = fr & 3;
   const int ky = wave / 3, kx = wave - ky * 3;
-  const int ks = blockIdx.x;
-  const int tiles_x = W / WC9_TW;
-  const int cpi = ((H + WC9_TR - 1) / WC9_TR) * tiles_x;       // tiles per image
-
-  // staging roles: a thread keeps ONE channel float4 (sch) and ONE row of the tile (dY: yy of 4, X: hy of 6) and walks the
-  // row's pixels with a constant stride (dY: x = qy + nqy i, X: hx = qx + nqx i): one multiply-add per load, no divisions
-  // (item = row-of-25 + i * 25 cost ~35 VALU instructions per load: 1 us per tile)
-  // The roles are derived again from the thread id wherever they are used (`roles`): kept in registers between the tiles they
-  // were what spilled.
-  const int nqy = WC9_THREADS / (4 * c4n), nqx = min(WC9_HW, WC9_THREADS / (6 * c4n));
-  struct Roles { int sch, yy, qy, hy, qx; };
-  auto roles = [&]() __attribute__((always_inline)) -> Roles {
-    int t = threadIdx.x;
-    asm volatile("" : "+v"(t));
-    const int t2 = t / c4n;
-    const int h = t2 / 6;
-    return Roles{t - t2 * c4n, t2 & 3, t2 >> 2, t2 - h * 6, h};
-  };
-  unsigned st = 0u;                                            // items that exist: bit i: x < 32, bit 16 + i: hx < 34
-  {
-    const Roles ro = roles();
-#pragma unroll
-    for (int i = 0; i < NY; ++i) if (ro.qy < nqy && ro.qy + nqy * i < WC9_TW) st |= 1u << i;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) if (ro.qx < nqx && ro.qx + nqx * i < WC9_HW) st |= 1u << (16 + i);
-  }
-  const float* const dYb = p.dY + p.ycol0;
-  const float* const Xb = p.X;
-
-  f32x4 acc[NT][NT], accx[EX];
+  // the ninth tap: wave w < NT takes COLUMN w of its NT x NT MFMA tiles - the dY fragments it holds anyway and one more X
+  // fragment (dealing the tiles w, w + 8, .. over all eight waves cost two fragment reads per MFMA: 16 of a wave's 36
+  // transposing reads per step for 4 of its 29 MFMAs, and LDS reads are what bounds a tile)
+  f32x4 acc[NT][NT], accx[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < EX; ++i) accx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
-  int xen[EX], xec[EX];                                        // this wave's tiles of tap 8 (clamped: the surplus ones are not stored)
-#pragma unroll
-  for (int i = 0; i < EX; ++i) {
-    const int t = min(wave + 8 * i, NT * NT - 1);
-    xen[i] = t / NT;
-    xec[i] = t - xen[i] * NT;
-  }
-
-  f32x4 vy[NY], vx[NX];
-  unsigned okm = 0u;                                           // bit i: vy[i] is a real pixel; bit 16 + i: vx[i] is inside the image
-  auto issue = [&](const int chunk) __attribute__((always_inline)) {
-    const int b = chunk / cpi, r = chunk - b * cpi;
-    const int ty = r / tiles_x, tx = r - ty * tiles_x;
-    const int y0 = ty * WC9_TR, x0 = tx * WC9_TW;
-    const unsigned img = (unsigned)b * H;
-    const Roles ro = roles();
-    const int sch = ro.sch, qx = ro.qx;
-    const int y = y0 + ro.yy, iy = y0 - 1 + ro.hy;
-    okm = y < H ? (st & 0xffffu) : 0u;
-    const unsigned oy = ((img + min(y, H - 1)) * W + x0 + min(ro.qy, WC9_TW - 1)) * p.ldy + 4 * sch;
-    unsigned sy = (unsigned)nqy * p.ldy;
-    int nqx_o = nqx;
-    asm volatile("" : "+v"(sy), "+v"(nqx_o));                   // per-item offsets are recomputed, not kept in registers between tiles
-#pragma unroll
-    for (int i = 0; i < NY; ++i) {
-      const unsigned off = ((st >> i) & 1u) ? oy + i * sy : oy;
-      vy[i] = *reinterpret_cast<const f32x4*>(dYb + off);
-    }
-    const unsigned rowx = (img + min(max(iy, 0), H - 1)) * W;
-    const bool rok = iy >= 0 && iy < H;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      const int ix = x0 - 1 + qx + nqx_o * i;
-      if (rok && (unsigned)ix < (unsigned)W) okm |= st & (1u << (16 + i));
-      const unsigned off = (rowx + min(max(ix, 0), W - 1)) * p.ldx + 4 * sch;
-      vx[i] = *reinterpret_cast<const f32x4*>(Xb + off);
-    }
-  };
-  auto to_h4 = [](const f32x4 v) __attribute__((always_inline)) -> bf16x4 {
-    bf16x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-    return o;
-  };
-  auto store = [&](__bf16* const buf) __attribute__((always_inline)) {
-    const Roles ro = roles();
-    __bf16* const yrow = buf + (ro.yy * WC9_TW + ro.qy) * HS + 4 * ro.sch;
-    __bf16* const xrow = buf + (PT + ro.hy * HW + ro.qx) * HS + 4 * ro.sch;
-    int ysl = nqy * HS, xsl = nqx * HS;
-    asm volatile("" : "+v"(ysl), "+v"(xsl));
-#pragma unroll
-    for (int i = 0; i < NY; ++i) {
-      const f32x4 v = ((okm >> i) & 1u) ? vy[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-      bsum += v;
-      if ((st >> i) & 1u) *reinterpret_cast<bf16x4*>(yrow + i * ysl) = to_h4(v);
-    }
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      const f32x4 v = ((okm >> (16 + i)) & 1u) ? vx[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-      if ((st >> (16 + i)) & 1u) *reinterpret_cast<bf16x4*>(xrow + i * xsl) = to_h4(v);
-    }
-  };
+  for (int i = 0; i < NT; ++i) accx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto tr8 = [&](const __bf16* r0) __attribute__((always_inline)) -> bf16x8 {
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0 + 4 * HS));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0 + 16 * HS));
     bf16x8 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
     return o;
   };
-
-  const int c0 = ks * cpw, c_end = min(nchunks, c0 + cpw);
-  issue(c0);
-  store(lds0);
-  __syncthreads();
+  __syncthreads();                                             // tile c0 is in buffer 0
   for (int c = c0; c < c_end; ++c) {
-    __bf16* const cur = lds0 + ((c - c0) & 1) * ((PT + HT) * HS);
-    __bf16* const nxt = lds0 + (((c - c0) & 1) ^ 1) * ((PT + HT) * HS);
-    issue(min(c + 1, c_end - 1));                              // unconditional (a load inside a branch costs a vmcnt(0) at the join)
-    // ---- one 32-pixel step per tile row: lane (fq, fr) takes pixels 8 fq + 0..7 of the row ----
+    const __bf16* const cur = lds0 + (((c - c0) & 1) ? BUF : 0);
 #pragma unroll 1
     for (int s4 = 0; s4 < WC9_TR; ++s4) {
-      const __bf16* const arow = cur + (s4 * 32 + 8 * fq + tq) * HS + 4 * tp;
-      const __bf16* const brow = cur + (PT + (s4 + ky) * HW + kx + 8 * fq + tq) * HS + 4 * tp;
-      const __bf16* const b8row = cur + (PT + (s4 + 2) * HW + 2 + 8 * fq + tq) * HS + 4 * tp;
+      const __bf16* const arow = cur + (s4 * 32 + 4 * fq + tq) * HS + 4 * tp;
+      const __bf16* const brow = cur + (PT + (s4 + ky) * HW + kx + 4 * fq + tq) * HS + 4 * tp;
+      const __bf16* const b8row = cur + (PT + (s4 + 2) * HW + 2 + 4 * fq + tq) * HS + 4 * tp;
       bf16x8 ah[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) ah[t] = tr8(arow + 16 * t);
+      bf16x8 bh = tr8(brow);
 #pragma unroll
-      for (int ec = 0; ec < NT; ++ec) {                         // one X fragment at a time: registers are what bounds this kernel
-        const bf16x8 bh = tr8(brow + 16 * ec);
+      for (int ec = 0; ec < NT; ++ec) {                         // the next X fragment is in flight during this one's MFMAs
+        const bf16x8 bn = tr8(ec + 1 < NT ? brow + 16 * (ec + 1) : b8row + 16 * min(wave, NT - 1));
 #pragma unroll
         for (int en = 0; en < NT; ++en) acc[en][ec] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[en], bh, acc[en][ec], 0, 0, 0);
+        bh = bn;
       }
+      if (wave < NT) {                                          // bh: column `wave` of the ninth tap's X fragments (a dummy read otherwise)
 #pragma unroll
-      for (int i = 0; i < EX; ++i)
-        accx[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(arow + 16 * xen[i]), tr8(b8row + 16 * xec[i]), accx[i], 0, 0, 0);
+        for (int en = 0; en < NT; ++en) accx[en] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[en], bh, accx[en], 0, 0, 0);
+      }
     }
-    if (c + 1 < c_end) store(nxt);
     __syncthreads();
   }
-  // ---- partial tiles: lane (fq, fr) element e of an MFMA tile (en, ec) is (n = 16 en + 4 fq + e, c = 16 ec + fr).
-  //      Everything the epilogue needs is derived again from the thread id: nothing of it occupies registers during the loop ----
+  // ---- partial tiles: lane (fq, fr) element e of an MFMA tile (en, ec) is (n = 16 en + 4 fq + e, c = 16 ec + fr); the
+  //      indices are derived again from the thread id (kept across the loop they spilled) ----
   int tid_e = threadIdx.x;
   asm volatile("" : "+v"(tid_e));
-  const int wave_e = __builtin_amdgcn_readfirstlane(tid_e >> 6), fr_e = tid_e & 15, fq_e = (tid_e >> 4) & 3;
-  const int PART = C * C + C;
+  const int fr_e = tid_e & 15, fq_e = (tid_e >> 4) & 3;
   {
-    float* const mypart = part + ((size_t)wave_e * ksplit + ks) * PART;
+    float* const mypart = part + ((size_t)wave * ksplit + ks) * PART;
 #pragma unroll
     for (int en = 0; en < NT; ++en)
 #pragma unroll
@@ -674,27 +695,22 @@ __global__ __launch_bounds__(WC9_THREADS) void wgrad_conv9_kernel(const WgradPar
           if (n < C && c < C) mypart[n * C + c] = acc[en][ec][e];
         }
       }
-    float* const part8 = part + ((size_t)8 * ksplit + ks) * PART;
+    if (wave < NT) {
+      float* const part8 = part + ((size_t)8 * ksplit + ks) * PART;
 #pragma unroll
-    for (int i = 0; i < EX; ++i) {
-      const int t = wave_e + 8 * i, ten = t / NT, tec = t - ten * NT;
-      if (t < NT * NT) {
+      for (int en = 0; en < NT; ++en)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int n = 16 * ten + 4 * fq_e + e, c = 16 * tec + fr_e;
-          if (n < C && c < C) part8[n * C + c] = accx[i][e];
+          const int n = 16 * en + 4 * fq_e + e, c = 16 * wave + fr_e;
+          if (n < C && c < C) part8[n * C + c] = accx[en][e];
         }
-      }
     }
   }
-  // ---- bias sums: the staging threads' float4, summed over the 4 nqy thread rows in fixed order ----
-  f32x4* const bs = reinterpret_cast<f32x4*>(wsm);
-  const int c4n_e = C >> 2, sch_e = tid_e % c4n_e, t2_e = tid_e / c4n_e, nqy_e = WC9_THREADS / (4 * c4n_e);
-  if ((t2_e >> 2) < nqy_e) bs[t2_e * c4n_e + sch_e] = bsum;
-  __syncthreads();
-  if (tid_e < c4n_e) {
+  __syncthreads();                                             // the loaders' bias sums are in LDS
+  if (tid_e < c4n) {
+    const f32x4* const bs = reinterpret_cast<const f32x4*>(wsm);
     f32x4 t = bs[tid_e];
-    for (int r = 1; r < 4 * nqy_e; ++r) t += bs[r * c4n_e + tid_e];
+    for (int r = 1; r < 4 * nqy; ++r) t += bs[r * c4n + tid_e];
     *reinterpret_cast<f32x4*>(part + (size_t)ks * PART + C * C + 4 * tid_e) = t;
   }
 }
@@ -975,7 +991,7 @@ int launch_wgrad_conv9(const WgradParams& p, WgradQueue& q, hipStream_t s) {
       SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       configured = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)ksplit), dim3(WC9_THREADS), lds, s, p, cpw, nchunks, ksplit, part);
+    hipLaunchKernelGGL(kern, dim3((unsigned)ksplit), dim3(WC9S_THREADS), lds, s, p, cpw, nchunks, ksplit, part);
     return SRAD_OK;
   };
   static bool cfg[6] = {false, false, false, false, false, false};
