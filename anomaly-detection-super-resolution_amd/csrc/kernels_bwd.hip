@@ -667,43 +667,42 @@ __global__ __launch_bounds__(WC9S_THREADS) void wgrad_conv9_kernel(const WgradPa
       for (int ec = 0; ec < NT; ++ec) {                         // the next X fragment is in flight during this one's MFMAs
         const bf16x8 bn = tr8(ec + 1 < NT ? brow + 16 * (ec + 1) : b8row + 16 * min(wave, NT - 1));
 #pragma unroll
-        for (int en = 0; en < NT; ++en) acc[en][ec] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[en], bh, acc[en][ec], 0, 0, 0);
+        for (int en = 0; en < NT; ++en) acc[en][ec] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[en], acc[en][ec], 0, 0, 0);
         bh = bn;
       }
       if (wave < NT) {                                          // bh: column `wave` of the ninth tap's X fragments (a dummy read otherwise)
 #pragma unroll
-        for (int en = 0; en < NT; ++en) accx[en] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[en], bh, accx[en], 0, 0, 0);
+        for (int en = 0; en < NT; ++en) accx[en] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[en], accx[en], 0, 0, 0);
       }
     }
     __syncthreads();
   }
-  // ---- partial tiles: lane (fq, fr) element e of an MFMA tile (en, ec) is (n = 16 en + 4 fq + e, c = 16 ec + fr); the
-  //      indices are derived again from the thread id (kept across the loop they spilled) ----
+  // ---- partial tiles.  The MFMAs compute the TRANSPOSED tiles (X fragment as the A operand): lane (fq, fr) holds the four
+  //      consecutive input channels c = 16 ec + 4 fq + 0..3 of output channel n = 16 en + fr - one float4 of the row-major
+  //      partial per tile (the other way round a lane holds four ROWS: 116 four-byte stores per lane instead of 30 float4; the
+  //      launch takes the same time either way, the stores are not what its ~13 us of fixed cost are).
+  //      The indices are derived again from the thread id (kept across the loop they spilled) ----
   int tid_e = threadIdx.x;
   asm volatile("" : "+v"(tid_e));
   const int fr_e = tid_e & 15, fq_e = (tid_e >> 4) & 3;
   {
     float* const mypart = part + ((size_t)wave * ksplit + ks) * PART;
 #pragma unroll
-    for (int en = 0; en < NT; ++en)
+    for (int en = 0; en < NT; ++en) {
+      const int n = 16 * en + fr_e;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int n = 16 * en + 4 * fq_e + e;
-#pragma unroll
-        for (int ec = 0; ec < NT; ++ec) {
-          const int c = 16 * ec + fr_e;
-          if (n < C && c < C) mypart[n * C + c] = acc[en][ec][e];
-        }
+      for (int ec = 0; ec < NT; ++ec) {
+        const int c = 16 * ec + 4 * fq_e;
+        if (n < C && c < C) *reinterpret_cast<f32x4*>(mypart + n * C + c) = acc[en][ec];
       }
+    }
     if (wave < NT) {
       float* const part8 = part + ((size_t)8 * ksplit + ks) * PART;
 #pragma unroll
-      for (int en = 0; en < NT; ++en)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int n = 16 * en + 4 * fq_e + e, c = 16 * wave + fr_e;
-          if (n < C && c < C) part8[n * C + c] = accx[en][e];
-        }
+      for (int en = 0; en < NT; ++en) {
+        const int n = 16 * en + fr_e, c = 16 * wave + 4 * fq_e;
+        if (n < C && c < C) *reinterpret_cast<f32x4*>(part8 + n * C + c) = accx[en];
+      }
     }
   }
   __syncthreads();                                             // the loaders' bias sums are in LDS
@@ -850,7 +849,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceBatc
   if (d.db != nullptr && cy == 0 && tap == 0 && tid < 16 && n0 + quarter * 16 + tid < d.n_real) {
     const float* bb = d.part + (size_t)tile_id * d.ksplit * WG_TS + 4096 + quarter * 16 + tid;
     float vb = 0.f;
-    for (int kk = 0; kk < d.ksplit; ++kk) vb += bb[(size_t)kk * WG_TS];
+    int kk = 0;
+    for (; kk + 8 <= d.ksplit; kk += 8) {                      // 8 loads in flight (one after the other they were the launch's tail)
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = bb[(size_t)(kk + u) * WG_TS];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) vb += t[u];
+    }
+    for (; kk < d.ksplit; ++kk) vb += bb[(size_t)kk * WG_TS];
     d.db[n0 + quarter * 16 + tid] += vb * d.alpha;
   }
 }
