@@ -770,7 +770,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceBatc
     const int col = (tile_id * 4 + quarter) * 16 + cl;
     const int cc = min(col, d.n_real - 1);
     float sum = 0.f;
-    for (int k = r; k < d.ksplit; k += 16) sum += d.part[(size_t)k * d.cin_real + cc];
+    int k = r;
+    for (; k + 112 < d.ksplit; k += 128) {                      // 8 loads in flight (512 partial rows of a LayerNorm: 32 loads per thread)
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = d.part[(size_t)(k + 16 * u) * d.cin_real + cc];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += t[u];
+    }
+    for (; k < d.ksplit; k += 16) sum += d.part[(size_t)k * d.cin_real + cc];
     red[r][cl] = sum;
     __syncthreads();
     if (threadIdx.x < 16 && col < d.n_real) {
