@@ -166,6 +166,25 @@ def test_cosine_schedule_matches_torch():
         sch.step()
 
 
+def test_adam_device_scalars_match_torch_bias_correction():
+    """TensorAdam.hyper / FusedAdam.hyper: the four scalars a captured step reads from the GPU ([lr, 1 - b1^t, sqrt(1 - b2^t),
+    grad_scale] of the NEXT step) are torch.optim.Adam's bias corrections (src/trainer.py:49-73 builds torch Adams)."""
+    import math
+    import struct
+    import torch
+    from srad_amd.train import TensorAdam
+    p = torch.nn.Parameter(torch.zeros(4))
+    opt = TensorAdam([p], lr=3e-4, betas=(0.9, 0.999))
+    for step in (0, 1, 9, 999):
+        opt.step_count = step
+        lr, c1, c2, gs = opt.hyper(grad_scale=0.5)
+        t = step + 1
+        assert lr == 3e-4 and gs == 0.5
+        b1, b2 = (struct.unpack("f", struct.pack("f", b))[0] for b in (0.9, 0.999))      # the betas as the C ABI passes them (fp32)
+        assert abs(c1 - (1 - b1 ** t)) < 1e-12 and abs(c2 - math.sqrt(1 - b2 ** t)) < 1e-12
+        assert abs(c1 - (1 - 0.9 ** t)) < 1e-5 and abs(c2 - math.sqrt(1 - 0.999 ** t)) < 1e-5
+
+
 def test_launch_plan_for_gpus_n():
     """``--gpus N`` without a launcher starts N ranks (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* on 127.0.0.1); under
     torch.distributed.run (WORLD_SIZE set) or with one GPU nothing is spawned."""
