@@ -103,6 +103,28 @@ def test_wgrad_conv3x3(dev, prec, B, H, W, Cin, Cout, stride):
     assert _rel(db, b.grad) < TOL[prec]
 
 
+def test_wgrad_conv3x3_strided_operands(dev):
+    """The nine-taps-per-workgroup kernel on operands that are column blocks of wider row-major buffers (DRN's [up | skip]
+    concatenation buffers: row stride 2 C; the gradient block starts at a column offset)."""
+    from srad_amd import ops
+    B, H, W, Cc = 2, 64, 64, 80
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, Cc, H, W, generator=g)
+    w = torch.randn(Cc, Cc, 3, 3, generator=g, requires_grad=True)
+    b = torch.zeros(Cc, requires_grad=True)
+    y = F.conv2d(x, w, b, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    x_wide = torch.randn(B * H * W, 2 * Cc, generator=g)
+    dy_wide = torch.randn(B * H * W, Cc + 8, generator=g)
+    x_wide[:, Cc:] = x.permute(0, 2, 3, 1).reshape(-1, Cc)
+    dy_wide[:, 4:4 + Cc] = dy.permute(0, 2, 3, 1).reshape(-1, Cc)
+    xd, dyd = x_wide.to(dev), dy_wide.to(dev)
+    dw, db = ops.wgrad(dyd[:, 4:4 + Cc], xd[:, Cc:], Cc, Cc, ntaps=9, B=B, H=H, W=W, precision="bf16")
+    assert _rel(dw.reshape(Cc, Cc, 3, 3), w.grad) < TOL["bf16"]
+    assert _rel(db, b.grad) < TOL["bf16"]
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_dgrad_linear_and_activation_modes(dev, prec):
     from srad_amd import ops
