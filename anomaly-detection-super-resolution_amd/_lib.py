@@ -11,7 +11,9 @@ LIB_PATH = os.path.join(_HERE, "libsrad.so")
 
 PREC_F32 = 0
 PREC_BF16 = 1
-PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": PREC_BF16, "bfloat16": PREC_BF16}
+PREC_BF16X3 = 2      # split-bf16: operands as hi + lo bf16 terms, three bf16 MFMAs per product, fp32-grade outputs (inference)
+PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": PREC_BF16, "bfloat16": PREC_BF16,
+              "bf16x3": PREC_BF16X3, "split-bf16": PREC_BF16X3}
 
 ACT_NONE, ACT_GELU, ACT_LRELU, ACT_RELU = 0, 1, 2, 3
 
@@ -124,9 +126,9 @@ _SIG = {
     "srad_bench_qkv_attn": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_size_t,
                                       C.c_int, C.POINTER(C.c_float), _P]),
     "srad_op_swin_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
-    "srad_op_qkv_attn": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P,
+    "srad_op_qkv_attn": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P,
                                    C.c_size_t, _P]),
-    "srad_op_mlp_block": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P,
+    "srad_op_mlp_block": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P,
                                     _P, _P, C.c_int, C.c_float, C.c_float, _P, C.c_int, _P, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "srad_op_gemm_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "srad_op_window_attn": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

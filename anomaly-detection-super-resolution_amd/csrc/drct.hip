@@ -90,7 +90,9 @@ int forward_body(srad_drct* h, const float* x, int B, int H, int W, float* y, co
       const SwinW& sw = h->blocks[i * 5 + k];
       const int d = sw.d;
       const int no = k < 4 ? c.gc : E;
-      // the attention output is handed to the fused second half as bf16 (what its MFMA rounds it to anyway: half the bytes)
+      // the attention output is handed to the fused second half as bf16 (what its MFMA rounds it to anyway: half the bytes);
+      // split-bf16: as fp32, both fused kernels with their lo weight packs
+      const bool x3 = prec == SRAD_PREC_BF16X3;
       const bool mlp_fused = h->fuse_mlp && srad_mlp_block_supported(prec, T, d, sw.hidden, no);
       __bf16* const attn_h = reinterpret_cast<__bf16*>(w.attn);
       if (h->fuse_mlp && srad_qkv_attn_supported(prec, c.window_size, H, W, d, sw.heads)) {
@@ -99,7 +101,8 @@ int forward_body(srad_drct* h, const float* x, int B, int H, int W, float* y, co
         QkvAttnParams a{};
         a.x = cur; a.ldx = D; a.ln_g = h->pt.fptr(sw.n1g); a.ln_b = h->pt.fptr(sw.n1b);
         a.w_qkv = h->pt.frag_ptr(sw.qkv.w); a.b_qkv = h->pt.fptr(sw.qkv.b); a.table = h->pt.fptr(sw.table);
-        a.out = w.attn; a.out_h = mlp_fused ? attn_h : nullptr; a.ld_out = d;
+        a.out = w.attn; a.out_h = mlp_fused && !x3 ? attn_h : nullptr; a.ld_out = d;
+        a.split = x3; a.w_qkv_lo = h->pt.frag_lo_ptr(sw.qkv.w);
         a.B = B; a.H = H; a.W = W; a.shift = sw.shift; a.d = d; a.heads = sw.heads;
         a.no_xcd_map = srad_no_xcd_map();
         SRAD_TRY(srad_launch_qkv_attn(a, s));
@@ -127,7 +130,7 @@ int forward_body(srad_drct* h, const float* x, int B, int H, int W, float* y, co
         {
           AttnParams a{w.qkv, w.attn, h->pt.fptr(sw.table), B, H, W, c.window_size, sw.shift, d, sw.heads,
                        hdp_of(d, sw.heads)};
-          if (mlp_fused) a.out_h = attn_h;
+          if (mlp_fused && !x3) a.out_h = attn_h;
           if (qkv_bf16) a.qkv_h = reinterpret_cast<const __bf16*>(w.qkv);
           SRAD_TRY(srad_launch_window_attn(prec, a, s));
         }
@@ -137,6 +140,9 @@ int forward_body(srad_drct* h, const float* x, int B, int H, int W, float* y, co
         // (drct.py:300, 509-510, 184-190, 389-396)
         MlpBlockParams q{};
         q.attn_h = attn_h; q.ld_attn = d; q.shortcut = cur; q.ld_short = D;
+        q.split = x3; q.attn_f = w.attn;
+        q.w_proj_lo = h->pt.frag_lo_ptr(sw.proj.w); q.w_fc1_lo = h->pt.frag_lo_ptr(sw.fc1.w); q.w_fc2_lo = h->pt.frag_lo_ptr(sw.fc2.w);
+        q.w_adj_lo = h->pt.frag_lo_ptr(sw.adjust.w);
         q.M = T; q.d = d; q.m = sw.hidden; q.no = no;
         q.w_proj = h->pt.frag_ptr(sw.proj.w); q.w_fc1 = h->pt.frag_ptr(sw.fc1.w); q.w_fc2 = h->pt.frag_ptr(sw.fc2.w);
         q.w_adj = h->pt.frag_ptr(sw.adjust.w);
@@ -231,7 +237,8 @@ int srad_drct_create(const srad_drct_config* cfg, srad_drct_t** out) {
   SRAD_REQUIRE(cfg->window_size >= 1 && cfg->window_size <= 128, "drct_create: window_size %d out of range", cfg->window_size);
   SRAD_REQUIRE(cfg->embed_dim > 0 && cfg->embed_dim % 4 == 0 && cfg->gc % 4 == 0, "drct_create: embed_dim/gc must be multiples of 4");
   SRAD_REQUIRE(cfg->embed_dim % cfg->num_heads == 0, "drct_create: embed_dim %d not divisible by num_heads %d", cfg->embed_dim, cfg->num_heads);
-  SRAD_REQUIRE(cfg->precision == SRAD_PREC_F32 || cfg->precision == SRAD_PREC_BF16, "drct_create: bad precision %d", cfg->precision);
+  SRAD_REQUIRE(cfg->precision == SRAD_PREC_F32 || cfg->precision == SRAD_PREC_BF16 || cfg->precision == SRAD_PREC_BF16X3,
+               "drct_create: bad precision %d", cfg->precision);
   srad_drct* h = new (std::nothrow) srad_drct();
   if (!h) return srad_set_error(SRAD_ERR_NOMEM, "drct_create: out of host memory");
   h->cfg = *cfg;
@@ -259,8 +266,8 @@ int srad_drct_create(const srad_drct_config* cfg, srad_drct_t** out) {
       sw.table = h->pt.add_raw(p + "attn.relative_position_bias_table", (int64_t)(2 * ws - 1) * (2 * ws - 1) * sw.heads);
       sw.qkv = h->pt.add_layer(p + "attn.qkv", 3 * sw.d, sw.d, 1, true);
       if (cfg->precision == SRAD_PREC_BF16) h->pt.entries[sw.qkv.w].tfrag = true;   // operand of the fused qkv + LayerNorm1 backward
-      if (cfg->precision == SRAD_PREC_BF16 && sw.d % sw.heads == 0) h->pt.add_qkv_frag(sw.qkv, sw.d, sw.heads);   // fused attention kernel
-      const bool frag = cfg->precision == SRAD_PREC_BF16;      // operands of the fused second half (kernels_fused.hip)
+      const bool frag = cfg->precision == SRAD_PREC_BF16 || cfg->precision == SRAD_PREC_BF16X3;   // operands of the fused block kernels
+      if (frag && sw.d % sw.heads == 0) h->pt.add_qkv_frag(sw.qkv, sw.d, sw.heads);   // fused attention kernel
       sw.proj = frag ? h->pt.add_layer_frag(p + "attn.proj", sw.d, sw.d, true) : h->pt.add_layer(p + "attn.proj", sw.d, sw.d, 1, true);
       sw.n2g = h->pt.add_raw(p + "norm2.weight", sw.d);
       sw.n2b = h->pt.add_raw(p + "norm2.bias", sw.d);

@@ -488,7 +488,8 @@ int srad_drn_create(const srad_drn_config* cfg, srad_drn_t** out) {
                "drn_create: n_feats must be even (got %d): levels >= 1 then hold multiples of 4 channels and only "
                "level 0 is zero-padded to one", cfg->n_feats);
   SRAD_REQUIRE(cfg->n_blocks > 0, "drn_create: n_blocks must be positive");
-  SRAD_REQUIRE(cfg->precision == SRAD_PREC_F32 || cfg->precision == SRAD_PREC_BF16, "drn_create: bad precision %d", cfg->precision);
+  SRAD_REQUIRE(cfg->precision == SRAD_PREC_F32 || cfg->precision == SRAD_PREC_BF16 || cfg->precision == SRAD_PREC_BF16X3,
+               "drn_create: bad precision %d", cfg->precision);
   srad_drn* h = new (std::nothrow) srad_drn();
   if (!h) return srad_set_error(SRAD_ERR_NOMEM, "drn_create: out of host memory");
   h->cfg = *cfg;

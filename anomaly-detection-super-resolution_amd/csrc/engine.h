@@ -16,6 +16,7 @@ struct ParamEntry {
   long long frag_off = -1;                    // >= 0: second copy as bf16 MFMA fragments (srad_launch_pack_weight_frag)
   bool tfrag = false;                         // training: keep W^T as bf16 MFMA fragments too (fused backward kernels)
   int qkv_heads = 0;                          // > 0: frag_off holds the per-head [q | k | v] fragment pack (srad_launch_pack_qkv_frag)
+  long long frag_lo_off = -1;                 // >= 0 (split-bf16): the lo terms of the fragment pack at frag_off, same geometry
 };
 
 struct ConvW {       // one Linear / conv layer
@@ -80,6 +81,10 @@ struct ParamTable {
     ConvW c = add_layer(prefix, n, cin, 1, bias);
     entries[c.w].frag_off = (long long)bytes;
     bytes += srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, n, cin, 1), 256);
+    if (prec == SRAD_PREC_BF16X3) {
+      entries[c.w].frag_lo_off = (long long)bytes;
+      bytes += srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, n, cin, 1), 256);
+    }
     return c;
   }
   // qkv Linear of a Swin block that is also kept as per-head fragments (the fused attention kernel's operand)
@@ -87,9 +92,14 @@ struct ParamTable {
     entries[c.w].frag_off = (long long)bytes;
     entries[c.w].qkv_heads = heads;
     bytes += srad_align_up(srad_qkv_frag_bytes(d, heads), 256);
+    if (prec == SRAD_PREC_BF16X3) {
+      entries[c.w].frag_lo_off = (long long)bytes;
+      bytes += srad_align_up(srad_qkv_frag_bytes(d, heads), 256);
+    }
   }
   const void* ptr(int idx) const { return idx < 0 ? nullptr : arena + entries[idx].off; }
   const void* frag_ptr(int idx) const { return idx < 0 || entries[idx].frag_off < 0 ? nullptr : arena + entries[idx].frag_off; }
+  const void* frag_lo_ptr(int idx) const { return idx < 0 || entries[idx].frag_lo_off < 0 ? nullptr : arena + entries[idx].frag_lo_off; }
   const float* fptr(int idx) const { return reinterpret_cast<const float*>(ptr(idx)); }
 
   int set(const char* name, const float* src, int64_t numel, hipStream_t s) {
@@ -103,6 +113,8 @@ struct ParamTable {
     if (e.packed) {
       if (e.frag_off >= 0 && e.qkv_heads > 0) SRAD_TRY(srad_launch_pack_qkv_frag(src, arena + e.frag_off, e.cin, e.qkv_heads, s));
       else if (e.frag_off >= 0) SRAD_TRY(srad_launch_pack_weight_frag(src, arena + e.frag_off, e.n, e.cin, s));
+      if (e.frag_lo_off >= 0 && e.qkv_heads > 0) SRAD_TRY(srad_launch_pack_qkv_frag_lo(src, arena + e.frag_lo_off, e.cin, e.qkv_heads, s));
+      else if (e.frag_lo_off >= 0) SRAD_TRY(srad_launch_pack_weight_frag_lo(src, arena + e.frag_lo_off, e.n, e.cin, s));
       return srad_launch_pack_weight_padded(prec, src, arena + e.off, e.n, e.cin, e.ntaps, e.n_pad > 0 ? e.n_pad : e.n, e.grp_real, e.grp_pad, s);
     }
     if (e.n_pad > numel) SRAD_CHECK_HIP(hipMemsetAsync(arena + e.off, 0, (size_t)e.n_pad * 4, s));

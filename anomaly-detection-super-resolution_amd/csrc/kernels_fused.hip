@@ -59,14 +59,20 @@ __device__ __forceinline__ float gelu_fast(float x) {
 // matrices, so at 65536 tokens 16-row tiles move 4096 x 0.5 MB per launch through L2).
 // KCD / KCM = 32-wide k chunks of the block dim / hidden (exact: a stage loads and multiplies only its real chunks; a
 // run-time chunk count meant duplicate loads of chunk 0 or branches around the loads, both measured slower).
-template <int FM, int GD, int KGD, int GM, int KGM, int GN, int KCD, int KCM, bool STAMP = false>
+// SPLIT = the split-bf16 mode (SRAD_PREC_BF16X3, inference): both activation tiles exist as a hi and a lo bf16 plane, every
+// weight stage streams twice (hi pack, then lo pack: "half stages" through the same register sets) and a product is
+// W_hi.A_hi + W_hi.A_lo + W_lo.A_hi; the attention output comes in as fp32.  Nothing else changes - same stages, same epilogues.
+template <int FM, int GD, int KGD, int GM, int KGM, int GN, int KCD, int KCM, bool STAMP = false, bool SPLIT = false>
 __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) {
   static_assert(KGD == (KCD + 7) / 8 && KGM == (KCM + 7) / 8, "k groups are 8 chunks wide");
+  static_assert(!SPLIT || (FM <= 32 && !STAMP), "split-bf16: 16 / 32-row tiles (two planes of each tile in LDS)");
   constexpr int NRT = FM / 16;       // 16-row MFMA tiles per workgroup
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* A1 = reinterpret_cast<__bf16*>(smem);                  // [FM][F_LDA] attn tile -> LN2(x1) -> x2
   __bf16* Hs = A1 + FM * F_LDA;                                  // [FM][F_LDH] GELU(fc1)
-  float* vec = reinterpret_cast<float*>(Hs + FM * F_LDH);        // b_proj | b_fc1 | b_fc2 | b_adj | gamma | beta
+  __bf16* A1L = Hs + FM * F_LDH;                                 // split-bf16: the lo planes of the two tiles
+  __bf16* HsL = A1L + FM * F_LDA;
+  float* vec = reinterpret_cast<float*>(SPLIT ? HsL + FM * F_LDH : Hs + FM * F_LDH);   // b_proj | b_fc1 | b_fc2 | b_adj | gamma | beta
   float* red = vec + F_NV;                                       // [FM][8 waves][2] LayerNorm partial sums
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -91,6 +97,8 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
   constexpr int Kd = KCD * 32, Km = KCM * 32;                    // packed K of the weights
   constexpr int n_proj = GD * KGD, n_fc1 = GM * KGD, n_fc2 = GD * KGM, n_adj = GN * KGD;
   constexpr int n_stages = n_proj + n_fc1 + n_fc2 + n_adj;
+  constexpr int NPART = SPLIT ? 2 : 1;                           // weight streams per stage (hi | hi, lo)
+  constexpr int n_vst = n_stages * NPART;                        // (stage, part) pairs in stream order
   // offsets of the staged vectors
   float* const v_bp = vec; float* const v_b1 = vec + 384; float* const v_b2 = vec + 896; float* const v_ba = vec + 1280;
   float* const v_g = vec + 1664; float* const v_b = vec + 2048;
@@ -115,11 +123,14 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
   // 8 waves (two per SIMD), each owns 16 output columns of a 128-column stage, i.e. 16 rows of the packed weight that
   // NOBODY else reads: the weights go straight from global memory into MFMA fragment registers, three stages ahead (no
   // LDS stage, no barrier per stage), from the fragment-major pack (one contiguous kilobyte per wave load).
-  constexpr int NSETS = FM == 16 ? SRAD_MLP_NSETS16 : 3;   // 16-row tiles leave ~100 VGPRs free at 2 waves per SIMD: deeper weight stream
+  constexpr int NSETS = SPLIT ? 4 : (FM == 16 ? SRAD_MLP_NSETS16 : 3);   // 16-row tiles leave ~100 VGPRs free at 2 waves per SIMD: deeper weight stream
   u32x4 w_reg[NSETS][8];
   auto load_w = [&](auto S, u32x4 (&reg)[8]) __attribute__((always_inline)) {
-    constexpr StageGeo sg = geo(decltype(S)::value);
-    const char* w = (const char*)(sg.ph == 0 ? p.w_proj : (sg.ph == 1 ? p.w_fc1 : (sg.ph == 2 ? p.w_fc2 : p.w_adj)));
+    constexpr int vs = decltype(S)::value < n_vst - 1 ? decltype(S)::value : n_vst - 1;
+    constexpr StageGeo sg = geo(vs / NPART);
+    constexpr bool lo = (vs % NPART) == 1;
+    const char* w = lo ? (const char*)(sg.ph == 0 ? p.w_proj_lo : (sg.ph == 1 ? p.w_fc1_lo : (sg.ph == 2 ? p.w_fc2_lo : p.w_adj_lo)))
+                       : (const char*)(sg.ph == 0 ? p.w_proj : (sg.ph == 1 ? p.w_fc1 : (sg.ph == 2 ? p.w_fc2 : p.w_adj)));
     const int nreal = sg.ph == 0 ? d : (sg.ph == 1 ? m : (sg.ph == 2 ? d : no));
     // fragment-major pack: 1 KB tiles (16 rows x 32 k), tile (n / 16, k / 32); this wave's row tile is g * 8 + wave;
     // lane: row fr, k 8 fq .. of the tile - the 64 lanes cover its 1 KB
@@ -134,12 +145,24 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     for (int cc = 0; cc < sg.nch; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + cc * step);
   };
   // c[rt] += (A[16 rows][k0 .. k0 + nch*32) . W[16 columns of this wave][..]^T)^T
-  auto mma_stage = [&](const __bf16* A, int lda, int k0, int nch, const u32x4 (&reg)[8], f32x4 (&c)[NRT]) __attribute__((always_inline)) {
+  // (split-bf16: `reg` holds the hi weights and both planes of A are multiplied - AL = the lo plane -, or the lo weights
+  // against the hi plane only: AL = null)
+  auto mma_stage = [&](const __bf16* A, const __bf16* AL, int lda, int k0, int nch, const u32x4 (&reg)[8], f32x4 (&c)[NRT]) __attribute__((always_inline)) {
     const __bf16* ar = A + fr * lda + k0 + 8 * fq;
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
       if (cc < nch) {
         const bf16x8 b0 = __builtin_bit_cast(bf16x8, reg[cc]);
+        if constexpr (SPLIT) {
+          if (AL) {
+            const __bf16* al = AL + fr * lda + k0 + 8 * fq;
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) {
+              const bf16x8 a = *reinterpret_cast<const bf16x8*>(al + rt * 16 * lda + cc * 32);
+              c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, c[rt], 0, 0, 0);
+            }
+          }
+        }
         // operands swapped (W as the MFMA "A", activations as "B"): the result tile is transposed, so a lane
         // holds 4 CONSECUTIVE OUTPUT COLUMNS (4*fq + e) of one token row (fr) - exactly the k-contiguous
         // quad the next GEMM's A operand, the bias/residual vectors and the global store want.
@@ -159,12 +182,17 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
   constexpr int NAQ = 32 * GD;                                    // float4 per row of the attn tile actually needed
   constexpr int NAJ = FM * NAQ / 512;                             // float4 per thread
   static_assert(FM * NAQ % 512 == 0, "attn tile must divide over the workgroup");
-  u32x2 a_reg[NAJ];                                               // four bf16 columns each
+  u32x2 a_reg[SPLIT ? 1 : NAJ];                                   // four bf16 columns each
+  f32x4 a_regf[SPLIT ? NAJ : 1];                                  // split-bf16: the fp32 attention output
 #pragma unroll
   for (int j = 0; j < NAJ; ++j) {
     const int idx = tid + 512 * j, row = idx / NAQ, c = (idx - row * NAQ) * 4;
-    a_reg[j] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(p.attn_h) + (size_t)(m0 + row) * p.ld_attn * 2 +
-                                               (unsigned)min(c, d - 4) * 2u);
+    if constexpr (SPLIT)
+      a_regf[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.attn_f) + (size_t)(m0 + row) * p.ld_attn * 4 +
+                                                  (unsigned)min(c, d - 4) * 4u);
+    else
+      a_reg[j] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(p.attn_h) + (size_t)(m0 + row) * p.ld_attn * 2 +
+                                                 (unsigned)min(c, d - 4) * 2u);
   }
   // accumulator layout of this lane: token row 16*rt + fr, columns 128*g + 16*wave + 4*fq + (0..3)
   f32x4 x1[GD][NRT];
@@ -216,7 +244,14 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
 #pragma unroll
     for (int j = 0; j < NAJ; ++j) {
       const int idx = tid + 512 * j, row = idx / NAQ, c = (idx - row * NAQ) * 4;
-      *reinterpret_cast<u32x2*>(A1 + row * F_LDA + c) = c < d ? a_reg[j] : u32x2{0u, 0u};
+      if constexpr (SPLIT) {
+        bf16x4 hh, ll;
+        srad_split4(c < d ? a_regf[j] : f32x4{0.f, 0.f, 0.f, 0.f}, hh, ll);
+        *reinterpret_cast<bf16x4*>(A1 + row * F_LDA + c) = hh;
+        *reinterpret_cast<bf16x4*>(A1L + row * F_LDA + c) = ll;
+      } else {
+        *reinterpret_cast<u32x2*>(A1 + row * F_LDA + c) = c < d ? a_reg[j] : u32x2{0u, 0u};
+      }
     }
   }
   static_for<1, NSETS>([&](auto Q) { load_w(Q, w_reg[decltype(Q)::value]); });   // the rest of the look-ahead, behind the tile
@@ -227,7 +262,13 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
   // weight gradient reads ([M][gld])
   auto store_bf4 = [&](__bf16* base, int ld, int rt, int c4, f32x4 v, __bf16* gsave = nullptr, int gld = 0, bool real = false) __attribute__((always_inline)) {
     bf16x4 h;
-    h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+    if constexpr (SPLIT) {                                           // hi plane here, lo plane at the same place of the tile's twin
+      bf16x4 l;
+      srad_split4(v, h, l);
+      *reinterpret_cast<bf16x4*>((base == A1 ? A1L : HsL) + (rt * 16 + fr) * ld + c4) = l;
+    } else {
+      h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+    }
     *reinterpret_cast<bf16x4*>(base + (rt * 16 + fr) * ld + c4) = h;
     if (gsave && real) *reinterpret_cast<bf16x4*>(gsave + (size_t)(m0 + rt * 16 + fr) * gld + c4) = h;
   };
@@ -366,39 +407,41 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
 
   // ---- all weight stages, unrolled at compile time over the register sets ----
   f32x4 c[NRT];
-  static_for<0, n_stages>([&](auto S) {
-    constexpr int s = decltype(S)::value;
+  static_for<0, n_vst>([&](auto S) {
+    constexpr int vs = decltype(S)::value;
+    constexpr int s = vs / NPART, part = vs % NPART;               // split-bf16: part 0 = hi weights, 1 = lo weights
     constexpr int ph = s < n_proj ? 0 : (s < n_proj + n_fc1 ? 1 : (s < n_proj + n_fc1 + n_fc2 ? 2 : 3));
     constexpr int ls = s - (ph == 0 ? 0 : (ph == 1 ? n_proj : (ph == 2 ? n_proj + n_fc1 : n_proj + n_fc1 + n_fc2)));
     constexpr int kgs = ph == 2 ? KGM : KGD;
     constexpr int g = ls / kgs, kg = ls - g * kgs;
-    u32x4 (&reg)[8] = w_reg[s % NSETS];
+    u32x4 (&reg)[8] = w_reg[vs % NSETS];
     constexpr int Kp = ph == 2 ? Km : Kd;
     constexpr int nch = (Kp >> 5) - kg * 8 < 8 ? (Kp >> 5) - kg * 8 : 8;
-    if constexpr (ls == 0) {
+    if constexpr (ls == 0 && part == 0) {
       stamp(3 + 3 * ph);                               // this wave's previous phase (its epilogue included) is done
       __syncthreads();                                 // first stage of a phase: the activation tile (A1 / Hs) and,
                                                        // at s == 0, the staged vectors written before are visible
       stamp(4 + 3 * ph);
     }
-    if constexpr (kg == 0) {
+    if constexpr (kg == 0 && part == 0) {
 #pragma unroll
       for (int rt = 0; rt < NRT; ++rt) c[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const bool live = (g * 8 + wave_s) * 16 < (ph == 0 ? d : (ph == 1 ? m : (ph == 2 ? d : no)));
-    if (!(dbg & 2) && live) mma_stage(ph == 2 ? Hs : A1, ph == 2 ? F_LDH : F_LDA, kg * 256, nch, reg, c);
+    if (!(dbg & 2) && live)
+      mma_stage(ph == 2 ? Hs : A1, (SPLIT && part == 0) ? (ph == 2 ? HsL : A1L) : nullptr, ph == 2 ? F_LDH : F_LDA, kg * 256, nch, reg, c);
     // refill this set, NSETS stages ahead.  Issuing a load can block (the queue is full while the weights stream), so where
     // an epilogue follows that other waves wait for (LayerNorm2, the tile hand-overs) the refill goes behind it
-    constexpr bool epi_first = kg == kgs - 1;
-    if constexpr (!epi_first) { if (!(dbg & 1)) load_w(std::integral_constant<int, s + NSETS>{}, reg); }
-    if constexpr (kg == kgs - 1 && g == (ph == 0 ? GD : (ph == 1 ? GM : (ph == 2 ? GD : GN))) - 1) stamp(5 + 3 * ph);   // last MFMAs of the phase issued
-    if (!(dbg & 16)) if constexpr (kg == kgs - 1) {
+    constexpr bool epi_first = kg == kgs - 1 && part == NPART - 1;
+    if constexpr (!epi_first) { if (!(dbg & 1)) load_w(std::integral_constant<int, vs + NSETS>{}, reg); }
+    if constexpr (epi_first && g == (ph == 0 ? GD : (ph == 1 ? GM : (ph == 2 ? GD : GN))) - 1) stamp(5 + 3 * ph);   // last MFMAs of the phase issued
+    if (!(dbg & 16)) if constexpr (epi_first) {
       if constexpr (ph == 0) epi_proj(std::integral_constant<int, g>{}, c);
       else if constexpr (ph == 1) epi_fc1(g, c);
       else if constexpr (ph == 2) epi_fc2(std::integral_constant<int, g>{}, c);
       else epi_adj(g, c);
     }
-    if constexpr (epi_first) { if (!(dbg & 1)) load_w(std::integral_constant<int, s + NSETS>{}, reg); }
+    if constexpr (epi_first) { if (!(dbg & 1)) load_w(std::integral_constant<int, vs + NSETS>{}, reg); }
   });
   stamp(15);
 }
@@ -408,10 +451,10 @@ inline FusedCfg fused_cfg(int d, int m, int no) {
   const int Kd = srad_cp(d), Km = srad_cp(m);
   return FusedCfg{(d + F_SC - 1) / F_SC, (Kd + 255) / 256, (m + F_SC - 1) / F_SC, (Km + 255) / 256, (no + F_SC - 1) / F_SC, Kd / 32, Km / 32};
 }
-template <int FM, int GD, int KGD, int GM, int KGM, int GN, int KCD, int KCM, bool STAMP = false>
+template <int FM, int GD, int KGD, int GM, int KGM, int GN, int KCD, int KCM, bool STAMP = false, bool SPLIT = false>
 int launch_mlp_fm(const MlpBlockParams& p, hipStream_t stream) {
-  constexpr size_t lds = (size_t)(FM * F_LDA + FM * F_LDH) * 2 + (F_NV + FM * 16) * sizeof(float);
-  auto kern = mlp_block_kernel<FM, GD, KGD, GM, KGM, GN, KCD, KCM, STAMP>;
+  constexpr size_t lds = (size_t)(FM * F_LDA + FM * F_LDH) * 2 * (SPLIT ? 2 : 1) + (F_NV + FM * 16) * sizeof(float);
+  auto kern = mlp_block_kernel<FM, GD, KGD, GM, KGM, GN, KCD, KCM, STAMP, SPLIT>;
   static bool configured = false;
   if (!configured) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -426,6 +469,10 @@ int launch_mlp_fm(const MlpBlockParams& p, hipStream_t stream) {
 }
 template <int GD, int KGD, int GM, int KGM, int GN, int KCD, int KCM>
 int launch_mlp(const MlpBlockParams& p, hipStream_t stream) {
+  if (p.split) {                                                  // split-bf16: 32-row tiles once every CU still gets a workgroup
+    if ((p.fm == 32 || (p.fm == 0 && p.M >= 8192)) && p.M % 32 == 0) return launch_mlp_fm<32, GD, KGD, GM, KGM, GN, KCD, KCM, false, true>(p, stream);
+    return launch_mlp_fm<16, GD, KGD, GM, KGM, GN, KCD, KCM, false, true>(p, stream);
+  }
   // 16-row tiles until there are enough tokens to fill the chip several times with 64-row tiles
   if (p.fm == 64 && p.M % 64 == 0) return launch_mlp_fm<64, GD, KGD, GM, KGM, GN, KCD, KCM>(p, stream);
   if (p.fm == 32 && p.M % 32 == 0) return launch_mlp_fm<32, GD, KGD, GM, KGM, GN, KCD, KCM>(p, stream);
@@ -441,7 +488,7 @@ int launch_mlp(const MlpBlockParams& p, hipStream_t stream) {
 }  // namespace
 
 bool srad_mlp_block_supported(int prec, int M, int d, int m, int no) {
-  if (!(prec == SRAD_PREC_BF16 && M % 16 == 0 && d % 4 == 0 && m % 4 == 0 && no % 4 == 0 && d >= 32 && d <= 384 && m >= 32 &&
+  if (!((prec == SRAD_PREC_BF16 || prec == SRAD_PREC_BF16X3) && M % 16 == 0 && d % 4 == 0 && m % 4 == 0 && no % 4 == 0 && d >= 32 && d <= 384 && m >= 32 &&
         m <= 512 && no >= 4 && no <= 384))
     return false;
   const FusedCfg c = fused_cfg(d, m, no);
@@ -453,6 +500,13 @@ bool srad_mlp_block_supported(int prec, int M, int d, int m, int no) {
 
 int srad_launch_mlp_block(const MlpBlockParams& p, hipStream_t stream) {
   SRAD_REQUIRE(srad_mlp_block_supported(SRAD_PREC_BF16, p.M, p.d, p.m, p.no), "mlp_block: unsupported shape M=%d d=%d m=%d no=%d", p.M, p.d, p.m, p.no);
+  if (p.split) {
+    SRAD_REQUIRE(p.attn_f && (p.ld_attn & 3) == 0 && ((uintptr_t)p.attn_f & 15) == 0, "mlp_block (split-bf16): the fp32 attn rows must be float4-addressable");
+    SRAD_REQUIRE(p.w_proj_lo && p.w_fc1_lo && p.w_fc2_lo && p.w_adj_lo, "mlp_block (split-bf16): the lo weight packs are missing");
+    SRAD_REQUIRE(p.fm == 0 || p.fm == 16 || p.fm == 32, "mlp_block (split-bf16): 16 or 32 rows per workgroup");
+    SRAD_REQUIRE(!p.stamps && !p.rs1 && !p.rs2 && !p.save_x1 && !p.save_xn2 && !p.save_hpre && !p.save_hact && !p.save_x2 && !p.save_hpre_h &&
+                     !p.save_xn2_h && !p.save_hact_h && !p.save_x2_h, "mlp_block (split-bf16): inference only");
+  } else
   SRAD_REQUIRE((p.ld_attn & 3) == 0 && ((uintptr_t)p.attn_h & 7) == 0, "mlp_block: the bf16 attn rows must be 8-byte addressable");
   SRAD_REQUIRE((p.ld_short & 3) == 0 && ((uintptr_t)p.shortcut & 15) == 0 && (p.ldy & 3) == 0 && (p.yoff & 3) == 0 &&
                    ((uintptr_t)p.Y & 15) == 0 && (!p.R || ((p.ldr & 3) == 0 && ((uintptr_t)p.R & 15) == 0)),

@@ -28,7 +28,12 @@ constexpr int QA_LDP = 72;     // probability tile row stride
 constexpr int QA_LDB = 68;     // bias table row stride (floats): the 16 keys a float4 read group touches fall on 16 different bank quads
 
 // HDT = ceil(head_dim / 16) (2, 3, 4, 5 or 8), KC = ceil(d / 32) 32-wide k chunks (<= 10)
-template <int HDT, int KC, bool STAMP = false>
+// SPLIT = the split-bf16 mode (SRAD_PREC_BF16X3, inference): the normalised window, q, k, v and the probabilities each exist as a
+// hi and a lo bf16 plane, the weights stream twice (hi pack, lo pack) and every product is three MFMAs (hi.hi + hi.lo + lo.hi).
+// Two planes of everything do not fit next to each other (head dim 122: 208 KB), so q | k | v and P OVERLAY the normalised
+// window: a wave keeps its q | k | v accumulators of all (<= 3) column stages in registers until every wave is done reading
+// the window (one more barrier), then writes them.  The output is fp32.
+template <int HDT, int KC, bool STAMP = false, bool SPLIT = false>
 __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
   constexpr int KG = (KC + 7) / 8;         // 256-wide k groups per weight stage
   constexpr int QA_LDX = KC * 32 + 8;      // LDS row stride of the normalised window tile
@@ -38,11 +43,18 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
   constexpr int NV = 3 * HDP;              // virtual output columns [q | k | v]
   constexpr int NS = (NV + 127) / 128;     // 128-column stages: each of the 8 waves owns 16 of them
   constexpr int n_stages = NS * KG;
+  constexpr int NPART = SPLIT ? 2 : 1;                          // weight streams per stage (hi | hi, lo)
+  constexpr int n_vst = n_stages * NPART;
+  constexpr int XN_E = 64 * QA_LDX, QKV_E = 3 * 64 * HS, PS_E = 64 * QA_LDP;     // bf16 elements per plane
+  constexpr int R0_E = SPLIT ? (2 * XN_E > 2 * (QKV_E + PS_E) ? 2 * XN_E : 2 * (QKV_E + PS_E)) : XN_E + QKV_E + PS_E;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* XN = reinterpret_cast<__bf16*>(smem);                 // [64][QA_LDX]
-  __bf16* QKV = XN + 64 * QA_LDX;                               // [3][64][HS]
-  __bf16* Ps = QKV + 3 * 64 * HS;                               // [64][QA_LDP] probabilities
-  float* v_g = reinterpret_cast<float*>(Ps + 64 * QA_LDP);      // [320] gamma
+  __bf16* XNL = XN + XN_E;                                      // split-bf16: its lo plane
+  __bf16* QKV = SPLIT ? XN : XN + XN_E;                         // [3][64][HS] (split-bf16: over the window tile, see above)
+  __bf16* QKVL = QKV + QKV_E;
+  __bf16* Ps = SPLIT ? QKVL + QKV_E : QKV + QKV_E;              // [64][QA_LDP] probabilities
+  __bf16* PsL = Ps + PS_E;
+  float* v_g = reinterpret_cast<float*>(XN + R0_E);             // [320] gamma
   float* v_b = v_g + 320;                                       // [320] beta
   float* v_bias = v_b + 320;                                    // [3][HDP] q|k|v bias of this head (0 in padding)
   float* tbl = v_bias + 3 * HDP;                                // [225] relative position bias of this head
@@ -106,15 +118,18 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
   //      from global memory into MFMA operand registers, three stages ahead: no LDS weight stage, no barrier per stage (as in
   //      mlp_block_kernel).  The loads are unconditional - a load inside a branch makes hipcc's wait-count pass drain every
   //      older load at the join; a wave without columns in a stage reads one 16-byte word per load instead. ----
-  constexpr int NSETS = 3;
+  constexpr int NSETS = SPLIT ? 4 : 3;
   u32x4 w_reg[NSETS][8];
   const char* const Wh = reinterpret_cast<const char*>(p.w_qkv) + (size_t)h * (NV / 16) * KC * 1024;
+  const char* const Wl = reinterpret_cast<const char*>(SPLIT ? p.w_qkv_lo : p.w_qkv) + (size_t)h * (NV / 16) * KC * 1024;
   auto load_w = [&](auto S, u32x4 (&reg)[8]) {
-    constexpr int sc = decltype(S)::value < n_stages - 1 ? decltype(S)::value : n_stages - 1;
+    constexpr int vs = decltype(S)::value < n_vst - 1 ? decltype(S)::value : n_vst - 1;
+    constexpr int sc = vs / NPART;
     constexpr int st = sc / KG, kg = sc - st * KG;
     constexpr int nch = KC - kg * 8 < 8 ? KC - kg * 8 : 8;
     const bool live = (st * 8 + wave_s) * 16 < NV;
-    const char* base = live ? Wh + ((size_t)(st * 8 + wave) * KC + kg * 8) * 1024 + fr * 64 + fq * 16 : Wh;
+    const char* const Wp = (vs % NPART) == 1 ? Wl : Wh;
+    const char* base = live ? Wp + ((size_t)(st * 8 + wave) * KC + kg * 8) * 1024 + fr * 64 + fq * 16 : Wp;
     const int step = live ? 1024 : 0;
 #pragma unroll
     for (int cc = 0; cc < nch; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + cc * step);
@@ -149,11 +164,15 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
     const int e = lane + 64 * q;
     if (e < v_cnt) v_g[v_dst + e] = e < v_n ? vq[q] : 0.f;        // bias entries of the padded head columns are 0
   }
-  if constexpr (HDP32 != HDP) {
-    // head dims padded to 48 / 80: the last 32-wide k step of q.k^T also covers 16 columns no epilogue writes
-    const int row = tid >> 2, part = tid & 3;                     // 128 (q and k) rows x 4 quads of 4 columns
-    *reinterpret_cast<bf16x4*>(QKV + row * HS + HDP + 4 * part) = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-  }
+  auto zero_qk_pad = [&]() {
+    if constexpr (HDP32 != HDP) {
+      // head dims padded to 48 / 80: the last 32-wide k step of q.k^T also covers 16 columns no epilogue writes
+      const int row = tid >> 2, part = tid & 3;                   // 128 (q and k) rows x 4 quads of 4 columns
+      *reinterpret_cast<bf16x4*>(QKV + row * HS + HDP + 4 * part) = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+      if constexpr (SPLIT) *reinterpret_cast<bf16x4*>(QKVL + row * HS + HDP + 4 * part) = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+    }
+  };
+  if constexpr (!SPLIT) zero_qk_pad();                            // (split-bf16: q | k | v overlay the window tile - after the GEMM)
 
   stamp(2);                                                       // vectors staged
   // ---- LayerNorm1 from the registers (the 8 lanes of a row hold all its columns) -> bf16 -> XN ----
@@ -196,7 +215,13 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
       const f32x4 v = c < d ? (a_reg[j] - mu) * rstd * g4 + b4 : f32x4{0.f, 0.f, 0.f, 0.f};
       if (p.save_xn && h == 0 && c < d) *reinterpret_cast<f32x4*>(p.save_xn + (size_t)my_tok * d + c) = v;
       bf16x4 hh;
-      hh[0] = (__bf16)v[0]; hh[1] = (__bf16)v[1]; hh[2] = (__bf16)v[2]; hh[3] = (__bf16)v[3];
+      if constexpr (SPLIT) {
+        bf16x4 ll;
+        srad_split4(v, hh, ll);
+        *reinterpret_cast<bf16x4*>(XNL + xrow * QA_LDX + c) = ll;
+      } else {
+        hh[0] = (__bf16)v[0]; hh[1] = (__bf16)v[1]; hh[2] = (__bf16)v[2]; hh[3] = (__bf16)v[3];
+      }
       if (p.save_xn_h && h == 0 && c < d) *reinterpret_cast<bf16x4*>(p.save_xn_h + (size_t)my_tok * d + c) = hh;
       *reinterpret_cast<bf16x4*>(XN + xrow * QA_LDX + c) = hh;
     }
@@ -208,51 +233,77 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
   stamp(7);
 
   // ---- q|k|v = xn . W^T : 128 virtual columns per stage, transposed result (lane: token fr of row tile t, 4 columns) ----
-  f32x4 acc[4];
-  static_for<0, n_stages>([&](auto S) {
-    constexpr int s = decltype(S)::value;
+  f32x4 acc[SPLIT ? NS : 1][4];
+  // bias, the attention's scale on q, zero padding -> the bf16 tile(s) the attention reads (and the training saves)
+  auto epi_qkv = [&](auto ST, const f32x4 (&a4)[4]) __attribute__((always_inline)) {
+    constexpr int st = decltype(ST)::value;
+    const bool live = (st * 8 + wave_s) * 16 < NV;
+    if (live) {
+      const int vc = (st * 8 + wave) * 16 + 4 * fq;               // virtual column of element 0
+      const int which = vc / HDP, c = vc - which * HDP;           // HDP % 16 == 0: the wave's 16 columns stay in one slice
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(v_bias + which * HDP + c);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f32x4 v = a4[t] + bias;
+        if (p.save_qkv && c < p.hdp)
+          *reinterpret_cast<f32x4*>(p.save_qkv + (size_t)tok[t * 16 + fr] * (3 * heads * p.hdp) + (which * heads + h) * p.hdp + c) = v;
+        if (which == 0) v = v * scale;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = c + e < hd ? v[e] : 0.f;
+        bf16x4 hh;
+        if constexpr (SPLIT) {
+          bf16x4 ll;
+          srad_split4(v, hh, ll);
+          *reinterpret_cast<bf16x4*>(QKVL + (which * 64 + t * 16 + fr) * HS + c) = ll;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hh[e] = (__bf16)v[e];
+        }
+        *reinterpret_cast<bf16x4*>(QKV + (which * 64 + t * 16 + fr) * HS + c) = hh;
+        if (p.save_qkv_h && c < p.hp_h)
+          *reinterpret_cast<bf16x4*>(p.save_qkv_h + (size_t)tok[t * 16 + fr] * (3 * heads * p.hp_h) + (which * heads + h) * p.hp_h + c) = hh;
+      }
+    }
+  };
+  static_for<0, n_vst>([&](auto S) {
+    constexpr int vs = decltype(S)::value;
+    constexpr int s = vs / NPART, part = vs % NPART;              // split-bf16: part 0 = hi weights, 1 = lo weights
     constexpr int st = s / KG, kg = s - st * KG;
-    u32x4 (&reg)[8] = w_reg[s % NSETS];
+    u32x4 (&reg)[8] = w_reg[vs % NSETS];
+    f32x4 (&ac)[4] = acc[SPLIT ? st : 0];
     constexpr int nch = KC - kg * 8 < 8 ? KC - kg * 8 : 8;
     const bool live = (st * 8 + wave_s) * 16 < NV;
-    if constexpr (kg == 0) {
+    if constexpr (kg == 0 && part == 0) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < 4; ++t) ac[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (live) {
       const __bf16* ar = XN + fr * QA_LDX + kg * 256 + 8 * fq;
 #pragma unroll
       for (int cc = 0; cc < nch; ++cc) {
         const bf16x8 b0 = __builtin_bit_cast(bf16x8, reg[cc]);
+        if constexpr (SPLIT && part == 0) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + XN_E + t * 16 * QA_LDX + cc * 32);
+            ac[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, ac[t], 0, 0, 0);
+          }
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + t * 16 * QA_LDX + cc * 32);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, acc[t], 0, 0, 0);
+          ac[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, ac[t], 0, 0, 0);
         }
       }
     }
-    load_w(std::integral_constant<int, s + NSETS>{}, reg);
-    if constexpr (kg == KG - 1) {
-      if (live) {
-        const int vc = (st * 8 + wave) * 16 + 4 * fq;             // virtual column of element 0
-        const int which = vc / HDP, c = vc - which * HDP;         // HDP % 16 == 0: the wave's 16 columns stay in one slice
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(v_bias + which * HDP + c);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          f32x4 v = acc[t] + bias;
-          if (p.save_qkv && c < p.hdp)
-            *reinterpret_cast<f32x4*>(p.save_qkv + (size_t)tok[t * 16 + fr] * (3 * heads * p.hdp) + (which * heads + h) * p.hdp + c) = v;
-          if (which == 0) v = v * scale;
-          bf16x4 hh;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) hh[e] = (__bf16)(c + e < hd ? v[e] : 0.f);
-          *reinterpret_cast<bf16x4*>(QKV + (which * 64 + t * 16 + fr) * HS + c) = hh;
-          if (p.save_qkv_h && c < p.hp_h)
-            *reinterpret_cast<bf16x4*>(p.save_qkv_h + (size_t)tok[t * 16 + fr] * (3 * heads * p.hp_h) + (which * heads + h) * p.hp_h + c) = hh;
-        }
-      }
-    }
+    load_w(std::integral_constant<int, vs + NSETS>{}, reg);
+    if constexpr (!SPLIT && kg == KG - 1) epi_qkv(std::integral_constant<int, st>{}, ac);
   });
+  if constexpr (SPLIT) {
+    __syncthreads();                                              // every wave is done reading the window tile: q | k | v go over it
+    zero_qk_pad();
+    static_for<0, NS>([&](auto ST) { epi_qkv(ST, acc[decltype(ST)::value]); });
+  }
   stamp(8);                                                       // this wave's q | k | v columns done
   __syncthreads();                                                // q, k, v complete
   stamp(9);
@@ -271,9 +322,16 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
 #pragma unroll
     for (int kk = 0; kk < HDP32; kk += 32) {
       const bf16x8 a = *reinterpret_cast<const bf16x8*>(Qs + (rt * 16 + fr) * HS + kk + 8 * fq);
+      [[maybe_unused]] bf16x8 al;
+      if constexpr (SPLIT) al = *reinterpret_cast<const bf16x8*>(Qs + QKV_E + (rt * 16 + fr) * HS + kk + 8 * fq);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const bf16x8 bb = *reinterpret_cast<const bf16x8*>(Ks + ((2 * kh + j) * 16 + fr) * HS + kk + 8 * fq);
+        if constexpr (SPLIT) {
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Ks + QKV_E + ((2 * kh + j) * 16 + fr) * HS + kk + 8 * fq);
+          sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bb, sc[j], 0, 0, 0);
+          sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bl, sc[j], 0, 0, 0);
+        }
         sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, sc[j], 0, 0, 0);
       }
     }
@@ -294,8 +352,13 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
       const float p0 = __expf(sc[0][e] - m), p1 = __expf(sc[1][e] - m);
       const float rs = srad_row16_sum(p0 + p1);
       if (fr == 0) lsum[kh * 64 + row] = rs;
-      Ps[row * QA_LDP + (2 * kh) * 16 + fr] = (__bf16)p0;
-      Ps[row * QA_LDP + (2 * kh + 1) * 16 + fr] = (__bf16)p1;
+      const __bf16 p0h = (__bf16)p0, p1h = (__bf16)p1;
+      Ps[row * QA_LDP + (2 * kh) * 16 + fr] = p0h;
+      Ps[row * QA_LDP + (2 * kh + 1) * 16 + fr] = p1h;
+      if constexpr (SPLIT) {
+        PsL[row * QA_LDP + (2 * kh) * 16 + fr] = (__bf16)(p0 - (float)p0h);
+        PsL[row * QA_LDP + (2 * kh + 1) * 16 + fr] = (__bf16)(p1 - (float)p1h);
+      }
     }
   }
   stamp(10);                                                      // scores + softmax
@@ -319,6 +382,16 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
         bf16x8 vb;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { vb[e] = lo[e]; vb[4 + e] = hi[e]; }
+        if constexpr (SPLIT) {                                      // v_lo . p_hi and v_hi . p_lo first (the small terms)
+          const bf16x4 llo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0 + QKV_E));
+          const bf16x4 lhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0 + QKV_E + 4 * HS));
+          bf16x8 vl;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { vl[e] = llo[e]; vl[4 + e] = lhi[e]; }
+          const bf16x8 pl = *reinterpret_cast<const bf16x8*>(PsL + (rt * 16 + fr) * QA_LDP + kk + 8 * fq);
+          o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, pa, o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb, pl, o, 0, 0, 0);
+        }
         o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb, pa, o, 0, 0, 0);
       }
       const int row = rt * 16 + fr;
@@ -343,12 +416,14 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
   stamp(15);
 }
 
-template <int HDT, int KC, bool STAMP = false>
+template <int HDT, int KC, bool STAMP = false, bool SPLIT = false>
 int launch_qa(const QkvAttnParams& p, hipStream_t stream) {
   constexpr int HDP = 16 * HDT, HS = ((HDP + 31) & ~31) + 8;
-  constexpr size_t lds = (size_t)(64 * (KC * 32 + 8) + 3 * 64 * HS + 64 * QA_LDP) * 2 +
+  constexpr int XN_E = 64 * (KC * 32 + 8), QP_E = 3 * 64 * HS + 64 * QA_LDP;
+  constexpr size_t lds = (size_t)(SPLIT ? 2 * (XN_E > QP_E ? XN_E : QP_E) : XN_E + QP_E) * 2 +
                          (size_t)(640 + 3 * HDP + 232 + 256 + 64 * QA_LDB) * sizeof(float) + 128 * sizeof(int);
-  auto kern = qkv_attn_kernel<HDT, KC, STAMP>;
+  static_assert(lds <= 160 * 1024, "qkv_attn: LDS budget");
+  auto kern = qkv_attn_kernel<HDT, KC, STAMP, SPLIT>;
   static bool configured = false;
   if (!configured) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -557,7 +632,7 @@ int srad_launch_ln_qkv(const LnQkvParams& p, hipStream_t stream) {
 }
 
 bool srad_qkv_attn_supported(int prec, int ws, int H, int W, int d, int heads) {
-  if (prec != SRAD_PREC_BF16 || ws != 8 || H % 8 || W % 8 || d % 4 || d > 320 || d < 32 || heads < 1 || d % heads) return false;
+  if ((prec != SRAD_PREC_BF16 && prec != SRAD_PREC_BF16X3) || ws != 8 || H % 8 || W % 8 || d % 4 || d > 320 || d < 32 || heads < 1 || d % heads) return false;
   const int hdt = (d / heads + 15) / 16, kc = (d + 31) / 32;
 #define X(a, b) if (hdt == a && kc == b) return true;
   SRAD_QA_CFGS(X)
@@ -570,6 +645,13 @@ int srad_launch_qkv_attn(const QkvAttnParams& p, hipStream_t stream) {
   SRAD_REQUIRE((p.ldx & 3) == 0 && ((uintptr_t)p.x & 15) == 0, "qkv_attn: x rows must be float4-addressable");
   SRAD_REQUIRE(p.shift >= 0 && p.shift < 8, "qkv_attn: shift %d must be in [0, 8)", p.shift);
   const int hdt = (p.d / p.heads + 15) / 16, kc = (p.d + 31) / 32;
+  if (p.split) {                                                  // split-bf16 (inference)
+    SRAD_REQUIRE(p.w_qkv_lo && p.out && !p.out_h, "qkv_attn (split-bf16): needs the lo weight pack and an fp32 output");
+    SRAD_REQUIRE(!p.stamps && !p.save_xn && !p.save_xn_h && !p.save_qkv && !p.save_qkv_h, "qkv_attn (split-bf16): inference only");
+#define X(a, b) if (hdt == a && kc == b) return launch_qa<a, b, false, true>(p, stream);
+    SRAD_QA_CFGS(X)
+#undef X
+  }
   if (p.stamps) {                                                 // diagnostic build
 #define X(a, b) if (hdt == a && kc == b) return launch_qa<a, b, true>(p, stream);
     SRAD_QA_CFGS(X)

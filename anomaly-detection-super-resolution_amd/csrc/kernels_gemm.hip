@@ -9,6 +9,8 @@
 // issued before the current chunk's MFMAs (register-staged prefetch).
 //   BF16 mode: v_mfma_f32_16x16x32_bf16, fp32 accumulate.
 //   F32  mode: v_mfma_f32_16x16x4_f32 (exact fp32 fma chain) - the parity mode.
+//   BF16X3 mode: split-bf16 - A and W staged as hi + lo bf16 planes, three bf16 MFMAs per product (hi.hi + hi.lo + lo.hi),
+//                fp32 accumulate: fp32-grade results at the bf16 pipe's rate (srad_common.h).
 #include "srad_common.h"
 #include <stdlib.h>
 
@@ -17,6 +19,7 @@ namespace {
 template <int PREC> struct PrecT;
 template <> struct PrecT<SRAD_PREC_BF16> { using type = __bf16; static constexpr int PAD = 8; };
 template <> struct PrecT<SRAD_PREC_F32>  { using type = float;  static constexpr int PAD = 4; };
+template <> struct PrecT<SRAD_PREC_BF16X3> { using type = __bf16; static constexpr int PAD = 8; };   // two planes (hi, lo) of this type
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // d/dx of the exact-erf GELU: Phi(x) + x * phi(x)
@@ -51,6 +54,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   constexpr int RPT = BM / 32;                       // A rows staged per thread
   constexpr int CPA = LN ? CPS + (PREC == SRAD_PREC_BF16 ? 2 : 6) : CPS;   // LN: the whole K (<= 320) stays resident
   using T = typename PrecT<PREC>::type;
+  constexpr bool X3 = PREC == SRAD_PREC_BF16X3;
   constexpr int PADE = PrecT<PREC>::PAD;
   constexpr int STA = CPA * 32 + PADE;               // LDS row stride of A (elements)
   constexpr int STW = CPS * 32 + PADE;               // LDS row stride of W
@@ -61,7 +65,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* As = reinterpret_cast<T*>(smem);
   T* Ws = As + BM * STA;
-  float* s_g = reinterpret_cast<float*>(Ws + BN * STW);   // LN only: [CPA*32] gamma, [CPA*32] beta
+  T* AsL = Ws + BN * STW;                                  // split-bf16: the lo planes of both tiles
+  T* WsL = AsL + BM * STA;
+  float* s_g = reinterpret_cast<float*>(X3 ? WsL + BN * STW : Ws + BN * STW);   // LN only: [CPA*32] gamma, [CPA*32] beta
   float* s_b = s_g + CPA * 32;
 
   const int tid = threadIdx.x;
@@ -126,6 +132,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   constexpr int W_PT = BN / WRP;                              // rows tid/SEGS + WRP*j, segment tid%SEGS
   static_assert(W_PT * WRP == BN, "W rows must divide over the threads");
   u32x4 w_reg[W_PT];
+  [[maybe_unused]] u32x4 w_lo[X3 ? W_PT : 1];
+  const size_t w_lo_off = (size_t)((p.N + 127) / 128 * 128) * Kp * 2;   // split-bf16: hi plane -> lo plane of the pack (srad_packed_lo_offset)
   const int w_seg = tid % SEGS;
   const unsigned w_off0 = (unsigned)((tid / SEGS) * Kp) * (unsigned)sizeof(T);
   const char* const Wb = reinterpret_cast<const char*>(p.Wp) + (size_t)n0 * Kp * sizeof(T);
@@ -176,6 +184,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < W_PT; ++j)
       w_reg[j] = *reinterpret_cast<const u32x4*>(wb + (size_t)j * WRP * Kp * sizeof(T) + woff);
+    if constexpr (X3) {
+#pragma unroll
+      for (int j = 0; j < W_PT; ++j)
+        w_lo[j] = *reinterpret_cast<const u32x4*>(wb + w_lo_off + (size_t)j * WRP * Kp * sizeof(T) + woff);
+    }
   };
   [[maybe_unused]] float ln_mu[RPT], ln_rs[RPT];
   auto store_a = [&]() {
@@ -197,7 +210,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
           v = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         T* dst = As + row * STA + j * 32 + col4 * 4;
-        if constexpr (PREC == SRAD_PREC_BF16) {
+        if constexpr (X3) {
+          bf16x4 h, l;
+          srad_split4(v, h, l);
+          *reinterpret_cast<bf16x4*>(dst) = h;
+          *reinterpret_cast<bf16x4*>(AsL + row * STA + j * 32 + col4 * 4) = l;
+        } else if constexpr (PREC == SRAD_PREC_BF16) {
           bf16x4 h;
           h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
           *reinterpret_cast<bf16x4*>(dst) = h;
@@ -211,6 +229,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     char* wdst = reinterpret_cast<char*>(Ws) + ((tid / SEGS) * STW) * (int)sizeof(T) + w_seg * 16;
 #pragma unroll
     for (int j = 0; j < W_PT; ++j) *reinterpret_cast<u32x4*>(wdst + j * WRP * STW * (int)sizeof(T)) = w_reg[j];
+    if constexpr (X3) {
+      char* ldst = reinterpret_cast<char*>(WsL) + ((tid / SEGS) * STW) * (int)sizeof(T) + w_seg * 16;
+#pragma unroll
+      for (int j = 0; j < W_PT; ++j) *reinterpret_cast<u32x4*>(ldst + j * WRP * STW * (int)sizeof(T)) = w_lo[j];
+    }
   };
 
   // ---- issue every independent load now: first A/W stage, LN gamma/beta, bias, residual ----
@@ -276,8 +299,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const T* const a_rd = As + (wm0 + fr) * STA + (PREC == SRAD_PREC_BF16 ? 8 : 4) * fq;
-  const T* const w_rd = Ws + (wn0 + fr) * STW + (PREC == SRAD_PREC_BF16 ? 8 : 4) * fq;
+  const T* const a_rd = As + (wm0 + fr) * STA + (PREC != SRAD_PREC_F32 ? 8 : 4) * fq;
+  const T* const w_rd = Ws + (wn0 + fr) * STW + (PREC != SRAD_PREC_F32 ? 8 : 4) * fq;
 
   for (int st = 0; st < nstages; ++st) {
     if (!LN || st == 0) store_a();
@@ -292,7 +315,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int cc = 0; cc < CPS; ++cc) {
       if (cc < nch) {
-        if constexpr (PREC == SRAD_PREC_BF16) {
+        if constexpr (X3) {
+          bf16x8 a[MT], al[MT], b[NT], bl[NT];
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            a[i] = *reinterpret_cast<const bf16x8*>(a_st + i * 16 * STA + cc * 32);
+            al[i] = *reinterpret_cast<const bf16x8*>(a_st + (AsL - As) + i * 16 * STA + cc * 32);
+          }
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            b[j] = *reinterpret_cast<const bf16x8*>(w_rd + j * 16 * STW + cc * 32);
+            bl[j] = *reinterpret_cast<const bf16x8*>(w_rd + (WsL - Ws) + j * 16 * STW + cc * 32);
+          }
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], b[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else if constexpr (PREC == SRAD_PREC_BF16) {
           bf16x8 a[MT], b[NT];
 #pragma unroll
           for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const bf16x8*>(a_st + i * 16 * STA + cc * 32);
@@ -457,10 +500,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 // Optional channel-group padding: the destination channels are groups of grp_pad of which the first
 // grp_real are real (dst channel c <- src channel (c / grp_pad) * grp_real + c % grp_pad), and rows
 // n >= N are zero - how DRN's 10-channel level is widened to 12 for the float4 kernels. ----
+// one packed element: bf16 / fp32, or (split-bf16) the hi term here and the lo term `total` elements further on
+template <int PREC>
+__device__ __forceinline__ void pack_store(void* dst, size_t i, size_t total, float v) {
+  if constexpr (PREC == SRAD_PREC_F32) reinterpret_cast<float*>(dst)[i] = v;
+  else {
+    const __bf16 h = (__bf16)v;
+    reinterpret_cast<__bf16*>(dst)[i] = h;
+    if constexpr (PREC == SRAD_PREC_BF16X3) reinterpret_cast<__bf16*>(dst)[total + i] = (__bf16)(v - (float)h);
+  }
+}
+
 template <int PREC>
 __global__ void pack_weight_kernel(const float* __restrict__ src, void* __restrict__ dst, int N, int Cin,
                                    int ntaps, int Np, int Cp, int grp_real, int grp_pad) {
-  using T = typename PrecT<PREC>::type;
   const size_t total = (size_t)Np * ntaps * Cp;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % Cp);
@@ -473,7 +526,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, void* __restri
     }
     float v = 0.f;
     if (n < N && sc >= 0 && sc < Cin) v = src[((size_t)n * Cin + sc) * ntaps + tap];
-    reinterpret_cast<T*>(dst)[i] = (T)v;
+    pack_store<PREC>(dst, i, total, v);
   }
 }
 
@@ -481,7 +534,6 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, void* __restri
 template <int PREC>
 __global__ void pack_weight_t_kernel(const float* __restrict__ src, void* __restrict__ dst, int N, int Cin, int ntaps,
                                      int Rp, int Kp) {
-  using T = typename PrecT<PREC>::type;
   const size_t total = (size_t)Rp * ntaps * Kp;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int n = (int)(i % Kp);
@@ -489,13 +541,19 @@ __global__ void pack_weight_t_kernel(const float* __restrict__ src, void* __rest
     const int c = (int)(i / ((size_t)Kp * ntaps));
     float v = 0.f;
     if (n < N && c < Cin) v = src[((size_t)n * Cin + c) * ntaps + (ntaps - 1 - tap)];
-    reinterpret_cast<T*>(dst)[i] = (T)v;
+    pack_store<PREC>(dst, i, total, v);
   }
 }
 
 // Fragment-major bf16 pack for kernels that feed MFMA operands straight from global memory (kernels_fused.hip):
 // 16-row x 32-k tiles, tile (n / 16, k / 32) is 1 KB contiguous, row-major inside - exactly the 64 lanes x 16 bytes
 // of one v_mfma_f32_16x16x32_bf16 operand, so a wave's fragment load is one fully coalesced request.
+// LO: write the lo terms bf16(w - float(bf16(w))) instead (the split-bf16 kernels' second weight stream)
+__device__ __forceinline__ __bf16 frag_term(float v, bool lo) {
+  const __bf16 h = (__bf16)v;
+  return lo ? (__bf16)(v - (float)h) : h;
+}
+template <bool LO>
 __global__ void pack_weight_frag_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int N, int Cin, int Np, int Kp,
                                         int sn, int sk) {
   const size_t total = (size_t)Np * Kp;
@@ -505,10 +563,11 @@ __global__ void pack_weight_frag_kernel(const float* __restrict__ src, __bf16* _
     const size_t tile = i >> 9;
     const int kt = (int)(tile % ktiles), nt = (int)(tile / ktiles);
     const int n = nt * 16 + rin, k = kt * 32 + kin;
-    dst[i] = (__bf16)((n < N && k < Cin) ? src[(size_t)n * sn + (size_t)k * sk] : 0.f);
+    dst[i] = frag_term((n < N && k < Cin) ? src[(size_t)n * sn + (size_t)k * sk] : 0.f, LO);
   }
 }
 
+template <bool LO>
 __global__ void pack_qkv_frag_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int d, int heads, int hd, int HDP, int Kp) {
   const size_t total = (size_t)heads * 3 * HDP * Kp;
   const int ktiles = Kp / 32, rtiles = 3 * HDP / 16;
@@ -519,7 +578,7 @@ __global__ void pack_qkv_frag_kernel(const float* __restrict__ src, __bf16* __re
     const int rg = (int)(tile / ktiles);
     const int h = rg / rtiles, vr = (rg - h * rtiles) * 16 + rin;
     const int which = vr / HDP, c = vr - which * HDP, k = kt * 32 + kin;
-    dst[i] = (__bf16)((c < hd && k < d) ? src[(size_t)(which * d + h * hd + c) * d + k] : 0.f);
+    dst[i] = frag_term((c < hd && k < d) ? src[(size_t)(which * d + h * hd + c) * d + k] : 0.f, LO);
   }
 }
 
@@ -528,7 +587,8 @@ int launch_one(const GemmParams& p, hipStream_t s) {
   constexpr int CPS = CPS_ ? CPS_ : (PREC == SRAD_PREC_BF16 ? 8 : 4);
   constexpr int CPA = LN ? CPS + (PREC == SRAD_PREC_BF16 ? 2 : 6) : CPS;
   using T = typename PrecT<PREC>::type;
-  constexpr size_t lds = ((size_t)BM * (CPA * 32 + PrecT<PREC>::PAD) + (size_t)BN * (CPS * 32 + PrecT<PREC>::PAD)) * sizeof(T) +
+  constexpr size_t lds = ((size_t)BM * (CPA * 32 + PrecT<PREC>::PAD) + (size_t)BN * (CPS * 32 + PrecT<PREC>::PAD)) * sizeof(T) *
+                             (PREC == SRAD_PREC_BF16X3 ? 2 : 1) +
                          (LN ? 2 * (size_t)CPA * 32 * sizeof(float) : 0);
   auto kern = gemm_kernel<PREC, BM, BN, WMV, WNV, CPS, LN, CONV, SPECIAL>;
   static bool configured = false;
@@ -540,7 +600,7 @@ int launch_one(const GemmParams& p, hipStream_t s) {
   const int cls = BN >= 64 ? SRAD_K_GEMM_BN64 : (BN == 32 ? SRAD_K_GEMM_BN32 : SRAD_K_GEMM_BN16);
   // algorithmic work: 2*M*N*K flops; bytes = A rows once + packed W once + Y once (+ residual)
   const double K = (double)p.ntaps * p.Cin;
-  const double wbytes = (double)p.N * K * (PREC == SRAD_PREC_BF16 ? 2 : 4);
+  const double wbytes = (double)p.N * K * (PREC == SRAD_PREC_BF16 ? 2 : 4);   // (split-bf16: two bf16 planes)
   const double abytes = 4.0 * (p.ntaps == 9 ? (double)p.M * p.stride * p.stride : (double)p.M) * p.Cin;
   SradProfScope prof(s, cls, 2.0 * p.M * p.N * K, abytes + wbytes + 4.0 * p.M * p.N * (p.R ? 2 : 1));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
@@ -631,7 +691,8 @@ int srad_launch_gemm(int prec, const GemmParams& p, hipStream_t stream) {
     SRAD_REQUIRE(p.Ho > 0 && p.Wo > 0 && p.M % (p.Ho * p.Wo) == 0, "gemm: M=%d not a multiple of Ho*Wo=%d*%d", p.M, p.Ho, p.Wo);
   if (srad_conv80_supported(prec, p)) return srad_launch_conv80(p, stream);
   SRAD_REQUIRE(!p.Xh && (!p.Yh || p.hsplit_hd > 0), "gemm: bf16 activations in / out are the 80-channel conv kernel's (srad_conv80_supported)");
-  int rc = prec == SRAD_PREC_BF16 ? launch_prec<SRAD_PREC_BF16>(p, stream) : launch_prec<SRAD_PREC_F32>(p, stream);
+  int rc = prec == SRAD_PREC_BF16 ? launch_prec<SRAD_PREC_BF16>(p, stream)
+           : prec == SRAD_PREC_BF16X3 ? launch_prec<SRAD_PREC_BF16X3>(p, stream) : launch_prec<SRAD_PREC_F32>(p, stream);
   if (rc) return rc;
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
@@ -648,6 +709,8 @@ int srad_launch_pack_weight_padded(int prec, const float* src, void* dst, int n,
   SradProfScope prof(stream, SRAD_K_PACK, 0.0, 4.0 * n * cin * ntaps + (prec == SRAD_PREC_BF16 ? 2.0 : 4.0) * total);
   if (prec == SRAD_PREC_BF16)
     hipLaunchKernelGGL((pack_weight_kernel<SRAD_PREC_BF16>), dim3(blocks), dim3(256), 0, stream, src, dst, n, cin, ntaps, Np, Cp, grp_real, grp_pad);
+  else if (prec == SRAD_PREC_BF16X3)
+    hipLaunchKernelGGL((pack_weight_kernel<SRAD_PREC_BF16X3>), dim3(blocks), dim3(256), 0, stream, src, dst, n, cin, ntaps, Np, Cp, grp_real, grp_pad);
   else
     hipLaunchKernelGGL((pack_weight_kernel<SRAD_PREC_F32>), dim3(blocks), dim3(256), 0, stream, src, dst, n, cin, ntaps, Np, Cp, grp_real, grp_pad);
   SRAD_CHECK_HIP(hipGetLastError());
@@ -667,21 +730,26 @@ int srad_launch_pack_weight_transposed(int prec, const float* src, void* dst, in
   SradProfScope prof(stream, SRAD_K_PACK, 0.0, 4.0 * n * cin * ntaps + (prec == SRAD_PREC_BF16 ? 2.0 : 4.0) * total);
   if (prec == SRAD_PREC_BF16)
     hipLaunchKernelGGL((pack_weight_t_kernel<SRAD_PREC_BF16>), dim3(blocks), dim3(256), 0, stream, src, dst, n, cin, ntaps, Rp, Kp);
+  else if (prec == SRAD_PREC_BF16X3)
+    hipLaunchKernelGGL((pack_weight_t_kernel<SRAD_PREC_BF16X3>), dim3(blocks), dim3(256), 0, stream, src, dst, n, cin, ntaps, Rp, Kp);
   else
     hipLaunchKernelGGL((pack_weight_t_kernel<SRAD_PREC_F32>), dim3(blocks), dim3(256), 0, stream, src, dst, n, cin, ntaps, Rp, Kp);
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
 }
 
-int srad_launch_pack_weight_frag(const float* src, void* dst, int n, int cin, hipStream_t stream) {
+static int pack_frag(const float* src, void* dst, int n, int cin, bool lo, hipStream_t stream) {
   const int Np = srad_np(n), Kp = srad_cp(cin);
   const size_t total = (size_t)Np * Kp;
   const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
   SradProfScope prof(stream, SRAD_K_PACK, 0.0, 4.0 * n * cin + 2.0 * total);
-  hipLaunchKernelGGL(pack_weight_frag_kernel, dim3(blocks), dim3(256), 0, stream, src, reinterpret_cast<__bf16*>(dst), n, cin, Np, Kp, cin, 1);
+  if (lo) hipLaunchKernelGGL(pack_weight_frag_kernel<true>, dim3(blocks), dim3(256), 0, stream, src, reinterpret_cast<__bf16*>(dst), n, cin, Np, Kp, cin, 1);
+  else hipLaunchKernelGGL(pack_weight_frag_kernel<false>, dim3(blocks), dim3(256), 0, stream, src, reinterpret_cast<__bf16*>(dst), n, cin, Np, Kp, cin, 1);
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
 }
+int srad_launch_pack_weight_frag(const float* src, void* dst, int n, int cin, hipStream_t stream) { return pack_frag(src, dst, n, cin, false, stream); }
+int srad_launch_pack_weight_frag_lo(const float* src, void* dst, int n, int cin, hipStream_t stream) { return pack_frag(src, dst, n, cin, true, stream); }
 
 // the fragment-major pack of W^T (rows = input channels, k = output channels) from the same [n][cin] source
 int srad_launch_pack_weight_frag_t(const float* src, void* dst, int n, int cin, hipStream_t stream) {
@@ -689,17 +757,20 @@ int srad_launch_pack_weight_frag_t(const float* src, void* dst, int n, int cin, 
   const size_t total = (size_t)Np * Kp;
   const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
   SradProfScope prof(stream, SRAD_K_PACK, 0.0, 4.0 * n * cin + 2.0 * total);
-  hipLaunchKernelGGL(pack_weight_frag_kernel, dim3(blocks), dim3(256), 0, stream, src, reinterpret_cast<__bf16*>(dst), cin, n, Np, Kp, 1, cin);
+  hipLaunchKernelGGL(pack_weight_frag_kernel<false>, dim3(blocks), dim3(256), 0, stream, src, reinterpret_cast<__bf16*>(dst), cin, n, Np, Kp, 1, cin);
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
 }
 
-int srad_launch_pack_qkv_frag(const float* src, void* dst, int d, int heads, hipStream_t stream) {
+static int pack_qkv(const float* src, void* dst, int d, int heads, bool lo, hipStream_t stream) {
   const int hd = d / heads, HDP = srad_qkv_hdp(d, heads), Kp = srad_cp(d);
   const size_t total = (size_t)heads * 3 * HDP * Kp;
   const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
   SradProfScope prof(stream, SRAD_K_PACK, 0.0, 12.0 * d * d + 2.0 * total);
-  hipLaunchKernelGGL(pack_qkv_frag_kernel, dim3(blocks), dim3(256), 0, stream, src, reinterpret_cast<__bf16*>(dst), d, heads, hd, HDP, Kp);
+  if (lo) hipLaunchKernelGGL(pack_qkv_frag_kernel<true>, dim3(blocks), dim3(256), 0, stream, src, reinterpret_cast<__bf16*>(dst), d, heads, hd, HDP, Kp);
+  else hipLaunchKernelGGL(pack_qkv_frag_kernel<false>, dim3(blocks), dim3(256), 0, stream, src, reinterpret_cast<__bf16*>(dst), d, heads, hd, HDP, Kp);
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
 }
+int srad_launch_pack_qkv_frag(const float* src, void* dst, int d, int heads, hipStream_t stream) { return pack_qkv(src, dst, d, heads, false, stream); }
+int srad_launch_pack_qkv_frag_lo(const float* src, void* dst, int d, int heads, hipStream_t stream) { return pack_qkv(src, dst, d, heads, true, stream); }

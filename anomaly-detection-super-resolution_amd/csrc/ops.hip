@@ -120,6 +120,17 @@ int srad_bench_mlp_block(int M, int d, int m, int no, const void* attn /* bf16 [
   q.b_proj = q.b_fc1 = q.b_fc2 = q.b_adj = q.ln_g = q.ln_b = w_fp32;
   q.act = SRAD_ACT_LRELU; q.slope = 0.2f; q.alpha = 1.f; q.R = nullptr; q.ldr = 0; q.Y = y; q.ldy = 320; q.yoff = 0; q.dbg = dbg & 0xff;
   q.fm = (dbg >> 8) & 0xff;                         // bits 8..15: rows per workgroup (0 = auto)
+  if (dbg & 0x20000) {                              // bit 17: the split-bf16 kernel; `attn` is then an fp32 [M][320] array and the
+    char* lo = sc + b1 + b2 + b3 + b4;              // lo packs follow the hi packs in scratch
+    SRAD_REQUIRE(scratch_bytes >= 2 * (b1 + b2 + b3 + b4), "bench_mlp_block: scratch too small for the lo packs");
+    SRAD_TRY(srad_launch_pack_weight_frag_lo(w_fp32, lo, d, d, s));
+    SRAD_TRY(srad_launch_pack_weight_frag_lo(w_fp32, lo + b1, m, d, s));
+    SRAD_TRY(srad_launch_pack_weight_frag_lo(w_fp32, lo + b1 + b2, d, m, s));
+    SRAD_TRY(srad_launch_pack_weight_frag_lo(w_fp32, lo + b1 + b2 + b3, no, d, s));
+    q.split = 1; q.attn_f = reinterpret_cast<const float*>(attn);
+    q.w_proj_lo = lo; q.w_fc1_lo = lo + b1; q.w_fc2_lo = lo + b1 + b2; q.w_adj_lo = lo + b1 + b2 + b3;
+    q.dbg = 0;
+  } else
   if (dbg & 0x100ff) {                              // bit 16 or any switch-off bit: the diagnostic build; its stamps go behind the packed weights
     SRAD_REQUIRE(scratch_bytes >= b1 + b2 + b3 + b4 + (size_t)(M / 16) * 8 * 16 * 8, "bench_mlp_block: scratch too small for the stamps");
     q.stamps = reinterpret_cast<unsigned long long*>(sc + b1 + b2 + b3 + b4);
@@ -140,34 +151,44 @@ int srad_bench_mlp_block(int M, int d, int m, int no, const void* attn /* bf16 [
   return SRAD_OK;
 }
 
-// ---- the two fused forward kernels of a Swin block (bf16, window 8), weights in PyTorch layout, packed into scratch ----
+// ---- the two fused forward kernels of a Swin block (bf16 / split-bf16, window 8), weights in PyTorch layout, packed into
+//      scratch: five hi packs, then (split-bf16) the five lo packs ----
 static size_t swin_scratch_parts(int d, int heads, int m, int no, size_t* off) {
   size_t o = 0;
-  off[0] = o; o += srad_align_up(srad_qkv_frag_bytes(d, heads), 256);
-  off[1] = o; o += srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, d, d, 1), 256);
-  off[2] = o; o += srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, m, d, 1), 256);
-  off[3] = o; o += srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, d, m, 1), 256);
-  off[4] = o; o += srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, no, d, 1), 256);
+  for (int lo = 0; lo < 2; ++lo) {
+    off[5 * lo + 0] = o; o += srad_align_up(srad_qkv_frag_bytes(d, heads), 256);
+    off[5 * lo + 1] = o; o += srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, d, d, 1), 256);
+    off[5 * lo + 2] = o; o += srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, m, d, 1), 256);
+    off[5 * lo + 3] = o; o += srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, d, m, 1), 256);
+    off[5 * lo + 4] = o; o += srad_align_up(srad_packed_bytes(SRAD_PREC_BF16, no, d, 1), 256);
+  }
   return o;
 }
 
 size_t srad_op_swin_scratch_bytes(int d, int heads, int m, int no) {
-  size_t off[5];
+  size_t off[10];
   return swin_scratch_parts(d, heads > 0 ? heads : 1, m > 0 ? m : 4, no > 0 ? no : 4, off);
 }
 
 // First half of a Swin block: LayerNorm1 -> qkv Linear -> shifted-window attention (src/drct.py:477-504, 271-299).
 //   x [B*H*W][ldx] (columns [0, d)), w_qkv [3d][d], b_qkv [3d], table [225][heads] -> out [B*H*W][d]
-int srad_op_qkv_attn(const float* x, int ldx, int B, int H, int W, int shift, int d, int heads, const float* ln_g,
+int srad_op_qkv_attn(int precision, const float* x, int ldx, int B, int H, int W, int shift, int d, int heads, const float* ln_g,
                      const float* ln_b, const float* w_qkv, const float* b_qkv, const float* table, void* out, int out_bf16,
                      void* scratch, size_t scratch_bytes, void* stream) {
   SRAD_REQUIRE(x && ln_g && ln_b && w_qkv && b_qkv && table && out && scratch, "op_qkv_attn: null argument");
-  SRAD_REQUIRE(srad_qkv_attn_supported(SRAD_PREC_BF16, 8, H, W, d, heads), "op_qkv_attn: unsupported shape d=%d heads=%d %dx%d", d, heads, H, W);
-  SRAD_REQUIRE(scratch_bytes >= srad_align_up(srad_qkv_frag_bytes(d, heads), 256) && ((uintptr_t)scratch & 255) == 0,
-               "op_qkv_attn: scratch too small or not 256-byte aligned");
+  SRAD_REQUIRE(precision == SRAD_PREC_BF16 || precision == SRAD_PREC_BF16X3, "op_qkv_attn: precision must be bf16 or split-bf16 (fp32 runs the unfused kernels)");
+  SRAD_REQUIRE(srad_qkv_attn_supported(precision, 8, H, W, d, heads), "op_qkv_attn: unsupported shape d=%d heads=%d %dx%d", d, heads, H, W);
+  const size_t wb = srad_align_up(srad_qkv_frag_bytes(d, heads), 256);
+  const bool x3 = precision == SRAD_PREC_BF16X3;
+  SRAD_REQUIRE(scratch_bytes >= wb * (x3 ? 2 : 1) && ((uintptr_t)scratch & 255) == 0, "op_qkv_attn: scratch too small or not 256-byte aligned");
+  SRAD_REQUIRE(!(x3 && out_bf16), "op_qkv_attn: the split-bf16 kernel writes fp32");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   SRAD_TRY(srad_launch_pack_qkv_frag(w_qkv, scratch, d, heads, s));
   QkvAttnParams a{};
+  if (x3) {
+    SRAD_TRY(srad_launch_pack_qkv_frag_lo(w_qkv, reinterpret_cast<char*>(scratch) + wb, d, heads, s));
+    a.split = 1; a.w_qkv_lo = reinterpret_cast<char*>(scratch) + wb;
+  }
   a.x = x; a.ldx = ldx; a.ln_g = ln_g; a.ln_b = ln_b; a.w_qkv = scratch; a.b_qkv = b_qkv; a.table = table;
   if (out_bf16) a.out_h = reinterpret_cast<__bf16*>(out); else a.out = reinterpret_cast<float*>(out);
   a.ld_out = d; a.B = B; a.H = H; a.W = W; a.shift = shift; a.d = d; a.heads = heads;
@@ -186,6 +207,13 @@ int srad_bench_qkv_attn(const float* x, int ldx, int B, int H, int W, int shift,
   a.x = x; a.ldx = ldx; a.ln_g = w_fp32; a.ln_b = w_fp32; a.w_qkv = scratch; a.b_qkv = w_fp32; a.table = w_fp32;
   a.out_h = reinterpret_cast<__bf16*>(out); a.ld_out = d;        // the hand-off the engines use (bf16, in the caller's buffer)
   a.B = B; a.H = H; a.W = W; a.shift = shift & 0xff; a.d = d; a.heads = heads;
+  if (shift & 0x20000) {                            // bit 17 of `shift`: the split-bf16 kernel (fp32 output [T][d], lo pack behind the hi pack)
+    const size_t wb = srad_align_up(srad_qkv_frag_bytes(d, heads), 256);
+    SRAD_REQUIRE(scratch_bytes >= 2 * wb, "bench_qkv_attn: scratch too small for the lo pack");
+    SRAD_TRY(srad_launch_pack_qkv_frag_lo(w_fp32, reinterpret_cast<char*>(scratch) + wb, d, heads, s));
+    a.split = 1; a.w_qkv_lo = reinterpret_cast<char*>(scratch) + wb;
+    a.out = reinterpret_cast<float*>(out); a.out_h = nullptr;
+  } else
   if (shift & 0x10000) {                            // bit 16 of `shift`: the stamp build; stamps go behind the weight pack in scratch
     const size_t wb = srad_align_up(srad_qkv_frag_bytes(d, heads), 256);
     SRAD_REQUIRE(scratch_bytes >= wb + (size_t)B * (H / 8) * (W / 8) * heads * 8 * 16 * 8, "bench_qkv_attn: scratch too small for the stamps");
@@ -210,16 +238,17 @@ int srad_bench_qkv_attn(const float* x, int ldx, int B, int H, int W, int shift,
 // Second half of a Swin block + the RDG's adjust conv (src/drct.py:300, 509-510, 184-190, 389-396):
 //   x1 = shortcut + proj(attn); x2 = x1 + fc2(GELU(fc1(LN2(x1)))); Y[:, yoff:yoff+no] = act(adjust(x2)) * alpha (+ R)
 //   fm: token rows per workgroup (16 / 32 / 64; 0 = the engine's choice for M)
-int srad_op_mlp_block(int M, int d, int m, int no, int fm, const void* attn /* bf16 [M][d] */, const float* shortcut, int ld_short,
+int srad_op_mlp_block(int precision, int M, int d, int m, int no, int fm, const void* attn /* bf16 [M][d]; split-bf16: fp32 */, const float* shortcut, int ld_short,
                       const float* w_proj, const float* b_proj, const float* ln_g, const float* ln_b, const float* w_fc1,
                       const float* b_fc1, const float* w_fc2, const float* b_fc2, const float* w_adj, const float* b_adj, int act,
                       float slope, float alpha, const float* r, int ldr, float* y, int ldy, int yoff, void* scratch,
                       size_t scratch_bytes, void* stream) {
   SRAD_REQUIRE(attn && shortcut && w_proj && b_proj && ln_g && ln_b && w_fc1 && b_fc1 && w_fc2 && b_fc2 && w_adj && b_adj && y && scratch,
                "op_mlp_block: null argument");
-  SRAD_REQUIRE(srad_mlp_block_supported(SRAD_PREC_BF16, M, d, m, no), "op_mlp_block: unsupported shape M=%d d=%d m=%d no=%d", M, d, m, no);
+  SRAD_REQUIRE(precision == SRAD_PREC_BF16 || precision == SRAD_PREC_BF16X3, "op_mlp_block: precision must be bf16 or split-bf16 (fp32 runs the unfused kernels)");
+  SRAD_REQUIRE(srad_mlp_block_supported(precision, M, d, m, no), "op_mlp_block: unsupported shape M=%d d=%d m=%d no=%d", M, d, m, no);
   SRAD_REQUIRE(fm == 0 || ((fm == 16 || fm == 32 || fm == 64) && M % fm == 0), "op_mlp_block: fm must be 0, 16, 32 or 64 and divide M");
-  size_t off[5];
+  size_t off[10];
   const size_t need = swin_scratch_parts(d, 1, m, no, off);
   SRAD_REQUIRE(scratch_bytes >= need && ((uintptr_t)scratch & 255) == 0, "op_mlp_block: scratch %zu bytes, %zu needed (256-byte aligned)", scratch_bytes, need);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -231,6 +260,14 @@ int srad_op_mlp_block(int M, int d, int m, int no, int fm, const void* attn /* b
   MlpBlockParams q{};
   q.attn_h = reinterpret_cast<const __bf16*>(attn); q.ld_attn = d; q.shortcut = shortcut; q.ld_short = ld_short; q.M = M; q.d = d; q.m = m; q.no = no;
   q.w_proj = sc + off[1]; q.w_fc1 = sc + off[2]; q.w_fc2 = sc + off[3]; q.w_adj = sc + off[4];
+  if (precision == SRAD_PREC_BF16X3) {
+    SRAD_TRY(srad_launch_pack_weight_frag_lo(w_proj, sc + off[6], d, d, s));
+    SRAD_TRY(srad_launch_pack_weight_frag_lo(w_fc1, sc + off[7], m, d, s));
+    SRAD_TRY(srad_launch_pack_weight_frag_lo(w_fc2, sc + off[8], d, m, s));
+    SRAD_TRY(srad_launch_pack_weight_frag_lo(w_adj, sc + off[9], no, d, s));
+    q.split = 1; q.attn_f = reinterpret_cast<const float*>(attn);
+    q.w_proj_lo = sc + off[6]; q.w_fc1_lo = sc + off[7]; q.w_fc2_lo = sc + off[8]; q.w_adj_lo = sc + off[9];
+  }
   q.b_proj = b_proj; q.b_fc1 = b_fc1; q.b_fc2 = b_fc2; q.b_adj = b_adj; q.ln_g = ln_g; q.ln_b = ln_b;
   q.act = act; q.slope = slope; q.alpha = alpha; q.R = r; q.ldr = ldr; q.Y = y; q.ldy = ldy; q.yoff = yoff; q.fm = fm;
   return srad_launch_mlp_block(q, s);

@@ -11,7 +11,11 @@
 #define SRAD_ERR_HIP 3
 #define SRAD_ERR_NOMEM 4
 
-enum { SRAD_PREC_F32 = 0, SRAD_PREC_BF16 = 1 };
+// SRAD_PREC_BF16X3: split-bf16.  Every MFMA operand x is held as two bf16 terms, hi = bf16(x) and lo = bf16(x - hi) (~16 mantissa
+// bits), and a product is three v_mfma_f32_16x16x32_bf16 (hi.hi + hi.lo + lo.hi), fp32 accumulation: fp32-grade results (measured
+// ~1e-5 per op against the fp32 oracle) from the bf16 matrix pipe.  Kernels without a split instance run their exact-fp32 form
+// in this mode (every `prec == SRAD_PREC_BF16 ? bf16 : fp32` dispatch), so the mode is never less accurate than asked.
+enum { SRAD_PREC_F32 = 0, SRAD_PREC_BF16 = 1, SRAD_PREC_BF16X3 = 2 };
 enum { SRAD_ACT_NONE = 0, SRAD_ACT_GELU = 1, SRAD_ACT_LRELU = 2, SRAD_ACT_RELU = 3 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -52,6 +56,14 @@ __device__ __forceinline__ float srad_row16_max(float v) {
   v = fmaxf(v, srad_dpp<0x141>(v));
   v = fmaxf(v, srad_dpp<0x140>(v));
   return v;
+}
+// split-bf16 terms of four values: hi = bf16(v) (round to nearest even), lo = bf16(v - hi); hi + lo carries ~16 mantissa bits
+__device__ __forceinline__ void srad_split4(const f32x4 v, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hi[e] = (__bf16)v[e];
+    lo[e] = (__bf16)(v[e] - (float)hi[e]);
+  }
 }
 __device__ __forceinline__ float srad_wave_sum(float v) {
   v += srad_dpp<0xB1>(v);
@@ -147,8 +159,12 @@ int srad_launch_conv80(const GemmParams& p, hipStream_t stream);
 // Packed weight geometry shared by the packer and the GEMM
 static inline int srad_cp(int cin) { return srad_round_up(cin, 32); }
 static inline int srad_np(int n) { return srad_round_up(n, 128); }   // rows padded so 64- and 128-row stages never leave the tensor
+// (split-bf16: a bf16 hi plane followed by a bf16 lo plane of the same geometry = the fp32 pack's size)
 static inline size_t srad_packed_bytes(int prec, int n, int cin, int ntaps) {
   return (size_t)srad_np(n) * ntaps * srad_cp(cin) * (prec == SRAD_PREC_BF16 ? 2 : 4);
+}
+static inline size_t srad_packed_lo_offset(int n, int cin, int ntaps) {    // bytes from the hi plane to the lo plane
+  return (size_t)srad_np(n) * ntaps * srad_cp(cin) * 2;
 }
 // src: PyTorch layout [N][Cin][kh][kw] (kh*kw = ntaps) or [N][Cin] for Linear
 int srad_launch_pack_weight(int prec, const float* src, void* dst, int n, int cin, int ntaps,
@@ -159,12 +175,15 @@ int srad_launch_pack_weight_padded(int prec, const float* src, void* dst, int n,
                                    int grp_real, int grp_pad, hipStream_t stream);
 // Linear weights once more as bf16 MFMA fragments (16 x 32 tiles of 1 KB, tile-major): same byte size as the bf16 pack
 int srad_launch_pack_weight_frag(const float* src, void* dst, int n, int cin, hipStream_t stream);
+// the lo terms of the same pack, bf16(w - float(bf16(w))): the second operand set of the split-bf16 kernels
+int srad_launch_pack_weight_frag_lo(const float* src, void* dst, int n, int cin, hipStream_t stream);
 int srad_launch_pack_weight_frag_t(const float* src, void* dst, int n, int cin, hipStream_t stream);   // W^T: rows = cin, k = n
 // qkv.weight [3d][d] as per-head fragments: head h owns 3 * HDP virtual rows [q_h | k_h | v_h], each slice padded with zero
 // rows from head_dim to HDP = ceil16(head_dim); layout [head][virtual row / 16][k / 32][16 x 32] (1 KB tiles)
 static inline int srad_qkv_hdp(int d, int heads) { return srad_round_up(d / heads, 16); }
 static inline size_t srad_qkv_frag_bytes(int d, int heads) { return (size_t)heads * 3 * srad_qkv_hdp(d, heads) * srad_cp(d) * 2; }
 int srad_launch_pack_qkv_frag(const float* src, void* dst, int d, int heads, hipStream_t stream);
+int srad_launch_pack_qkv_frag_lo(const float* src, void* dst, int d, int heads, hipStream_t stream);
 // Data-gradient operand: the same tensor packed as the weight of the transposed convolution,
 // dst[c][8 - tap][n] (taps mirrored for 3x3, identity for 1x1), geometry (rows cin_pad, columns n_pad).
 int srad_launch_pack_weight_transposed(int prec, const float* src, void* dst, int n, int cin, int ntaps, int n_pad,
@@ -204,6 +223,11 @@ struct MlpBlockParams {
   int fm;                                // token rows per workgroup: 0 = chosen from M, else 16 / 32 / 64
   int no_xcd_map;                        // 1: plain workgroup -> row tile order (A/B of the XCD-affine mapping)
   unsigned long long* stamps;            // diagnostic build (16-row tiles): [workgroup][8 waves][16] s_memtime stamps, else null
+  // ---- split-bf16 (SRAD_PREC_BF16X3; inference only, 16 / 32 rows per workgroup): the attention output as fp32 and the lo
+  //      fragment packs of the four weights (srad_launch_pack_weight_frag_lo); attn_h is unused ----
+  int split;
+  const float* attn_f;                   // [M][ld_attn] fp32
+  const void *w_proj_lo, *w_fc1_lo, *w_fc2_lo, *w_adj_lo;
   // ---- training (all optional): DropPath factors of the two residual branches and the tensors the backward needs ----
   const float *rs1, *rs2; int rps;       // per-sample factors (row m belongs to sample m / rps), null = 1
   float *save_x1, *save_xn2, *save_hpre, *save_hact, *save_x2;   // [M][d] x + attn branch, [M][d] LayerNorm2, [M][m] fc1 pre-activation, [M][m] GELU, [M][d] block output
@@ -232,6 +256,8 @@ struct QkvAttnParams {
   float* save_qkv; int hdp;                // [T][3][heads][hdp] head-padded q | k | v (q unscaled), as the QKV GEMM writes it
   __bf16* save_qkv_h; int hp_h;            // or [T][3][heads][hp_h] bf16 exactly as the attention used them (q scaled, padding 0), hp_h % 8 == 0
   unsigned long long* stamps;              // diagnostic build: [workgroup][8 waves][16] s_memtime stamps, else null
+  // split-bf16 (SRAD_PREC_BF16X3; inference only): lo terms of the per-head pack (srad_launch_pack_qkv_frag_lo); the output is fp32 (`out`)
+  int split; const void* w_qkv_lo;
 };
 bool srad_no_xcd_map();     // SRAD_NO_XCD_MAP=1 (read once): plain workgroup order in the Swin-block kernels, for A/B runs
 bool srad_qkv_attn_supported(int prec, int ws, int H, int W, int d, int heads);

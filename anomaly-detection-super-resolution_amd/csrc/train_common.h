@@ -194,6 +194,7 @@ inline int train_param_floats(const ParamTable& pt, TrainState& ts, int64_t* tot
 }
 
 inline int train_arena_bytes(const ParamTable& pt, TrainState& ts, size_t* bytes) {
+  SRAD_REQUIRE(pt.prec != SRAD_PREC_BF16X3, "training runs in fp32 or bf16: the split-bf16 precision is an inference mode");
   int64_t tot = 0;
   SRAD_TRY(train_param_floats(pt, ts, &tot));
   if (ts.t_off.empty()) {

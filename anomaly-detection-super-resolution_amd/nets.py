@@ -224,6 +224,8 @@ class _EngineModule(nn.Module):
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("srad_amd trains on the GPU only (HIP engine); move the model with .cuda() first")
+        if L.PRECISIONS[self.precision] == L.PREC_BF16X3:
+            raise RuntimeError("the split-bf16 precision ('bf16x3') is an inference mode; train with precision 'fp32' or 'bf16'")
         self._ensure_handle(dev)
         h = self._handle
         total = C.c_int64()

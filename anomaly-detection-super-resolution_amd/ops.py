@@ -288,11 +288,12 @@ def lin_ln_bwd(dy: torch.Tensor, w: torch.Tensor, x: torch.Tensor, gamma: torch.
 
 # ----------------------------------------------------------------------------------- fused Swin-block halves (bf16, window 8)
 def qkv_attn(x: torch.Tensor, ln_g: torch.Tensor, ln_b: torch.Tensor, w_qkv: torch.Tensor, b_qkv: torch.Tensor,
-             table: torch.Tensor, B: int, H: int, W: int, shift: int, heads: int, out_bf16: bool = False) -> torch.Tensor:
+             table: torch.Tensor, B: int, H: int, W: int, shift: int, heads: int, out_bf16: bool = False,
+             precision: str = "bf16") -> torch.Tensor:
     """First half of a Swin block in ONE launch (``srad_op_qkv_attn``; src/drct.py:477-504 up to attn.proj, 271-299):
     x [B*H*W, >=d] block input rows (columns [0, d) are read), w_qkv [3d, d], table [225, heads] -> attention output
     [B*H*W, d] in token order (window partition, cyclic shift and their inverses are index arithmetic inside); fp32, or
-    with ``out_bf16`` the bf16 tensor the engines hand to ``mlp_block``."""
+    with ``out_bf16`` the bf16 tensor the engines hand to ``mlp_block``.  precision "bf16" or "bf16x3" (split-bf16: fp32 out)."""
     _need_cuda(x, ln_g, ln_b, w_qkv, b_qkv, table)
     d = w_qkv.shape[1]
     assert x.dim() == 2 and x.shape[0] == B * H * W and x.stride(1) == 1 and x.dtype == torch.float32 and w_qkv.shape[0] == 3 * d
@@ -300,7 +301,7 @@ def qkv_attn(x: torch.Tensor, ln_g: torch.Tensor, ln_b: torch.Tensor, w_qkv: tor
     keep = [f(ln_g), f(ln_b), f(w_qkv), f(b_qkv), f(table)]
     out = torch.empty(x.shape[0], d, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     sbuf, sp, sb = _scratch(L.lib().srad_op_swin_scratch_bytes(d, heads, 4, 4), x.device)
-    L.check(L.lib().srad_op_qkv_attn(L.dptr(x), x.stride(0), B, H, W, shift, d, heads, L.dptr(keep[0]), L.dptr(keep[1]),
+    L.check(L.lib().srad_op_qkv_attn(L.PRECISIONS[precision], L.dptr(x), x.stride(0), B, H, W, shift, d, heads, L.dptr(keep[0]), L.dptr(keep[1]),
                                      L.dptr(keep[2]), L.dptr(keep[3]), L.dptr(keep[4]), L.dptr(out), int(out_bf16), sp, sb,
                                      L.current_stream_ptr()), "op_qkv_attn")
     return out
@@ -308,20 +309,20 @@ def qkv_attn(x: torch.Tensor, ln_g: torch.Tensor, ln_b: torch.Tensor, w_qkv: tor
 
 def mlp_block(attn: torch.Tensor, shortcut: torch.Tensor, w_proj, b_proj, ln_g, ln_b, w_fc1, b_fc1, w_fc2, b_fc2, w_adj, b_adj, *,
               act: int = L.ACT_LRELU, slope: float = 0.2, alpha: float = 1.0, residual: Optional[torch.Tensor] = None,
-              out: Optional[torch.Tensor] = None, out_offset: int = 0, fm: int = 0) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, out_offset: int = 0, fm: int = 0, precision: str = "bf16") -> torch.Tensor:
     """Second half of a Swin block + the RDG's 1x1 adjust conv in ONE launch (``srad_op_mlp_block``; src/drct.py:300,
     509-510, 184-190, 389-396).  attn [M, d] (crosses the boundary as bf16 - the operand the MFMA takes; an fp32 tensor is
-    rounded here), shortcut [M, >=d]; returns / fills out[:, out_offset:out_offset+no]."""
+    rounded here; with precision "bf16x3" it crosses as fp32), shortcut [M, >=d]; returns / fills out[:, out_offset:out_offset+no]."""
     _need_cuda(attn, shortcut, w_proj, w_fc1, w_fc2, w_adj)
     M, d = attn.shape
     m, no = w_fc1.shape[0], w_adj.shape[0]
     f = lambda t: t.detach().float().contiguous()
     keep = [f(w_proj), f(b_proj), f(ln_g), f(ln_b), f(w_fc1), f(b_fc1), f(w_fc2), f(b_fc2), f(w_adj.reshape(no, d)), f(b_adj)]
-    attn = attn.detach().to(torch.bfloat16).contiguous()
+    attn = attn.detach().to(torch.float32 if L.PRECISIONS[precision] == L.PREC_BF16X3 else torch.bfloat16).contiguous()
     if out is None:
         out = torch.empty(M, no, dtype=torch.float32, device=attn.device)
     sbuf, sp, sb = _scratch(L.lib().srad_op_swin_scratch_bytes(d, 1, m, no), attn.device)
-    L.check(L.lib().srad_op_mlp_block(M, d, m, no, int(fm), L.dptr(attn), L.dptr(shortcut), shortcut.stride(0), *[L.dptr(k) for k in keep],
+    L.check(L.lib().srad_op_mlp_block(L.PRECISIONS[precision], M, d, m, no, int(fm), L.dptr(attn), L.dptr(shortcut), shortcut.stride(0), *[L.dptr(k) for k in keep],
                                       int(act), float(slope), float(alpha), L.dptr(residual), 0 if residual is None else residual.stride(0),
                                       L.dptr(out), out.stride(0), int(out_offset), sp, sb, L.current_stream_ptr()), "op_mlp_block")
     return out

@@ -193,7 +193,7 @@ def parse_train_args(argv: Optional[List[str]] = None) -> argparse.Namespace:
     p.add_argument('--pretrain', action='store_true')
     p.add_argument('--test-only', action='store_true')
     p.add_argument('--workers', type=int, default=0 if sys.platform == 'darwin' else 4)
-    p.add_argument('--dtype', type=str, default='fp32', choices=['fp32', 'bf16'])
+    p.add_argument('--dtype', type=str, default='fp32', choices=['fp32', 'bf16', 'bf16x3'])
     p.add_argument('--gpus', type=int, default=1)
     _with_config(p, pre_args)
     return p.parse_args(argv)
@@ -218,7 +218,7 @@ def parse_eval_args(argv=None) -> argparse.Namespace:
     p.add_argument('--output-dir', type=str, default='')
     p.add_argument('--save-images', action='store_true', default=True)
     p.add_argument('--workers', type=int, default=0 if sys.platform == 'darwin' else 4)
-    p.add_argument('--dtype', type=str, default='fp32', choices=['fp32', 'bf16'])
+    p.add_argument('--dtype', type=str, default='fp32', choices=['fp32', 'bf16', 'bf16x3'])
     p.add_argument('--gpus', type=int, default=1)
     _with_config(p, pre_args)
     return p.parse_args(argv)

@@ -28,6 +28,9 @@ extern "C" {
 
 #define SRAD_PRECISION_F32 0  /* v_mfma_f32_16x16x4_f32: exact fp32, the parity mode            */
 #define SRAD_PRECISION_BF16 1 /* v_mfma_f32_16x16x32_bf16, fp32 accumulate, fp32 residual stream */
+#define SRAD_PRECISION_BF16X3 2 /* split-bf16: every MFMA operand as hi + lo bf16 terms, three bf16 MFMAs per product
+                                 * (hi.hi + hi.lo + lo.hi), fp32 accumulate - fp32-grade outputs (the 1e-3 / AUC +-0.002 bar)
+                                 * from the bf16 matrix pipe.  Inference only (forward / scoring); training is fp32 or bf16. */
 
 const char* srad_last_error(void);
 int srad_version(void);
@@ -229,8 +232,9 @@ int srad_op_window_attn(int precision, const float* qkv, float* out, const float
 int srad_op_layernorm(const float* x, int ldx, float* y, int ldy, int rows, int C, const float* g, const float* b,
                       void* stream);
 
-/* The two fused launches a Swin block becomes in bf16 mode with 8 x 8 windows (BASELINE configs C2 / C4; what bench.py
- * times).  Weights in PyTorch layout (device fp32), packed into `scratch` (>= srad_op_swin_scratch_bytes, 256-byte aligned).
+/* The two fused launches a Swin block becomes in bf16 and split-bf16 mode with 8 x 8 windows (BASELINE configs C2 / C4; what
+ * bench.py times).  precision = SRAD_PRECISION_BF16 | SRAD_PRECISION_BF16X3; in split-bf16 mode the hand-off between the two
+ * (out of the first, attn of the second) is fp32 and out_bf16 must be 0.  Weights in PyTorch layout (device fp32), packed into `scratch` (>= srad_op_swin_scratch_bytes, 256-byte aligned).
  *   srad_op_qkv_attn : norm1 -> attn.qkv -> cyclic shift + window partition -> softmax(q k^T * scale + relative position
  *                      bias + 0/-100 shift mask) v -> window reverse + shift back
  *                      (SwinTransformerBlock.forward src/drct.py:477-504 up to attn.proj; WindowAttention.forward 271-299)
@@ -241,10 +245,10 @@ int srad_op_layernorm(const float* x, int ldx, float* y, int ldy, int rows, int 
  *                      fm = token rows per workgroup (16 | 32 | 64, 0 = the engine's choice for M); attn is a bf16 [M][d]
  *                      array: the first half's output in the form the MFMA takes it */
 size_t srad_op_swin_scratch_bytes(int d, int heads, int m, int no);
-int srad_op_qkv_attn(const float* x, int ldx, int B, int H, int W, int shift, int d, int heads, const float* ln_g,
+int srad_op_qkv_attn(int precision, const float* x, int ldx, int B, int H, int W, int shift, int d, int heads, const float* ln_g,
                      const float* ln_b, const float* w_qkv, const float* b_qkv, const float* table, void* out, int out_bf16,
                      void* scratch, size_t scratch_bytes, void* stream);
-int srad_op_mlp_block(int M, int d, int m, int no, int fm, const void* attn, const float* shortcut, int ld_short,
+int srad_op_mlp_block(int precision, int M, int d, int m, int no, int fm, const void* attn, const float* shortcut, int ld_short,
                       const float* w_proj, const float* b_proj, const float* ln_g, const float* ln_b, const float* w_fc1,
                       const float* b_fc1, const float* w_fc2, const float* b_fc2, const float* w_adj, const float* b_adj, int act,
                       float slope, float alpha, const float* r, int ldr, float* y, int ldy, int yoff, void* scratch,

@@ -39,6 +39,30 @@ def test_drct_fp32_matches_reference_golden(sr_golden, name):
     assert rel_err(out, y) < 2e-4          # what the exact-fp32 MFMA path actually achieves
 
 
+@pytest.mark.parametrize("name", DRCT_CASES)
+@pytest.mark.parametrize("fused", [True, False])
+def test_drct_split_bf16_matches_reference_golden(sr_golden, name, fused, monkeypatch):
+    """The split-bf16 mode ("bf16x3": hi + lo operands, three bf16 MFMAs per product) is held to the fp32 mode's bar on every
+    reference golden (window sizes 2 / 4 / 8 / 16, RGB, 12 RDG, the dynamic-mask path): window 8 runs the two fused block
+    kernels, the other sizes and SRAD_NO_FUSE the split GEMM + the exact-fp32 attention kernel."""
+    if not fused:
+        monkeypatch.setenv("SRAD_NO_FUSE", "1")
+    cfg, sd, x, y = drct_case(sr_golden, name)
+    m = build(cfg, sd, "bf16x3")
+    with torch.no_grad():
+        out = m(torch.from_numpy(x).cuda()).cpu().numpy()
+    e = rel_err(out, y)
+    print(name, "bf16x3", "fused" if fused else "unfused", "rel err", e)
+    assert out.shape == y.shape and e < 2e-4, e
+
+
+def test_split_bf16_is_an_inference_mode(sr_golden):
+    cfg, sd, x, y = drct_case(sr_golden, "drct_r2_rgb_x4")
+    m = build(cfg, sd, "bf16x3")
+    with pytest.raises(RuntimeError, match="inference mode"):
+        m.enable_training()
+
+
 @pytest.mark.parametrize("name", ["drct_full_gray_x4", "drct_r2_rgb_x4", "drct_r2_gray_x4_dyn64"])
 def test_drct_bf16_close_to_reference(sr_golden, name):
     cfg, sd, x, y = drct_case(sr_golden, name)

@@ -44,6 +44,25 @@ def test_drn_fp32_matches_reference_golden(sr_golden, name, graph):
     assert rel_err(dy.cpu().numpy(), dual_y) < 2e-4
 
 
+@pytest.mark.parametrize("name", DRN_CASES)
+def test_drn_split_bf16_matches_reference_golden(sr_golden, name):
+    """split-bf16 ("bf16x3"): every convolution through the split GEMM (hi + lo planes of A and W), held to the fp32 bar;
+    the dual model too."""
+    cfg, sd, dual, x, ys, dual_y = drn_case(sr_golden, name)
+    m = build(cfg, sd, "bf16x3")
+    with torch.no_grad():
+        outs = m(torch.from_numpy(x).cuda())
+    for o, y in zip(outs, ys):
+        assert tuple(o.shape) == y.shape
+        assert rel_err(o.cpu().numpy(), y) < 2e-4, rel_err(o.cpu().numpy(), y)
+    from srad_amd.nets import DownBlock
+    d = DownBlock(Opt(cfg, "bf16x3")).cuda()
+    d.load_state_dict({k: torch.from_numpy(v) for k, v in dual.items()})
+    with torch.no_grad():
+        dy = d(torch.from_numpy(ys[-1]).cuda())
+    assert rel_err(dy.cpu().numpy(), dual_y) < 2e-4
+
+
 @pytest.mark.parametrize("name", ["drn_x2_gray", "drn_x4_rgb"])
 def test_drn_bf16_close_to_reference(sr_golden, name):
     cfg, sd, dual, x, ys, _ = drn_case(sr_golden, name)

@@ -30,9 +30,10 @@ def bf16r(t: torch.Tensor) -> torch.Tensor:
     return t.bfloat16().float()
 
 
-def make_block(d, heads, hidden, no, seed):
+def make_block(d, heads, hidden, no, seed, round_weights=True):
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s, std=1.0: torch.randn(*s, generator=g) * std
+    bf16r = (lambda t: t.bfloat16().float()) if round_weights else (lambda t: t)
     sd = {"norm1.weight": 1 + 0.2 * rn(d), "norm1.bias": 0.1 * rn(d),
           "attn.qkv.weight": bf16r(rn(3 * d, d, std=d ** -0.5)), "attn.qkv.bias": 0.2 * rn(3 * d),
           "attn.relative_position_bias_table": rn(225, heads, std=0.5),
@@ -132,6 +133,83 @@ def test_mlp_block_kernel_matches_oracle(d, heads, hidden, fm, M):
     e = rel(got, ref)
     print(f"mlp_block d={d} m={hidden} no={no} fm={fm} M={M}: rel err {e:.2e}")
     assert e < BAR, e
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# split-bf16 ("bf16x3": every MFMA operand as hi + lo bf16 terms, three MFMAs per product): the SAME two kernels against the
+# plain fp32 oracle - no rounding hook, weights NOT pre-rounded.  Bar 2e-4 of the output's max.
+# ------------------------------------------------------------------------------------------------------------------------
+BAR_X3 = 2e-4
+
+
+@pytest.mark.parametrize("d,heads,hidden", BLOCKS)
+@pytest.mark.parametrize("shift", [0, 4])
+@pytest.mark.parametrize("B,H,W", [(2, 16, 24), (1, 8, 8), (4, 32, 32)])
+def test_qkv_attn_split_bf16_matches_fp32_oracle(d, heads, hidden, shift, B, H, W):
+    if (B, H, W) == (4, 32, 32) and (d, shift) not in ((180, 4), (308, 0), (244, 4), (276, 4)):
+        pytest.skip("the C2 geometry is run on four block shapes (CPU oracle time)")
+    sd = make_block(d, heads, hidden, 32, seed=d + shift, round_weights=False)
+    g = torch.Generator().manual_seed(7)
+    D = 308
+    x = torch.randn(B, H * W, D, generator=g) * 1.5 + 0.3
+    taps = {}
+    R.swin_block({k: v for k, v in sd.items()}, "", x[..., :d].contiguous(), H, W, 8, heads, shift, taps=taps)      # fp32, no rnd hook
+    ref = taps["attn"].reshape(B * H * W, d)
+    out = ops.qkv_attn(x.reshape(B * H * W, D).cuda(), sd["norm1.weight"].cuda(), sd["norm1.bias"].cuda(), sd["attn.qkv.weight"].cuda(),
+                       sd["attn.qkv.bias"].cuda(), sd["attn.relative_position_bias_table"].cuda(), B, H, W, shift, heads, precision="bf16x3")
+    e = rel(out.cpu(), ref)
+    print(f"qkv_attn bf16x3 d={d} heads={heads} shift={shift} {B}x{H}x{W}: rel err {e:.2e}")
+    assert out.dtype == torch.float32 and not torch.isnan(out).any()
+    assert e < BAR_X3, e
+    # the plain bf16 kernel on the same unrounded operands is two orders of magnitude off that bar (what the mode is for)
+    e16 = rel(ops.qkv_attn(x.reshape(B * H * W, D).cuda(), sd["norm1.weight"].cuda(), sd["norm1.bias"].cuda(), sd["attn.qkv.weight"].cuda(),
+                           sd["attn.qkv.bias"].cuda(), sd["attn.relative_position_bias_table"].cuda(), B, H, W, shift, heads).cpu(), ref)
+    assert e16 > 5 * BAR_X3, e16
+
+
+@pytest.mark.parametrize("d,heads,hidden", BLOCKS)
+@pytest.mark.parametrize("fm,M", [(16, 4096), (32, 8192), (0, 512), (0, 16384)])
+def test_mlp_block_split_bf16_matches_fp32_oracle(d, heads, hidden, fm, M):
+    last = d == 308
+    no = 180 if last else 32
+    sd = make_block(d, heads, hidden, no, seed=3 * d + fm, round_weights=False)
+    g = torch.Generator().manual_seed(11)
+    D = 308
+    dense = torch.randn(M, D, generator=g) * 1.2
+    attn = torch.randn(M, d, generator=g) * 0.8                  # fp32 hand-off, not rounded
+    x1 = dense[:, :d] + F.linear(attn, sd["attn.proj.weight"], sd["attn.proj.bias"])
+    y = F.layer_norm(x1, (d,), sd["norm2.weight"], sd["norm2.bias"], 1e-5)
+    y = F.gelu(F.linear(y, sd["mlp.fc1.weight"], sd["mlp.fc1.bias"]))
+    x2 = x1 + F.linear(y, sd["mlp.fc2.weight"], sd["mlp.fc2.bias"])
+    a = F.linear(x2, sd["adjust.weight"], sd["adjust.bias"])
+    ref = (a * 0.2 + dense[:, :180]) if last else F.leaky_relu(a, 0.2)
+    dg = dense.cuda()
+    c = lambda k: sd[k].cuda()
+    args = (c("attn.proj.weight"), c("attn.proj.bias"), c("norm2.weight"), c("norm2.bias"), c("mlp.fc1.weight"), c("mlp.fc1.bias"),
+            c("mlp.fc2.weight"), c("mlp.fc2.bias"), c("adjust.weight"), c("adjust.bias"))
+    if last:
+        out = torch.full((M, D), float("nan"), device="cuda")
+        ops.mlp_block(attn.cuda(), dg, *args, act=L.ACT_NONE, slope=0.0, alpha=0.2, residual=dg, out=out, out_offset=0, fm=fm, precision="bf16x3")
+        got = out[:, :180].cpu()
+        assert torch.isnan(out[:, 180:]).all()
+    else:
+        before = dg.clone()
+        ops.mlp_block(attn.cuda(), dg, *args, act=L.ACT_LRELU, slope=0.2, alpha=1.0, out=dg, out_offset=d, fm=fm, precision="bf16x3")
+        got = dg[:, d:d + 32].cpu()
+        assert torch.equal(dg[:, :d], before[:, :d]) and torch.equal(dg[:, d + 32:], before[:, d + 32:])
+    e = rel(got, ref)
+    print(f"mlp_block bf16x3 d={d} m={hidden} no={no} fm={fm} M={M}: rel err {e:.2e}")
+    assert e < BAR_X3, e
+
+
+def test_split_bf16_ops_refuse_what_they_do_not_do():
+    x = torch.zeros(64, 180, device="cuda")
+    w = torch.zeros(540, 180, device="cuda")
+    with pytest.raises(RuntimeError, match="writes fp32"):
+        ops.qkv_attn(x, x[0], x[0], w, w[:, 0], torch.zeros(225, 6, device="cuda"), 1, 8, 8, 0, 6, out_bf16=True, precision="bf16x3")
+    with pytest.raises(RuntimeError, match="16 or 32 rows"):
+        ops.mlp_block(x, x, w[:180], w[0], w[0], w[0], w[:360], torch.zeros(360, device="cuda"), torch.zeros(180, 360, device="cuda"), w[0],
+                      w[:32], torch.zeros(32, device="cuda"), fm=64, precision="bf16x3")
 
 
 def test_fused_ops_report_bad_arguments():

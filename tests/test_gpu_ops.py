@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"fp32": 1e-4, "bf16": 3e-2}
+TOL = {"fp32": 1e-4, "bf16": 3e-2, "bf16x3": 1e-4}     # bf16x3 = split-bf16 (hi + lo operands, three bf16 MFMAs per product)
 
 
 def _rel(a, b):
@@ -23,7 +23,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("M,K,N", [(4096, 180, 540), (1000, 212, 32), (77, 308, 180), (256, 488, 244), (130, 36, 3)])
 def test_linear_variants(dev, prec, M, K, N):
     from srad_amd import ops
@@ -52,7 +52,7 @@ def test_linear_variants(dev, prec, M, K, N):
     assert float(out[:, :8].abs().max()) == 0 and float(out[:, 8 + N:].abs().max()) == 0
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(2, 32, 32, 180, 64, 1), (1, 17, 23, 1, 180, 1), (2, 16, 12, 3, 20, 1),
                                                    (1, 32, 32, 20, 20, 2), (1, 15, 11, 40, 80, 2), (3, 8, 8, 64, 1, 1)])
 def test_conv3x3(dev, prec, B, H, W, Cin, Cout, stride):
@@ -99,7 +99,7 @@ def test_conv3x3_80_channels_weight_resident_kernel(dev, B, H, W, mode):
     assert _rel(y, ref) < 1e-4
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "bf16x3"])
 def test_conv_pixel_shuffle(dev, prec):
     from srad_amd import ops
     g = torch.Generator(device="cpu").manual_seed(5)
@@ -136,7 +136,7 @@ def _attn_ref(qkv, table, B, H, W, ws, shift, heads):
     return o.reshape(B * H * W, d)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("B,H,W,ws,shift,d,heads", [
     (2, 32, 32, 8, 0, 180, 6), (2, 32, 32, 8, 4, 212, 4), (1, 32, 32, 8, 0, 244, 2), (1, 32, 32, 8, 4, 276, 6),
     (1, 32, 32, 8, 0, 308, 4), (1, 64, 32, 8, 4, 212, 4), (2, 16, 16, 4, 2, 180, 6), (1, 8, 8, 2, 1, 212, 4),
