@@ -7,7 +7,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsrad.so")
+# SRAD_LIB_PATH: a differently built libsrad (an A/B build of tools/), else the in-tree library
+LIB_PATH = os.environ.get("SRAD_LIB_PATH") or os.path.join(_HERE, "libsrad.so")
 
 PREC_F32 = 0
 PREC_BF16 = 1

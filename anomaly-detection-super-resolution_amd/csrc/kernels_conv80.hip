@@ -230,7 +230,8 @@ __global__ __launch_bounds__(C80_NT) void conv80_kernel(const GemmParams p, cons
 bool srad_conv80_supported(int prec, const GemmParams& p) {
   static const bool off = getenv("SRAD_NO_CONV80") != nullptr;
   return !off && prec == SRAD_PREC_BF16 && p.ntaps == 9 && p.stride == 1 && p.Cin == 80 && p.N == 80 && !p.ln_g && p.ps == 0 &&
-         p.hsplit_hd == 0 && !p.row_scale && !p.Ypre && p.Hi == p.Ho && p.Wi == p.Wo && p.Hi % C80_TH == 0 && p.Wi % C80_TW == 0 &&
+         p.hsplit_hd == 0 && !p.row_scale && !p.Ypre && (p.act == SRAD_ACT_NONE || p.act == SRAD_ACT_RELU || p.act == SRAD_ACT_LRELU) &&   // the epilogue has no GELU: such a call stays on the tiled GEMM
+         p.Hi == p.Ho && p.Wi == p.Wo && p.Hi % C80_TH == 0 && p.Wi % C80_TW == 0 &&
          (!p.R || p.rmode == SRAD_RMODE_ADD || p.rmode == SRAD_RMODE_DLRELU) && (p.ldx & 3) == 0 && (p.ldy & 3) == 0 && (p.yoff & 3) == 0 &&
          (!p.R || (p.ldr & 3) == 0) && (((uintptr_t)p.X | (uintptr_t)p.Y | (uintptr_t)p.R | (uintptr_t)p.bias | (uintptr_t)p.Wp) & 15) == 0 &&
          (((uintptr_t)p.Xh | (uintptr_t)p.Yh) & 7) == 0 &&

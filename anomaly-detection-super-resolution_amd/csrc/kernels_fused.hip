@@ -38,6 +38,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 #ifndef SRAD_MLP_NSETS16
 #define SRAD_MLP_NSETS16 3
 #endif
+// split-bf16: 1 = a register set holds the hi AND the lo weights of a stage (two sets; an activation fragment is read from LDS
+// once per plane and meets both), 0 = hi and lo stream as half stages through four sets (the hi plane is read twice)
+#ifndef SRAD_X3_FULLSTAGE
+#define SRAD_X3_FULLSTAGE 1
+#endif
 constexpr int F_LDA = 392;         // LDS row stride of the <=384-wide bf16 activation tile
 constexpr int F_LDH = 520;         // LDS row stride of the <=512-wide hidden tile
 constexpr int F_SC = 128;          // output columns per weight stage
@@ -97,7 +102,9 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
   constexpr int Kd = KCD * 32, Km = KCM * 32;                    // packed K of the weights
   constexpr int n_proj = GD * KGD, n_fc1 = GM * KGD, n_fc2 = GD * KGM, n_adj = GN * KGD;
   constexpr int n_stages = n_proj + n_fc1 + n_fc2 + n_adj;
-  constexpr int NPART = SPLIT ? 2 : 1;                           // weight streams per stage (hi | hi, lo)
+  constexpr bool FULLST = SPLIT && SRAD_X3_FULLSTAGE;
+  constexpr int NPART = (SPLIT && !FULLST) ? 2 : 1;              // weight streams per stage (hi | hi, lo)
+  constexpr int RPS = FULLST ? 16 : 8;                           // registers (32-wide k chunks) per set
   constexpr int n_vst = n_stages * NPART;                        // (stage, part) pairs in stream order
   // offsets of the staged vectors
   float* const v_bp = vec; float* const v_b1 = vec + 384; float* const v_b2 = vec + 896; float* const v_ba = vec + 1280;
@@ -123,9 +130,9 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
   // 8 waves (two per SIMD), each owns 16 output columns of a 128-column stage, i.e. 16 rows of the packed weight that
   // NOBODY else reads: the weights go straight from global memory into MFMA fragment registers, three stages ahead (no
   // LDS stage, no barrier per stage), from the fragment-major pack (one contiguous kilobyte per wave load).
-  constexpr int NSETS = SPLIT ? 4 : (FM == 16 ? SRAD_MLP_NSETS16 : 3);   // 16-row tiles leave ~100 VGPRs free at 2 waves per SIMD: deeper weight stream
-  u32x4 w_reg[NSETS][8];
-  auto load_w = [&](auto S, u32x4 (&reg)[8]) __attribute__((always_inline)) {
+  constexpr int NSETS = FULLST ? 2 : (SPLIT ? 4 : (FM == 16 ? SRAD_MLP_NSETS16 : 3));   // 16-row tiles leave ~100 VGPRs free at 2 waves per SIMD: deeper weight stream
+  u32x4 w_reg[NSETS][RPS];
+  auto load_w = [&](auto S, u32x4 (&reg)[RPS]) __attribute__((always_inline)) {
     constexpr int vs = decltype(S)::value < n_vst - 1 ? decltype(S)::value : n_vst - 1;
     constexpr StageGeo sg = geo(vs / NPART);
     constexpr bool lo = (vs % NPART) == 1;
@@ -143,16 +150,35 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     const int step = live ? 1024 : 0;
 #pragma unroll
     for (int cc = 0; cc < sg.nch; ++cc) reg[cc] = *reinterpret_cast<const u32x4*>(base + cc * step);
+    if constexpr (FULLST) {                                         // the lo terms of the same fragments: same offsets in the lo pack
+      const char* wl = (const char*)(sg.ph == 0 ? p.w_proj_lo : (sg.ph == 1 ? p.w_fc1_lo : (sg.ph == 2 ? p.w_fc2_lo : p.w_adj_lo)));
+      const char* bl = wl + (base - w);
+#pragma unroll
+      for (int cc = 0; cc < sg.nch; ++cc) reg[8 + cc] = *reinterpret_cast<const u32x4*>(bl + cc * step);
+    }
   };
   // c[rt] += (A[16 rows][k0 .. k0 + nch*32) . W[16 columns of this wave][..]^T)^T
   // (split-bf16: `reg` holds the hi weights and both planes of A are multiplied - AL = the lo plane -, or the lo weights
   // against the hi plane only: AL = null)
-  auto mma_stage = [&](const __bf16* A, const __bf16* AL, int lda, int k0, int nch, const u32x4 (&reg)[8], f32x4 (&c)[NRT]) __attribute__((always_inline)) {
+  auto mma_stage = [&](const __bf16* A, const __bf16* AL, int lda, int k0, int nch, const u32x4 (&reg)[RPS], f32x4 (&c)[NRT]) __attribute__((always_inline)) {
     const __bf16* ar = A + fr * lda + k0 + 8 * fq;
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
       if (cc < nch) {
         const bf16x8 b0 = __builtin_bit_cast(bf16x8, reg[cc]);
+        if constexpr (FULLST) {                                     // W_hi.A_lo, W_lo.A_hi, W_hi.A_hi: each plane read once
+          const bf16x8 bl = __builtin_bit_cast(bf16x8, reg[8 + cc]);
+          const __bf16* al = AL + fr * lda + k0 + 8 * fq;
+#pragma unroll
+          for (int rt = 0; rt < NRT; ++rt) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + rt * 16 * lda + cc * 32);
+            const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(al + rt * 16 * lda + cc * 32);
+            c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a2, c[rt], 0, 0, 0);
+            c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, a, c[rt], 0, 0, 0);
+            c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, c[rt], 0, 0, 0);
+          }
+          continue;
+        }
         if constexpr (SPLIT) {
           if (AL) {
             const __bf16* al = AL + fr * lda + k0 + 8 * fq;
@@ -414,7 +440,7 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     constexpr int ls = s - (ph == 0 ? 0 : (ph == 1 ? n_proj : (ph == 2 ? n_proj + n_fc1 : n_proj + n_fc1 + n_fc2)));
     constexpr int kgs = ph == 2 ? KGM : KGD;
     constexpr int g = ls / kgs, kg = ls - g * kgs;
-    u32x4 (&reg)[8] = w_reg[vs % NSETS];
+    u32x4 (&reg)[RPS] = w_reg[vs % NSETS];
     constexpr int Kp = ph == 2 ? Km : Kd;
     constexpr int nch = (Kp >> 5) - kg * 8 < 8 ? (Kp >> 5) - kg * 8 : 8;
     if constexpr (ls == 0 && part == 0) {
@@ -429,7 +455,7 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     }
     const bool live = (g * 8 + wave_s) * 16 < (ph == 0 ? d : (ph == 1 ? m : (ph == 2 ? d : no)));
     if (!(dbg & 2) && live)
-      mma_stage(ph == 2 ? Hs : A1, (SPLIT && part == 0) ? (ph == 2 ? HsL : A1L) : nullptr, ph == 2 ? F_LDH : F_LDA, kg * 256, nch, reg, c);
+      mma_stage(ph == 2 ? Hs : A1, (SPLIT && part == 0) ? (ph == 2 ? HsL : A1L) : nullptr, ph == 2 ? F_LDH : F_LDA, kg * 256, nch, reg, c);   // (part == 0 always when a set holds both packs)
     // refill this set, NSETS stages ahead.  Issuing a load can block (the queue is full while the weights stream), so where
     // an epilogue follows that other waves wait for (LayerNorm2, the tile hand-overs) the refill goes behind it
     constexpr bool epi_first = kg == kgs - 1 && part == NPART - 1;

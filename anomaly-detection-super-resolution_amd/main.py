@@ -63,7 +63,7 @@ def _train(opt, dual_model: bool) -> None:
             eval_opt = copy.deepcopy(opt)
             eval_opt.test_only, eval_opt.no_augment, eval_opt.batch_size = True, True, 1
             eval_opt.data_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.normpath(opt.data_dir))), 'val', 'good')
-            eval_opt.data_test = opt.data_test = 'mvtec_val_good'
+            eval_opt.data_test = 'mvtec_val_good'               # eval_opt only (src/main.py:322,374): the run's log lines / results dir keep its own data_test
             t.loader_test = Data(eval_opt).loader_test
             t.test()
         except Exception as e:                                  # the reference prints and carries on

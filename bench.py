@@ -22,7 +22,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}      # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK = {"bf16": 2.5e15, "fp32": 157.3e12, "bf16x3": 2.5e15}      # dense MFMA peaks, MI355X_MICROARCH.md (split-bf16 runs on the bf16 pipe)
 HBM_PEAK = 8.0e12
 CSRC = os.path.join(ROOT, "anomaly-detection-super-resolution_amd", "csrc")
 
@@ -126,25 +126,27 @@ def anomaly_eval_leg(model, args, torch):
         ref = O.evaluate_pairs(y, o_sr, hr_u8)
         out["auc_oracle"] = {k: round(ref[k], 4) for k in ("auc_ssim", "auc_mse", "auc_psnr")}
         out["auc_abs_diff"] = round(max(abs(got[k] - ref[k]) for k in ("auc_ssim", "auc_mse", "auc_psnr")), 5)
-        # the parity mode (exact-fp32 MFMA) on the same split
+        # the modes that own the AUC +-0.002 claim on the same split: split-bf16 (the evaluator's default) and exact fp32
         from srad_amd.nets import DRCT
-        o32 = Opt()
-        o32.precision, o32.use_graph = "fp32", False
-        m32 = DRCT(o32).to(next(model.parameters()).device).eval()
-        m32.load_state_dict(model.state_dict())
-        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
-            g32 = E.evaluate_on_test(EvalOpt, m32, good, bad)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                E.evaluate_on_test(EvalOpt, m32, good, bad)
-            torch.cuda.synchronize()
-            dt32 = (time.perf_counter() - t0) / reps
-        out["auc_abs_diff_fp32_mode"] = round(max(abs(g32[k] - ref[k]) for k in ("auc_ssim", "auc_mse", "auc_psnr")), 5)
-        out["images_per_s_fp32_mode"] = round(len(pairs) / dt32, 1)
+        for mode in ("bf16x3", "fp32"):
+            o32 = Opt()
+            o32.precision, o32.use_graph = mode, False
+            m32 = DRCT(o32).to(next(model.parameters()).device).eval()
+            m32.load_state_dict(model.state_dict())
+            with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+                g32 = E.evaluate_on_test(EvalOpt, m32, good, bad)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    E.evaluate_on_test(EvalOpt, m32, good, bad)
+                torch.cuda.synchronize()
+                dt32 = (time.perf_counter() - t0) / reps
+            out[f"auc_abs_diff_{mode}_mode"] = round(max(abs(g32[k] - ref[k]) for k in ("auc_ssim", "auc_mse", "auc_psnr")), 5)
+            out[f"images_per_s_{mode}_mode"] = round(len(pairs) / dt32, 1)
+            del m32
         out["auc_parity_note"] = (f"HIP engine vs fp32 CPU oracle, same random-init weights (AUC is near chance, so rankings are "
-                                  f"noise-sensitive).  The evaluator's DEFAULT is the fp32 parity mode (evaluate --dtype fp32): identical "
-                                  f"AUCs, bar +-0.002 met; '{args.dtype}' is the opt-in fast mode this leg times")
+                                  f"noise-sensitive).  The evaluator's DEFAULT is the split-bf16 mode (evaluate --dtype bf16x3): "
+                                  f"bar +-0.002; '{args.dtype}' is the opt-in fast mode this leg's headline images/s times")
     return out
 
 
@@ -373,7 +375,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -393,13 +395,23 @@ def rank_plan(args, env=None):
     return launch_plan(args.gpus, env=env)
 
 
-def parity_mode_leg(model, x, y_bf16, args, torch, dev):
-    """The mode that owns the 1e-3 parity claim: the same C2 forward in fp32 mode (exact-fp32 MFMA v_mfma_f32_16x16x4_f32, the
-    unfused launches), timed like the headline (graph replay), with its own roofline against the 157.3 TFLOP/s fp32 peak."""
+PARITY_MODES = {
+    # name: (what, peak the roofline is priced against, MFMA issues per algorithmic product)
+    "bf16x3": ("C2 forward in the split-bf16 parity mode (hi + lo bf16 operands, three bf16 MFMAs per product, fp32 accumulate; "
+               "the same two fused launches per Swin block as the bf16 headline)", PEAK["bf16"]),
+    "fp32": ("C2 forward in the fp32 mode (exact-fp32 MFMA, six launches per Swin block)", PEAK["fp32"]),
+}
+
+
+def parity_mode_leg(model, x, y_bf16, args, torch, dev, mode="bf16x3"):
+    """A mode that meets the 1e-3 parity bar on the same C2 forward, timed like the headline (graph replay), with its own
+    roofline: "bf16x3" = split-bf16 (the evaluator's default; algorithmic FLOPs against the bf16 dense peak - the three MFMAs per
+    product are the mode's cost, not extra work), "fp32" = exact-fp32 MFMA v_mfma_f32_16x16x4_f32 against the 157.3 TFLOP/s peak."""
     from srad_amd import _lib as L
     from srad_amd.nets import DRCT
+    what, peak = PARITY_MODES[mode]
     o32 = Opt()
-    o32.precision, o32.use_graph = "fp32", not args.no_graph
+    o32.precision, o32.use_graph = mode, not args.no_graph
     m32 = DRCT(o32).to(dev).eval()
     m32.load_state_dict(model.state_dict())
     steps = max(10, min(args.steps, 50))
@@ -428,13 +440,13 @@ def parity_mode_leg(model, x, y_bf16, args, torch, dev):
     dom = max(prof, key=lambda k: prof[k]["ms"])
     d = prof[dom]
     ach = d["flops"] / (d["ms"] * 1e-3)
-    out = {"dtype": "fp32", "what": "C2 forward in the fp32 parity mode (exact-fp32 MFMA, six launches per Swin block)",
+    out = {"dtype": mode, "what": what,
            "ms_per_step": round(dt * 1e3, 4), "hr_mpixels_per_s": round(B * H * 4 * W * 4 / dt / 1e6, 3),
            "model_tflops": round(flops / dt / 1e12, 2),
-           "roofline": {"kernel": dom, "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": PEAK["fp32"] / 1e12,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK["fp32"], 4), "traffic": None,
+           "roofline": {"kernel": dom, "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": peak / 1e12,
+                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                         "launches_per_step": d["launches"] // reps, "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 3)},
-           "bf16_vs_fp32_mode_max_rel": float(f"{float((y_bf16 - y32).abs().max() / y32.abs().max()):.3e}")}
+           "headline_bf16_vs_this_mode_max_rel": float(f"{float((y_bf16 - y32).abs().max() / y32.abs().max()):.3e}")}
     return out, y32, m32
 
 
@@ -569,13 +581,18 @@ def run_rank(args):
                                  "gbytes_per_s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
                              for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
 
-        y32 = None
+        y32, yf32 = None, None
         if n_gpus == 1:
             try:
-                result["parity_mode"], y32, m32 = parity_mode_leg(model, x, y, args, torch, dev)
+                result["parity_mode"], y32, m32 = parity_mode_leg(model, x, y, args, torch, dev, "bf16x3")
                 del m32
             except Exception as e:
                 result["parity_mode"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                result["fp32_mode"], yf32, m32 = parity_mode_leg(model, x, y, args, torch, dev, "fp32")
+                del m32
+            except Exception as e:
+                result["fp32_mode"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and n_gpus == 1:
             # the reference's --device cpu path, restated (oracle), same weights, same batch, fp32
             from oracle import sr_ref as R
@@ -600,10 +617,11 @@ def run_rank(args):
                                                 f"the cores this job may use, host has {os.cpu_count()} logical cores"}
             result["speedup_vs_cpu"] = round(value / (hr_px / cpu_t / 1e6), 1)
             result["max_rel_err_vs_cpu_fp32"] = float(f"{err:.3e}")
-            if y32 is not None and isinstance(result.get("parity_mode"), dict) and "error" not in result["parity_mode"]:
-                e32 = float((y32.cpu() - ref).abs().max() / ref.abs().max())
-                result["parity_mode"]["max_rel_err_vs_cpu_fp32"] = float(f"{e32:.3e}")
-                result["parity_mode"]["speedup_vs_cpu"] = round(result["parity_mode"]["hr_mpixels_per_s"] / (hr_px / cpu_t / 1e6), 1)
+            for key, yy in (("parity_mode", y32), ("fp32_mode", yf32)):
+                if yy is not None and isinstance(result.get(key), dict) and "error" not in result[key]:
+                    e32 = float((yy.cpu() - ref).abs().max() / ref.abs().max())
+                    result[key]["max_rel_err_vs_cpu_fp32"] = float(f"{e32:.3e}")
+                    result[key]["speedup_vs_cpu"] = round(result[key]["hr_mpixels_per_s"] / (hr_px / cpu_t / 1e6), 1)
         if n_gpus == 1 and not args.no_eval:
             result["anomaly_eval"] = anomaly_eval_leg(model, args, torch)
             try:

@@ -99,6 +99,22 @@ def test_conv3x3_80_channels_weight_resident_kernel(dev, B, H, W, mode):
     assert _rel(y, ref) < 1e-4
 
 
+def test_conv80_eligible_shape_with_gelu_is_not_sent_to_the_weight_resident_kernel(dev):
+    """conv80's epilogue implements none / ReLU / LeakyReLU; an 80 -> 80 3x3 convolution with another activation at a
+    conv80-eligible shape must take the tiled GEMM (which applies GELU) instead of silently dropping the activation."""
+    from srad_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(9)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    B, H, W = 2, 64, 64
+    x = bf(torch.randn(B, 80, H, W, generator=g)).to(dev)
+    w = bf(torch.randn(80, 80, 3, 3, generator=g) / math.sqrt(720)).to(dev)
+    b = torch.randn(80, generator=g).to(dev)
+    xn = x.permute(0, 2, 3, 1).reshape(-1, 80).clone(memory_format=torch.contiguous_format)
+    y = ops.gemm(xn, w, b, B=B, H=H, W=W, act=1, precision="bf16")
+    ref = F.gelu(F.conv2d(x, w, b, padding=1)).permute(0, 2, 3, 1).reshape(-1, 80)
+    assert _rel(y, ref) < 1e-3, _rel(y, ref)
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16", "bf16x3"])
 def test_conv_pixel_shuffle(dev, prec):
     from srad_amd import ops

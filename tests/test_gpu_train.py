@@ -229,12 +229,12 @@ def test_cli_train_writes_a_run_dir_the_evaluator_resolves_from_config_txt(tmp_p
     assert sorted(os.listdir(os.path.join(run, "model"))) == ["model_best.pt", "model_latest.pt"]
     log = open(os.path.join(run, "log.txt")).read()
     assert "[Epoch 1]\tLearning rate: 1.00e-4" in log and "[Epoch 2]\tLearning rate: 5.0" in log      # cosine, T_max = 2: 5.005e-5
-    assert log.count("[L1: ") == 6 and "[mvtec_val_good x4]\tPSNR:" in log and "Total Training Time" in log
+    assert log.count("[L1: ") == 6 and "[ x4]\tPSNR:" in log and "Total Training Time" in log
     loss_log = torch.load(os.path.join(run, "loss_log.pt"))
     assert tuple(loss_log.shape) == (2, 1) and float(loss_log[1, 0]) < float(loss_log[0, 0])
     pl = torch.load(os.path.join(run, "psnr_ssim_log.pt"))
     assert tuple(pl.shape) == (1, 2) and float(pl[0, 0]) > 5 and 0 < float(pl[0, 1]) <= 1
-    assert sorted(os.listdir(os.path.join(run, "results", "mvtec_val_good", "x4"))) == ["100.png", "101.png"]
+    assert sorted(os.listdir(os.path.join(run, "results", "x4"))) == ["100.png", "101.png"]
     osd = torch.load(os.path.join(run, "optimizer.pt"))
     assert osd["step"] == 6 and osd["exp_avg"].numel() > 1e6
     cfg = open(os.path.join(run, "config.txt")).read()
