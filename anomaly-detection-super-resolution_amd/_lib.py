@@ -135,6 +135,10 @@ _SIG = {
     "srad_op_window_attn": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, _P]),
     "srad_op_layernorm": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "srad_op_window_attn_qscale": (C.c_float, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "srad_op_ln_qkv_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "srad_op_ln_qkv": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_float, _P, C.c_size_t, _P]),
+    "srad_op_window_attn_bf16_in": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     # backward operators
     "srad_op_wgrad": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, _P, C.c_float, _P, _P, _P, _P]),

@@ -471,6 +471,40 @@ int srad_op_window_attn(int precision, const float* qkv, float* out, const float
   return srad_launch_window_attn(precision, a, reinterpret_cast<hipStream_t>(stream));
 }
 
+// ---- the two kernels of the 64 x 64-window attention of BASELINE config C5 (bf16), each on its own ----
+// the factor q carries into the attention's bf16 operands (head_dim^-0.5 * log2 e), or 0 when this geometry does not take
+// the bf16-operand path (srad_window_attn_bf16_in)
+float srad_op_window_attn_qscale(int ws, int shift, int d, int heads) {
+  float qs = 0.f;
+  return srad_window_attn_bf16_in(SRAD_PREC_BF16, ws, shift, d, heads, &qs) ? qs : 0.f;
+}
+size_t srad_op_ln_qkv_scratch_bytes(int d, int heads) { return srad_align_up(srad_qkv_frag_bytes(d, heads > 0 ? heads : 1), 256); }
+// LayerNorm1 + attn.qkv (src/drct.py:477, 278) -> qkv_h [M][3][heads][hdp] bf16: q times qscale, padding columns 0, column
+// head_dim of every v slice 1 (ln_qkv_kernel).  M % 64 == 0.
+int srad_op_ln_qkv(const float* x, int ldx, int M, int d, int heads, const float* ln_g, const float* ln_b, const float* w_qkv,
+                   const float* b_qkv, void* qkv_h, int hdp, float qscale, void* scratch, size_t scratch_bytes, void* stream) {
+  SRAD_REQUIRE(x && ln_g && ln_b && w_qkv && b_qkv && qkv_h && scratch, "op_ln_qkv: null argument");
+  SRAD_REQUIRE(srad_ln_qkv_supported(SRAD_PREC_BF16, M, d, heads), "op_ln_qkv: unsupported shape M=%d d=%d heads=%d", M, d, heads);
+  SRAD_REQUIRE(scratch_bytes >= srad_op_ln_qkv_scratch_bytes(d, heads) && ((uintptr_t)scratch & 255) == 0, "op_ln_qkv: scratch too small or not 256-byte aligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  SRAD_TRY(srad_launch_pack_qkv_frag(w_qkv, scratch, d, heads, s));
+  LnQkvParams q{};
+  q.x = x; q.ldx = ldx; q.M = M; q.d = d; q.heads = heads; q.ln_g = ln_g; q.ln_b = ln_b; q.w_qkv = scratch; q.b_qkv = b_qkv;
+  q.qkv_h = reinterpret_cast<__bf16*>(qkv_h); q.hdp = hdp; q.qscale = qscale;
+  return srad_launch_ln_qkv(q, s);
+}
+// the attention on those operands (window_attn_kernel, ROW64 / QH path; src/drct.py:281-299 + roll / partition / reverse):
+// qkv_h as above -> out [B*H*W][d] fp32
+int srad_op_window_attn_bf16_in(const void* qkv_h, float* out, const float* table, int B, int H, int W, int ws, int shift, int d,
+                                int heads, int hdp, void* stream) {
+  SRAD_REQUIRE(qkv_h && out && table, "op_window_attn_bf16_in: null argument");
+  float qs = 0.f;
+  SRAD_REQUIRE(srad_window_attn_bf16_in(SRAD_PREC_BF16, ws, shift, d, heads, &qs), "op_window_attn_bf16_in: this geometry does not take bf16 operands");
+  AttnParams a{nullptr, out, table, B, H, W, ws, shift, d, heads, hdp};
+  a.qkv_h = reinterpret_cast<const __bf16*>(qkv_h);
+  return srad_launch_window_attn(SRAD_PREC_BF16, a, reinterpret_cast<hipStream_t>(stream));
+}
+
 int srad_op_layernorm(const float* x, int ldx, float* y, int ldy, int rows, int C, const float* g, const float* b,
                       void* stream) {
   SRAD_REQUIRE(x && y && g && b, "op_layernorm: null argument");

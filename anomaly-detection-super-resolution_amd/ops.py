@@ -286,6 +286,39 @@ def lin_ln_bwd(dy: torch.Tensor, w: torch.Tensor, x: torch.Tensor, gamma: torch.
     return out, dg, db
 
 
+# ----------------------------------------------------------------------------------- C5: the 64 x 64-window attention's two kernels
+def ln_qkv(x: torch.Tensor, ln_g: torch.Tensor, ln_b: torch.Tensor, w_qkv: torch.Tensor, b_qkv: torch.Tensor, heads: int,
+           ws: int = 64, shift: int = 0) -> torch.Tensor:
+    """norm1 + attn.qkv in one launch (``srad_op_ln_qkv``; src/drct.py:477, 278) -> the bf16 operands of the 64 x 64-window
+    attention, [M, 3, heads, hdp]: q times head_dim^-0.5 log2 e, padding 0, column head_dim of the v slices 1."""
+    _need_cuda(x, ln_g, ln_b, w_qkv, b_qkv)
+    d = w_qkv.shape[1]
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32 and w_qkv.shape[0] == 3 * d
+    qs = L.lib().srad_op_window_attn_qscale(ws, shift, d, heads)
+    if qs == 0.0:
+        raise ValueError(f"window {ws} / shift {shift} / head dim {d // heads}: not the bf16-operand attention path")
+    hdp = (d // heads + 3) // 4 * 4
+    f = lambda t: t.detach().float().contiguous()
+    keep = [f(ln_g), f(ln_b), f(w_qkv), f(b_qkv)]
+    out = torch.empty(x.shape[0], 3, heads, hdp, dtype=torch.bfloat16, device=x.device)
+    sbuf, sp, sb = _scratch(L.lib().srad_op_ln_qkv_scratch_bytes(d, heads), x.device)
+    L.check(L.lib().srad_op_ln_qkv(L.dptr(x), x.stride(0), x.shape[0], d, heads, L.dptr(keep[0]), L.dptr(keep[1]), L.dptr(keep[2]),
+                                   L.dptr(keep[3]), L.dptr(out), hdp, float(qs), sp, sb, L.current_stream_ptr()), "op_ln_qkv")
+    return out
+
+
+def window_attention_bf16_in(qkv_h: torch.Tensor, table: torch.Tensor, B: int, H: int, W: int, ws: int, shift: int, d: int) -> torch.Tensor:
+    """WindowAttention on ``ln_qkv``'s operands (``srad_op_window_attn_bf16_in``; src/drct.py:281-299, 482-504) -> [B*H*W, d] fp32."""
+    _need_cuda(qkv_h, table)
+    T, three, heads, hdp = qkv_h.shape
+    assert three == 3 and T == B * H * W and qkv_h.dtype == torch.bfloat16 and qkv_h.is_contiguous()
+    tb = table.detach().float().contiguous()
+    out = torch.empty(T, d, dtype=torch.float32, device=qkv_h.device)
+    L.check(L.lib().srad_op_window_attn_bf16_in(L.dptr(qkv_h), L.dptr(out), L.dptr(tb), B, H, W, ws, shift, d, heads, hdp,
+                                                L.current_stream_ptr()), "op_window_attn_bf16_in")
+    return out
+
+
 # ----------------------------------------------------------------------------------- fused Swin-block halves (bf16, window 8)
 def qkv_attn(x: torch.Tensor, ln_g: torch.Tensor, ln_b: torch.Tensor, w_qkv: torch.Tensor, b_qkv: torch.Tensor,
              table: torch.Tensor, B: int, H: int, W: int, shift: int, heads: int, out_bf16: bool = False,

@@ -29,27 +29,28 @@ from .train import (FusedAdam, GradReducer, GraphedTrainStep, TensorAdam, cosine
 
 
 class timer():
-    """src/trainer.py:21-42 (wall-clock accumulate / release)."""
+    """Stopwatch with an accumulator - the interface of the reference's timer (src/trainer.py:21-42): ``tic`` restarts the
+    lap, ``toc`` reads it, ``hold`` adds the lap to ``acc``, ``release`` returns ``acc`` and clears it."""
+    __slots__ = ("acc", "t0")
 
     def __init__(self):
-        self.acc = 0
-        self.tic()
+        self.acc, self.t0 = 0.0, time.perf_counter()
 
-    def tic(self):
-        self.t0 = time.time()
+    def tic(self) -> None:
+        self.t0 = time.perf_counter()
 
-    def toc(self):
-        return time.time() - self.t0
+    def toc(self) -> float:
+        return time.perf_counter() - self.t0
 
-    def hold(self):
+    def hold(self) -> None:
         self.acc += self.toc()
 
-    def release(self):
-        ret, self.acc = self.acc, 0
-        return ret
+    def release(self) -> float:
+        held, self.acc = self.acc, 0.0
+        return held
 
-    def reset(self):
-        self.acc = 0
+    def reset(self) -> None:
+        self.acc = 0.0
 
 
 def quantize(img, rgb_range):
@@ -200,46 +201,51 @@ class Trainer():
             self.error_last = self.loss.log[-1, -1]
         self.step()
 
+    def _validate(self, s: int):
+        """One pass over ``loader_test`` at scale ``s``: SR -> round to the u8 grid -> PSNR / SSIM against HR (images that come
+        without HR are only super-resolved and saved).  Returns the two sums."""
+        psnr_sum = ssim_sum = 0.0
+        for lr, hr, names in self.loader_test:
+            has_hr = hr.nelement() != 1                              # the loader's placeholder for "no ground truth" is one element
+            if has_hr:
+                lr, hr = self.prepare(lr, hr)
+            else:
+                lr, = self.prepare(lr)
+            sr = self.model(lr[0])
+            sr = quantize(sr[-1] if isinstance(sr, list) else sr, self.opt.rgb_range)
+            if has_hr:
+                psnr_sum += M.psnr_torch(sr, hr, self.opt.rgb_range)
+                ssim_sum += M.ssim_torch(sr, hr, self.opt.rgb_range, win_size=11)
+            if self.opt.save_results and self.rank == 0:
+                self.ckp.save_results_nopostfix(names[0], sr, s)
+        return psnr_sum, ssim_sum
+
     def test(self):
+        """src/trainer.py:242-304: validation PSNR / SSIM of the largest scale into a new row of ``ckp.log``, the reference's
+        result line (current value, best value and its epoch), back to train mode."""
         self._log('\nEvaluation:')
         self.ckp.add_log(torch.zeros(1, 2))
         self.model.eval()
-        timer_test = timer()
+        watch = timer()
+        n = len(self.loader_test)
+        table = self.ckp.log
         with torch.no_grad():
-            scale = max(self.scale)
-            for si, s in enumerate([scale]):
-                eval_psnr = 0
-                eval_ssim = 0
-                for _, (lr, hr, filename) in enumerate(self.loader_test):
-                    filename = filename[0]
-                    no_eval = (hr.nelement() == 1)
-                    if not no_eval:
-                        lr, hr = self.prepare(lr, hr)
-                    else:
-                        lr, = self.prepare(lr)
-                    sr = self.model(lr[0])
-                    if isinstance(sr, list):
-                        sr = sr[-1]
-                    sr = quantize(sr, self.opt.rgb_range)
-                    if not no_eval:
-                        eval_psnr += M.psnr_torch(sr, hr, self.opt.rgb_range)
-                        eval_ssim += M.ssim_torch(sr, hr, self.opt.rgb_range, win_size=11)
-                    if self.opt.save_results and self.rank == 0:
-                        self.ckp.save_results_nopostfix(filename, sr, s)
-                self.ckp.log[-1, si] = eval_psnr / len(self.loader_test)
-                self.ckp.log[-1, si * 2 + 1] = eval_ssim / len(self.loader_test)
-                best = self.ckp.log.max(0)
+            for si, s in enumerate([max(self.scale)]):
+                psnr_sum, ssim_sum = self._validate(s)
+                # the reference stores PSNR at column si and SSIM at column 2 si + 1 and reads PSNR back from column 2 si
+                # (the same cell for its single scale): kept
+                table[-1, si], table[-1, 2 * si + 1] = psnr_sum / n, ssim_sum / n
+                top, at = table.max(0)
                 self._log('[{} x{}]\tPSNR: {:.2f} (Best: {:.2f} @epoch {})\tSSIM: {:.4f} (Best: {:.4f} @epoch {})'.format(
-                    self.opt.data_test, s, self.ckp.log[-1, si * 2], best[0][si * 2], best[1][si * 2] + 1,
-                    self.ckp.log[-1, si * 2 + 1], best[0][si * 2 + 1], best[1][si * 2 + 1] + 1))
-        self._log('Total time: {:.2f}s\n'.format(timer_test.toc()), refresh=True)
+                    self.opt.data_test, s, table[-1, 2 * si], top[2 * si], at[2 * si] + 1,
+                    table[-1, 2 * si + 1], top[2 * si + 1], at[2 * si + 1] + 1))
+        self._log('Total time: {:.2f}s\n'.format(watch.toc()), refresh=True)
         self.model.train()
 
     def step(self):
-        self.scheduler.step()
-        if self.dual_model:
-            for sch in self.dual_scheduler:
-                sch.step()
+        """End of an epoch: every cosine schedule advances once (src/trainer.py:312-316)."""
+        for sch in [self.scheduler] + (list(self.dual_scheduler) if self.dual_model else []):
+            sch.step()
 
     def prepare(self, *args):
         device = self.model.device if hasattr(self.model, 'device') else self.device
@@ -248,7 +254,8 @@ class Trainer():
         return [a.to(device, non_blocking=True) for a in args[0]],
 
     def terminate(self):
-        if self.opt.test_only:
-            self.test()
-            return True
-        return self.scheduler.last_epoch >= self.opt.epochs
+        """True when the run is over; a ``test_only`` run validates once on the way out (src/trainer.py:332-340)."""
+        if not self.opt.test_only:
+            return self.scheduler.last_epoch >= self.opt.epochs
+        self.test()
+        return True

@@ -254,6 +254,20 @@ int srad_op_mlp_block(int precision, int M, int d, int m, int no, int fm, const 
                       float slope, float alpha, const float* r, int ldr, float* y, int ldy, int yoff, void* scratch,
                       size_t scratch_bytes, void* stream);
 
+/* The two kernels of BASELINE config C5's attention (bf16, 64 x 64 windows = 4096-token windows; src/main.py:286), each on its own:
+ *   srad_op_ln_qkv              norm1 + attn.qkv (src/drct.py:477, 278) -> qkv_h [M][3][heads][hdp] bf16, the attention's MFMA
+ *                               operands: q times qscale (= head_dim^-0.5 log2 e, srad_op_window_attn_qscale), padding columns 0,
+ *                               column head_dim of every v slice 1 (P.V then also yields the softmax denominator); M % 64 == 0
+ *   srad_op_window_attn_bf16_in WindowAttention.forward on those operands (src/drct.py:281-299 and the roll / partition / reverse
+ *                               around it, 482-504): online softmax over 64-key chunks = rows of the window, relative position
+ *                               bias rows sliding through an LDS ring, 0 / -100 shift mask; out [B*H*W][d] fp32 */
+float srad_op_window_attn_qscale(int ws, int shift, int d, int heads);
+size_t srad_op_ln_qkv_scratch_bytes(int d, int heads);
+int srad_op_ln_qkv(const float* x, int ldx, int M, int d, int heads, const float* ln_g, const float* ln_b, const float* w_qkv,
+                   const float* b_qkv, void* qkv_h, int hdp, float qscale, void* scratch, size_t scratch_bytes, void* stream);
+int srad_op_window_attn_bf16_in(const void* qkv_h, float* out, const float* table, int B, int H, int W, int ws, int shift, int d,
+                                int heads, int hdp, void* stream);
+
 /* Backward operators (autograd of the rows above).
  * Weight/bias gradient of Linear / conv: dw[N][Cin][taps] += alpha * dy^T A(x), db[N] += alpha * colsum(dy);
  * dy [B*Ho*Wo][ldy], x [B*Hi*Wi][ldx]; N, Cin multiples of 4; row_scale optional per-sample factor [B].

@@ -68,19 +68,33 @@ def rel_pos_index(ws: int) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------ DRCT
-def attention_core(sd, p: str, x: torch.Tensor, ws: int, heads: int, mask, rnd=None) -> torch.Tensor:
+def attention_core(sd, p: str, x: torch.Tensor, ws: int, heads: int, mask, rnd=None, q_fold: float = 1.0,
+                   online_chunk: int = 0) -> torch.Tensor:
     """src/drct.py:271-299 (everything of WindowAttention.forward before ``proj``).  x: [B_, N, C] -> [B_, N, C].
     ``rnd`` (tests of the bf16 kernels only): the rounding the engine's bf16 mode applies to MFMA operands - q (after the
-    scale), k, v and the un-normalised probabilities exp(s - max); the row sum stays fp32 and un-rounded, as in the kernels."""
+    scale), k, v and the un-normalised probabilities exp(s - max); the row sum stays fp32 and un-rounded, as in the kernels.
+    ``q_fold`` (with ``rnd``): a constant the kernel folds into q BEFORE rounding it (the 64 x 64-window kernel works in the
+    log2 domain: q carries log2 e); the rounded value is divided back, so the arithmetic is unchanged up to that rounding.
+    ``online_chunk`` (with ``rnd``): the rounding points of a streaming-softmax kernel that walks the keys in chunks of this
+    many - each chunk's probabilities are exp(s - RUNNING max) when they are rounded, earlier partial sums are rescaled in fp32,
+    and the denominator is summed from the ROUNDED probabilities (the 64 x 64-window kernel gets it out of P.V through a column
+    of ones in V).  Mathematically the same softmax; only where the bf16 roundings fall differs."""
     B_, N, C = x.shape
     qkv = F.linear(x, _t(sd, p + "qkv.weight"), _t(sd, p + "qkv.bias"))
     qkv = qkv.reshape(B_, N, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
     q = q * ((C // heads) ** -0.5)
+    out = attention_from_qkv(q, k, v, _t(sd, p + "relative_position_bias_table"), ws, mask, rnd, q_fold, online_chunk)
+    return out.transpose(1, 2).reshape(B_, N, C)
+
+
+def attention_from_qkv(q, k, v, table, ws: int, mask, rnd=None, q_fold: float = 1.0, online_chunk: int = 0) -> torch.Tensor:
+    """src/drct.py:282-299: softmax(q k^T + relative position bias + mask) v for q (ALREADY times head_dim^-0.5), k, v of shape
+    [B_, heads, N, head_dim] -> [B_, heads, N, head_dim].  The hooks are ``attention_core``'s."""
+    B_, heads, N, _ = q.shape
     if rnd is not None:
-        q, k, v = rnd(q), rnd(k), rnd(v)
+        q, k, v = rnd(q * q_fold) / q_fold, rnd(k), rnd(v)
     attn = q @ k.transpose(-2, -1)
-    table = _t(sd, p + "relative_position_bias_table")
     idx = rel_pos_index(ws)
     bias = table[idx.view(-1)].view(N, N, -1).permute(2, 0, 1).contiguous()
     attn = attn + bias.unsqueeze(0)
@@ -91,10 +105,23 @@ def attention_core(sd, p: str, x: torch.Tensor, ws: int, heads: int, mask, rnd=N
     if rnd is None:
         attn = torch.softmax(attn, dim=-1)
         out = attn @ v
+    elif online_chunk > 0:
+        m = torch.full(attn.shape[:-1] + (1,), -1e30)
+        num = torch.zeros(attn.shape[:-1] + (v.shape[-1],))
+        den = torch.zeros_like(m)
+        for c in range(0, N, online_chunk):
+            sc = attn[..., c:c + online_chunk]
+            mnew = torch.maximum(m, sc.amax(-1, keepdim=True))
+            alpha = torch.exp(m - mnew)
+            pr = rnd(torch.exp(sc - mnew))
+            num = num * alpha + pr @ v[..., c:c + online_chunk, :]
+            den = den * alpha + pr.sum(-1, keepdim=True)
+            m = mnew
+        out = num / den
     else:
         e = torch.exp(attn - attn.amax(-1, keepdim=True))
         out = (rnd(e) @ v) / e.sum(-1, keepdim=True)
-    return out.transpose(1, 2).reshape(B_, N, C)
+    return out
 
 
 def window_attention(sd, p: str, x: torch.Tensor, ws: int, heads: int, mask, rnd=None, taps=None) -> torch.Tensor:

@@ -177,7 +177,7 @@ def test_c5_bf16_qkv_from_the_gemm_matches_fp32_staging(monkeypatch):
     print("bf16 q|k|v (ln_qkv) vs fp32 staging: max diff / range", np.abs(new - old).max() / rng, "; via the GEMM epilogue",
           np.abs(via_gemm - old).max() / rng, "; vs oracle", np.abs(new - ref).max() / rng)
     assert np.abs(new - old).max() / rng < 2e-3 and np.abs(via_gemm - old).max() / rng < 2e-3
-    assert np.abs(new - ref).max() / rng < 1e-2
+    assert np.abs(new - ref).max() / rng < 6e-3          # measured 3.1e-3 of the range (1 RDG, bf16 whole model vs the fp32 oracle)
 
 
 def test_c5_full_shape_bf16_close_to_fp32_mode():
@@ -199,4 +199,6 @@ def test_c5_full_shape_bf16_close_to_fp32_mode():
     err = (y16 - y32).abs()
     psnr = 10 * np.log10(rng ** 2 / float((err.double() ** 2).mean()))
     print("C5 full shape: bf16 vs fp32 mode max err / range", float(err.max()) / rng, "psnr", psnr)
-    assert float(err.max()) / rng < 3e-2 and psnr > 35.0
+    # measured 0.0036 of the range / 63.7 dB (12 RDG, 65536 tokens); the bar is the C2 whole-model bar (<= 1 %, >= 50 dB), ~3x / 13 dB above it.
+    # The two C5 kernels have their own oracle tests at 2e-3 (tests/test_gpu_c5_ops.py)
+    assert float(err.max()) / rng < 1e-2 and psnr > 50.0
