@@ -11,6 +11,8 @@
 #include "../../include/srad.h"
 #include <algorithm>
 #include <math.h>
+#include <stdlib.h>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -112,64 +114,102 @@ __global__ void sat_cols_carry_kernel(double* __restrict__ sat, const double* __
   for (int r = r0; r <= r1; ++r) p[(size_t)r * per] += carry;
 }
 
-struct Seg { int a, b; };   // inclusive index range of the unpadded image
-
-__device__ __forceinline__ int reflect_segments(int lo, int hi, int n, Seg* s) {
-  // padded coordinates lo..hi (may leave [0, n-1] on either side by less than n): numpy "reflect"
-  int k = 0;
-  s[k++] = Seg{max(lo, 0), min(hi, n - 1)};
-  if (lo < 0) s[k++] = Seg{1, -lo};
-  if (hi > n - 1) s[k++] = Seg{2 * (n - 1) - hi, n - 2};
-  return k;
+// Reflect-padded window along one axis as table differences.  Padded coordinates lo..hi (each side leaves [0, n-1] by less
+// than n) cover the real indices [max(lo,0), min(hi,n-1)] once, [1, -lo] once more if lo < 0, and [2(n-1)-hi, n-2] once more if
+// hi > n-1 (numpy "reflect": the edge sample is not repeated).  With P the prefix table (P[0] = 0) the covered sum is three
+// (+, -) pairs of table entries; a pair that is not needed has both indices equal and cancels.
+__device__ __forceinline__ void axis_pairs(int lo, int hi, int n, int (&idx)[6]) {
+  idx[0] = min(hi, n - 1) + 1; idx[1] = max(lo, 0);                       // + P[idx0] - P[idx1]: the part inside the image
+  idx[2] = lo < 0 ? -lo + 1 : 1; idx[3] = 1;                              // + P[-lo + 1] - P[1]: reflected over the low edge
+  idx[4] = n - 1; idx[5] = hi > n - 1 ? 2 * (n - 1) - hi : n - 1;         // + P[n - 1] - P[2 (n - 1) - hi]: over the high edge
 }
 
-// grid (pixel blocks, window sizes of the group, images): SSIM map values, block partial sums (float64).  Up to kWsGroup
-// window sizes share one launch (the list travels as a kernel argument).
+// Evaluation: one workgroup = kEvalPix consecutive pixels of one image for ONE window size; up to kWsGroup window sizes share
+// a launch (the list travels as a kernel argument; an image's window sizes run back to back).  SSIM map values summed per
+// block (float64, fixed order).  A pixel row i with pad p = ws / 2 reads table rows i - p and i + p + 1 (plus the reflected ones
+// near the borders): 80 B per pixel and window size, each table row exactly twice per window size.
+//
+// ROWS = the image width is a multiple of 64 (every MVTec size): a wave's 64 pixels are consecutive pixels of ONE row, so the row
+// pairs are wave-uniform (scalar row offsets) and the reflection pairs of both axes are skipped by wave-uniform branches when no
+// lane needs them; all loads of a (row pair, column pair) are issued before the first add.  Otherwise every lane works out its
+// own pixel (any width).  Same arithmetic either way.
+// (Tried: XCD k owns a strip of pixel blocks and window size k works p_k rows further down, so that all window sizes of a
+// launch share their top table row in one L2 - 5.0 -> 5.8 ms at 1024 px: the sweep is not bound by the fabric side.)
 constexpr int kWsGroup = 16;
-struct WsList { int ws[kWsGroup]; };
+struct WsList { int ws[kWsGroup]; double dinv[kWsGroup]; };    // window sizes of a launch and 1 / ws^2 (a float64 division per pixel otherwise)
+
+// Sum of the 64 SSIM map values of a wave's segment, in every lane.  The values are float32 in [-1, 1]; they are summed as
+// integers of 2^-24 (exact, so the order is irrelevant and DPP lane swizzles can do four of the six steps: a float64 shuffle
+// chain was 12 ds_bpermute round trips + 30 vector instructions per 64 pixels of a kernel that is VALU-bound).
+__device__ __forceinline__ double wave_sum_map(float m) {
+  int v = __float2int_rn(m * 16777216.0f);
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return (double)v * (1.0 / 16777216.0);
+}
+template <bool ROWS>
 __global__ __launch_bounds__(256) void ssim_eval_kernel(const double* __restrict__ sat, double* __restrict__ partial,
-                                                        int H, int W, const WsList wl, int nblk) {
-  const int kw = blockIdx.y, img = blockIdx.z;     // an image's window sizes run back to back: its tables stay in L2
-  const int ws = wl.ws[kw];
-  const size_t per = (size_t)(W + 1), plane = (size_t)(H + 1) * per;
+                                                        int H, int W, const WsList wl, int nblk, int g, int n_img) {
+  const int L = blockIdx.x, per_img = nblk * g;
+  const int img = L / per_img, r0 = L - img * per_img;
+  const int kw = r0 / nblk, pb = r0 - kw * nblk;
+  const int ws = wl.ws[kw], pad = ws / 2;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int iper = W + 1;
-  const double* S = sat + (size_t)img * kQ * plane;
-  const int pad = ws / 2;
-  const double dinv = 1.0 / (double)(ws * ws);
+  const size_t plane = (size_t)(H + 1) * iper;
+  const double* const S = sat + (size_t)img * kQ * plane;
+  const double dinv = wl.dinv[kw];
   const float C1 = (float)(0.01 * 0.01), C2 = (float)(0.03 * 0.03);
+  const int npix = H * W;
   double local = 0.0;
-  for (int k = 0; k < kEvalPix / 256; ++k) {
-    const int pix = blockIdx.x * kEvalPix + k * 256 + threadIdx.x;
-    if (pix >= H * W) continue;
-    const int i = pix / W, j = pix - i * W;
-    const int rlo = i - pad, rhi = i + ws - 1 - pad, clo = j - pad, chi = j + ws - 1 - pad;
+#pragma unroll 1
+  for (int it = 0; it < kEvalPix / 256; ++it) {
+    const int seg0 = pb * kEvalPix + (wave * (kEvalPix / 256) + it) * 64;    // first pixel of this wave's 64 (wave-uniform)
+    if (seg0 >= npix) break;
+    int i, j;
+    if constexpr (ROWS) { i = seg0 / W; j = seg0 - i * W + lane; }           // i scalar
+    else { const int pix = min(seg0 + lane, npix - 1); i = pix / W; j = pix - i * W; }
+    int ri[6], ci[6];
+    axis_pairs(i - pad, i + ws - 1 - pad, H, ri);
+    axis_pairs(j - pad, j + ws - 1 - pad, W, ci);
+    // does any lane of the wave need the reflection pairs?  (ROWS: the row answers are scalar anyway)
+    const bool row_lo = __builtin_amdgcn_ballot_w64(i - pad < 0) != 0, row_hi = __builtin_amdgcn_ballot_w64(i + ws - 1 - pad > H - 1) != 0;
+    const bool col_lo = __builtin_amdgcn_ballot_w64(j - pad < 0) != 0, col_hi = __builtin_amdgcn_ballot_w64(j + ws - 1 - pad > W - 1) != 0;
     double sum[kQ] = {0, 0, 0, 0, 0};
-    auto rect = [&](int ra, int rb, int ca, int cb) {          // rows ra..rb, columns ca..cb of the unpadded image (32-bit offsets:
-      const int o11 = (rb + 1) * iper + cb + 1, o01 = ra * iper + cb + 1, o10 = (rb + 1) * iper + ca, o00 = ra * iper + ca;   // a chunk's tables are < 2^31 doubles)
+    auto row_pair = [&](auto RP) __attribute__((always_inline)) {             // + row ri[2 rp], - row ri[2 rp + 1]
+      constexpr int rp = decltype(RP)::value;
+      const int oa = ri[2 * rp] * iper, ob = ri[2 * rp + 1] * iper;
+      auto col_pair = [&](auto CP) __attribute__((always_inline)) {
+        constexpr int cp = decltype(CP)::value;
+        double va[kQ], vb[kQ], vc[kQ], vd[kQ];
 #pragma unroll
-      for (int q = 0; q < kQ; ++q) {
-        const double* Sq = S + (size_t)q * plane;
-        sum[q] += (Sq[o11] - Sq[o01]) - (Sq[o10] - Sq[o00]);
-      }
+        for (int q = 0; q < kQ; ++q) {
+          const double* Sq = S + (size_t)q * plane;
+          va[q] = Sq[oa + ci[2 * cp]]; vb[q] = Sq[oa + ci[2 * cp + 1]];
+          vc[q] = Sq[ob + ci[2 * cp]]; vd[q] = Sq[ob + ci[2 * cp + 1]];
+        }
+#pragma unroll
+        for (int q = 0; q < kQ; ++q) sum[q] += (va[q] - vb[q]) - (vc[q] - vd[q]);
+      };
+      col_pair(std::integral_constant<int, 0>{});
+      if (col_lo) col_pair(std::integral_constant<int, 1>{});
+      if (col_hi) col_pair(std::integral_constant<int, 2>{});
     };
-    if (rlo >= 0 && rhi < H && clo >= 0 && chi < W) {          // the window lies inside the image: one rectangle
-      rect(rlo, rhi, clo, chi);
-    } else {
-      Seg rs[3], cs[3];
-      const int nr = reflect_segments(rlo, rhi, H, rs);
-      const int nc = reflect_segments(clo, chi, W, cs);
-      for (int a = 0; a < nr; ++a)
-        for (int b = 0; b < nc; ++b) rect(rs[a].a, rs[a].b, cs[b].a, cs[b].b);
-    }
+    row_pair(std::integral_constant<int, 0>{});
+    if (row_lo) row_pair(std::integral_constant<int, 1>{});
+    if (row_hi) row_pair(std::integral_constant<int, 2>{});
     const float mu1 = (float)(sum[0] * dinv), mu2 = (float)(sum[1] * dinv);
     const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
     const float s1 = (float)(sum[2] * dinv) - mu1_sq;
     const float s2 = (float)(sum[3] * dinv) - mu2_sq;
     const float s12 = (float)(sum[4] * dinv) - mu12;
     const float m = ((2.0f * mu12 + C1) * (2.0f * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2));
-    local += (double)m;
+    if (ROWS || seg0 + lane < npix) local += (double)m;
   }
-  // deterministic block reduction
   __shared__ double red[256];
   red[threadIdx.x] = local;
   __syncthreads();
@@ -177,22 +217,171 @@ __global__ __launch_bounds__(256) void ssim_eval_kernel(const double* __restrict
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) partial[((size_t)img * kWsGroup + kw) * nblk + blockIdx.x] = red[0];
+  if (threadIdx.x == 0) partial[((size_t)img * kWsGroup + kw) * nblk + pb] = red[0];
 }
 
-// one wave per (image, window size of the group): lanes sum every 64th block partial, then a fixed-order wave sum
+// ------------------------------------------------------------------------------------------------------------------------
+// The sweep for the image widths MVTec runs at (64 / 128 / 256 / 512 / 1024: a power of two that divides 1024): table rows
+// through LDS.
+//
+// Along the rows a reflect-padded window lo..hi is  B(hi) - T(lo)  with
+//     T(lo) = P[max(lo, 0)] - (lo < 0 ? P[1 - lo] - P[1] : 0)          B(hi) = P[min(hi, H-1) + 1] + (hi > H-1 ? P[H-1] - P[2(H-1) - hi] : 0)
+// (P[r] = table row r, all W + 1 columns of all five quantities).  T depends on the window's first row only, and pixel row i with
+// pad p has lo = i - p: for a fixed lo = t EVERY window size of the launch meets the same T(t), at pixel row i = t + p_k.  So a
+// 1024-thread workgroup owns 1024 / W consecutive values of t (1024 pixels per window size), keeps its T rows in registers, and
+// for each window size of the group streams the B rows once, coalesced, writes D = B - T (the row-summed window: W + 1 prefix
+// values per quantity and row) to LDS and evaluates its 1024 pixels from there - column pairs of D instead of 4 - 36 table
+// corners per quantity - while the next window size's B rows are in flight in registers (two LDS images, one barrier per
+// window size).
+//
+// The corner kernel above is bound by vector instructions and 8-byte loads (~45 per pixel and window size with the reflection
+// pairs of the big windows: 4.5 ms for 2 pairs x 102 window sizes at 1024 px), so this one is built to issue few of either: a
+// thread's row elements are (quantity q, row r = tid / W, column tid % W) for q = 0 .. 4 - the same table column for every
+// quantity; the quantity's plane and the row (wave-uniform: W >= 64) are the SCALAR offset of a buffer load, ~6 loads and no
+// address arithmetic per pixel and window size - plus column W of every (q, r) on the first 5 * 1024 / W threads; 1 / ws^2
+// comes from the host; the 64 map values of a wave are summed as integers through DPP.  2.06 ms (1024 px) / 0.38 ms (78 pairs at
+// 128 px, with the first, per-element form of this kernel).  What is left is a balance of LDS bytes (40 B per column term), the
+// B rows' 8-byte loads and ~120 vector instructions per pixel; the order in which workgroups take the rows (XCD strips, rows
+// shared between window sizes kept in one L2) changed nothing: the tables are served by the Infinity Cache fast enough.
+typedef __attribute__((ext_vector_type(2))) unsigned int sc_u32x2;
+__global__ __launch_bounds__(1024) void ssim_rows_lds_kernel(const double* __restrict__ sat, double* __restrict__ partial,
+                                                             int H, int lw, const WsList wl, int g, int t_first, int nt_blocks) {
+  const int W = 1 << lw, iper = W + 1, rb = 1024 >> lw, rowq = rb * iper, n_el = kQ * rowq;
+  extern __shared__ __attribute__((aligned(16))) double Dl[];              // two images of [kQ][rb][W + 1], then [2][16] wave sums
+  double* const wsum = Dl + 2 * n_el;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int img = blockIdx.x / nt_blocks, t0 = t_first + (blockIdx.x - img * nt_blocks) * rb;
+  const size_t plane = (size_t)(H + 1) * iper;
+  const double* const S = sat + (size_t)img * kQ * plane;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(S), 0, (int)(kQ * plane * 8), 0x00020000);
+  auto ld = [&](int voff, size_t soff_el) __attribute__((always_inline)) -> double {     // table entry at voff bytes + soff_el elements
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (int)(soff_el * 8), 0));
+  };
+  const int r = __builtin_amdgcn_readfirstlane((wave * 64) >> lw);         // this wave's row of the workgroup's rb (scalar)
+  const int c = tid & (W - 1);
+  const int t = t0 + r;
+  const int v_main = c * 8;
+  // column W of (quantity q, row rr) on thread q * rb + rr: per-lane rows, so the row offset is part of the vector offset
+  const bool tail = tid < kQ * rb;
+  const int tq = tail ? tid / rb : 0, trr = tail ? tid - tq * rb : 0;
+  const bool tail_wave = wave * 64 < kQ * rb;                              // scalar
+  auto tail_off = [&](int row) __attribute__((always_inline)) { return (int)((tq * plane + (size_t)row * iper + W) * 8); };
+  // T(t) = P[max(t, 0)] - (t < 0 ? P[1 - t] - P[1] : 0): unconditional loads, the pair cancels for t >= 0 (row 0 = zeros)
+  double Tv[kQ], Tt = 0.0;
+  {
+    const int ta = min(max(t, 0), H), tx = t < 0 ? min(1 - t, H) : 1;
+#pragma unroll
+    for (int q = 0; q < kQ; ++q) Tv[q] = ld(v_main, q * plane + (size_t)ta * iper) - (ld(v_main, q * plane + (size_t)tx * iper) - ld(v_main, q * plane + iper));
+    if (tail_wave) {
+      const int tt = t0 + trr, tta = min(max(tt, 0), H), ttx = tt < 0 ? min(1 - tt, H) : 1;
+      Tt = ld(tail_off(tta), 0) - (ld(tail_off(ttx), 0) - ld(tail_off(1), 0));
+    }
+  }
+  const float C1 = (float)(0.01 * 0.01), C2 = (float)(0.03 * 0.03);
+  double b0[kQ], bx[kQ], b0t = 0.0, bxt = 0.0;
+  auto load_b = [&](int kw) __attribute__((always_inline)) {
+    const int ws = wl.ws[kw], pad = ws / 2;
+    const int i = t + pad, hi = i + ws - 1 - pad;                           // scalar
+    const int rmain = min(max(hi, 0), H - 1) + 1;
+    if (hi > H - 1 && i < H) {                                             // scalar branch around straight-line loads
+      const int ry = 2 * (H - 1) - hi;
+#pragma unroll
+      for (int q = 0; q < kQ; ++q) {
+        b0[q] = ld(v_main, q * plane + (size_t)rmain * iper);
+        bx[q] = ld(v_main, q * plane + (size_t)(H - 1) * iper) - ld(v_main, q * plane + (size_t)ry * iper);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < kQ; ++q) { b0[q] = ld(v_main, q * plane + (size_t)rmain * iper); bx[q] = 0.0; }
+    }
+    if (tail_wave) {                                                       // per-lane rows: unconditional loads, the pair cancels where not needed
+      const int ti = t0 + trr + pad, thi = ti + ws - 1 - pad;
+      const bool over = thi > H - 1 && ti < H;
+      b0t = ld(tail_off(min(max(thi, 0), H - 1) + 1), 0);
+      bxt = ld(tail_off(H - 1), 0) - ld(tail_off(over ? 2 * (H - 1) - thi : H - 1), 0);
+    }
+  };
+  load_b(0);
+  for (int kw = 0; kw < g; ++kw) {
+    const int ws = wl.ws[kw], pad = ws / 2;
+    const int i = t + pad;                                                 // scalar: this wave's pixel row for this window size
+    const bool row_ok = i >= 0 && i < H;
+    const double dinv = wl.dinv[kw];
+    double* const Dk = Dl + (kw & 1) * n_el;
+    {
+      double* const Dw = Dk + r * iper + c;
+#pragma unroll
+      for (int q = 0; q < kQ; ++q) Dw[q * rowq] = (b0[q] + bx[q]) - Tv[q];   // (rows that do not exist for this window size are never read)
+      if (tail) Dk[tq * rowq + trr * iper + W] = (b0t + bxt) - Tt;
+    }
+    __syncthreads();
+    // the previous window size's 16 wave sums -> one partial per (window size, pixel row): thread 0 of each row's first wave
+    if (kw > 0 && (tid & (W - 1)) == 0) {
+      const int ip = t + wl.ws[kw - 1] / 2;
+      if (ip >= 0 && ip < H) {
+        const double* w0 = wsum + ((kw - 1) & 1) * 16 + wave;
+        double acc = 0.0;
+        for (int k = 0; k < (W >> 6); ++k) acc += w0[k];
+        partial[((size_t)img * kWsGroup + kw - 1) * H + ip] = acc;
+      }
+    }
+    if (kw + 1 < g) load_b(kw + 1);
+    float m_val = 0.f;
+    if (row_ok) {
+      const int lo = c - pad, hi = c + ws - 1 - pad;
+      const double* const Dr = Dk + r * iper;
+      const int c1 = min(hi, W - 1) + 1, c0 = max(lo, 0);
+      double sum[kQ];
+#pragma unroll
+      for (int q = 0; q < kQ; ++q) sum[q] = Dr[q * rowq + c1] - Dr[q * rowq + c0];
+      if (__builtin_amdgcn_ballot_w64(lo < 0) != 0) {
+        const int ca = lo < 0 ? 1 - lo : 1;
+#pragma unroll
+        for (int q = 0; q < kQ; ++q) sum[q] += Dr[q * rowq + ca] - Dr[q * rowq + 1];
+      }
+      if (__builtin_amdgcn_ballot_w64(hi > W - 1) != 0) {
+        const int cb = hi > W - 1 ? 2 * (W - 1) - hi : W - 1;
+#pragma unroll
+        for (int q = 0; q < kQ; ++q) sum[q] += Dr[q * rowq + W - 1] - Dr[q * rowq + cb];
+      }
+      const float mu1 = (float)(sum[0] * dinv), mu2 = (float)(sum[1] * dinv);
+      const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+      const float s1 = (float)(sum[2] * dinv) - mu1_sq;
+      const float s2 = (float)(sum[3] * dinv) - mu2_sq;
+      const float s12 = (float)(sum[4] * dinv) - mu12;
+      m_val = ((2.0f * mu12 + C1) * (2.0f * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2));
+    }
+    const double seg = wave_sum_map(m_val);
+    if (lane == 0) wsum[(kw & 1) * 16 + wave] = seg;
+  }
+  __syncthreads();
+  if ((tid & (W - 1)) == 0) {
+    const int ip = t + wl.ws[g - 1] / 2;
+    if (ip >= 0 && ip < H) {
+      const double* w0 = wsum + ((g - 1) & 1) * 16 + wave;
+      double acc = 0.0;
+      for (int k = 0; k < (W >> 6); ++k) acc += w0[k];
+      partial[((size_t)img * kWsGroup + g - 1) * H + ip] = acc;
+    }
+  }
+}
+
+// one workgroup per (image, window size of the group): thread i sums every 256th partial, then a fixed-order block sum
 __global__ __launch_bounds__(256) void ssim_finish_kernel(const double* __restrict__ partial, double* __restrict__ out, int n_img, int n_grp,
                                                           int nblk, int out_stride, int out_col0, double inv_count) {
-  const int lane = threadIdx.x & 63;
-  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (t >= n_img * n_grp) return;
-  const int img = t / n_grp, kw = t - img * n_grp;
+  const int img = blockIdx.x / n_grp, kw = blockIdx.x - img * n_grp;
   const double* p = partial + ((size_t)img * kWsGroup + kw) * nblk;
   double s = 0.0;
-  for (int b = lane; b < nblk; b += 64) s += p[b];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if (lane == 0) out[(size_t)img * out_stride + out_col0 + kw] = s * inv_count;
+  for (int b = threadIdx.x; b < nblk; b += 256) s += p[b];
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[(size_t)img * out_stride + out_col0 + kw] = red[0] * inv_count;
 }
 
 // mean((sr/255 - hr/255)^2) over all H*W*C values of an image: block partial sums (grid = blocks x images) ...
@@ -344,6 +533,11 @@ int chunk_images(int n_img, int H, int W) {
   if (c < 1) c = 1;
   return (int)std::min<size_t>(c, (size_t)n_img);
 }
+// widths the LDS-staged sweep takes (ssim_rows_lds_kernel), and the partial sums per (image, window size) either kernel writes
+inline bool lds_sweep_ok(int H, int W) {
+  return W >= 64 && W <= 1024 && (W & (W - 1)) == 0 && (long long)kQ * (H + 1) * (W + 1) * 8 < (1ll << 31) && getenv("SRAD_SCORE_NO_LDS") == nullptr;
+}
+inline int partial_slots(int H, int W) { return lds_sweep_ok(H, W) ? H : (H * W + kEvalPix - 1) / kEvalPix; }
 inline int grid1d(size_t total) {
   size_t b = (total + 255) / 256;
   return (int)std::min<size_t>(std::max<size_t>(b, 1), 4096);
@@ -374,7 +568,7 @@ int srad_quantize(const float* x, float* y, int64_t n, float rgb_range, void* st
 int srad_score_workspace_bytes(int n_img, int H, int W, size_t* bytes) {
   SRAD_REQUIRE(bytes && n_img > 0 && H > 0 && W > 0, "score_workspace_bytes: bad argument");
   const int chunk = chunk_images(n_img, H, W);
-  const int nblk = (H * W + kEvalPix - 1) / kEvalPix;
+  const int nblk = partial_slots(H, W);
   const int nseg = (H + kSeg - 1) / kSeg;
   *bytes = srad_align_up((size_t)chunk * (H + 1) * (W + 1) * kQ * sizeof(double), 256) +
            srad_align_up((size_t)chunk * kWsGroup * nblk * sizeof(double), 256) +
@@ -398,7 +592,7 @@ int srad_score_pairs(const uint8_t* sr, const uint8_t* hr, int n_img, int H, int
                  "score_pairs: window %d needs more than one reflection of a %dx%d image", ws_host[k], H, W);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int chunk = chunk_images(n_img, H, W);
-  const int nblk = (H * W + kEvalPix - 1) / kEvalPix;
+  const int nblk = partial_slots(H, W);
   double* sat = reinterpret_cast<double*>(workspace);
   double* partial = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) +
                                               srad_align_up((size_t)chunk * (H + 1) * (W + 1) * kQ * sizeof(double), 256));
@@ -433,13 +627,30 @@ int srad_score_pairs(const uint8_t* sr, const uint8_t* hr, int n_img, int H, int
     for (int k0 = 0; k0 < n_ws; k0 += kWsGroup) {      // up to kWsGroup window sizes per launch
       const int g = std::min(kWsGroup, n_ws - k0);
       WsList wl{};
-      for (int k = 0; k < g; ++k) wl.ws[k] = (int)ws_host[k0 + k];
+      for (int k = 0; k < g; ++k) { wl.ws[k] = (int)ws_host[k0 + k]; wl.dinv[k] = 1.0 / ((double)wl.ws[k] * (double)wl.ws[k]); }
       {
         // algorithmic bytes per (pair, window): the two fp32 luminance planes read once
         SradProfScope prof(s, SRAD_K_SCORE, 40.0 * n * H * W * g, 8.0 * n * H * W * g);
-        hipLaunchKernelGGL(ssim_eval_kernel, dim3(nblk, g, n), dim3(256), 0, s, sat, partial, H, W, wl, nblk);
+        static const bool generic = getenv("SRAD_SCORE_GENERIC") != nullptr;     // A/B: the per-lane kernel for every width
+        if (lds_sweep_ok(H, W)) {
+          int pmin = wl.ws[0] / 2, pmax = pmin;
+          for (int k = 1; k < g; ++k) { pmin = std::min(pmin, wl.ws[k] / 2); pmax = std::max(pmax, wl.ws[k] / 2); }
+          const int rb = 1024 / W, t_first = -pmax, nt = H - 1 - pmin - t_first + 1, nt_blocks = (nt + rb - 1) / rb;
+          const size_t lds = ((size_t)2 * kQ * rb * (W + 1) + 32) * sizeof(double);
+          static bool configured = false;
+          if (!configured) {
+            SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ssim_rows_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            configured = true;
+          }
+          int lw = 0;
+          while ((1 << lw) < W) ++lw;
+          hipLaunchKernelGGL(ssim_rows_lds_kernel, dim3((unsigned)((size_t)nt_blocks * n)), dim3(1024), lds, s, sat, partial, H, lw, wl, g, t_first, nt_blocks);
+        } else if (W % 64 == 0 && !generic)
+          hipLaunchKernelGGL(ssim_eval_kernel<true>, dim3((unsigned)((size_t)nblk * g * n)), dim3(256), 0, s, sat, partial, H, W, wl, nblk, g, n);
+        else
+          hipLaunchKernelGGL(ssim_eval_kernel<false>, dim3((unsigned)((size_t)nblk * g * n)), dim3(256), 0, s, sat, partial, H, W, wl, nblk, g, n);
       }
-      hipLaunchKernelGGL(ssim_finish_kernel, dim3((n * g + 3) / 4), dim3(256), 0, s, partial, ssim_out + (size_t)i0 * n_ws, n, g,
+      hipLaunchKernelGGL(ssim_finish_kernel, dim3(n * g), dim3(256), 0, s, partial, ssim_out + (size_t)i0 * n_ws, n, g,
                          nblk, n_ws, k0, 1.0 / ((double)H * W));
     }
   }

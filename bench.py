@@ -242,6 +242,15 @@ def scorer_leg(torch, dev):
     events on the launch stream, all window sizes in one call (one SAT build + one evaluation launch per window size)."""
     from srad_amd import metrics as M
     out = {}
+    pmc_cases, pmc_file, stale = {}, None, None
+    try:
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_scorer_pmc.json")))
+        if files:
+            pj = json.load(open(files[-1]))
+            pmc_cases, pmc_file, stale = pj.get("cases", {}), os.path.relpath(files[-1], ROOT), pj.get("kernel_source_sha") != kernel_source_sha()
+    except Exception:
+        pmc_cases = {}
     for tag, n, px in (("grid_128px", 78, 128), ("tile_1024px", 2, 1024)):
         g = torch.Generator(device="cpu").manual_seed(5)
         hr = torch.randint(0, 256, (n, px, px, 1), generator=g, dtype=torch.uint8).to(dev)
@@ -258,11 +267,18 @@ def scorer_leg(torch, dev):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         algo = 8.0 * px * px * n * len(sizes)
+        roof = {"bound": "hbm", "achieved": round(algo / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": round(algo / (ms * 1e-3) / HBM_PEAK, 4), "traffic": None, "algorithmic_bytes": int(algo)}
+        pmc = pmc_cases.get(tag)
+        if pmc is not None:
+            # FETCH_SIZE + WRITE_SIZE of one score_pairs call (tools/pmc_scorer.sh: separate rocprofv3 --pmc passes; the 8-byte-per-lane
+            # read factor is calibrated in the same pass); quoted only while the profile's source hash equals these kernels
+            roof["pmc_source"], roof["pmc_stale"] = pmc_file, bool(stale)
+            if not stale and pmc.get("traffic_bytes") is not None:
+                roof["traffic"] = pmc["traffic_bytes"]
+                roof["traffic_over_algorithmic"] = pmc.get("traffic_over_algorithmic")
         out[tag] = {"pairs": n, "hr_px": px, "window_sizes": len(sizes), "ms": round(ms, 3),
-                    "pairs_x_windows_per_s": round(n * len(sizes) / (ms * 1e-3), 1),
-                    "roofline": {"bound": "hbm", "achieved": round(algo / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                                 "frac": round(algo / (ms * 1e-3) / HBM_PEAK, 4), "traffic": None,
-                                 "algorithmic_bytes": int(algo)}}
+                    "pairs_x_windows_per_s": round(n * len(sizes) / (ms * 1e-3), 1), "roofline": roof}
     return out
 
 

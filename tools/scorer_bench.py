@@ -1,11 +1,20 @@
-"""Scorer timing at bench.py's two shapes (tools only)."""
-import os, sys
+"""Scorer timing at bench.py's two shapes (tools only).  --case grid_128px|tile_1024px limits it to one shape (PMC passes),
+--reps N timed calls after one warm-up call; prints `calls=<n>` so a counter pass can be averaged per call."""
+import argparse
+import os
+import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from importlib import import_module
 M = import_module("anomaly-detection-super-resolution_amd.metrics")
+ap = argparse.ArgumentParser()
+ap.add_argument("--case", default="")
+ap.add_argument("--reps", type=int, default=5)
+args = ap.parse_args()
 dev = "cuda"
 for tag, n, px in (("grid_128px", 78, 128), ("tile_1024px", 2, 1024)):
+    if args.case and args.case != tag:
+        continue
     g = torch.Generator(device="cpu").manual_seed(5)
     hr = torch.randint(0, 256, (n, px, px, 1), generator=g, dtype=torch.uint8).to(dev)
     sr = (hr.int() + torch.randint(-6, 7, hr.shape, generator=g).to(dev)).clamp(0, 255).to(torch.uint8)
@@ -13,12 +22,11 @@ for tag, n, px in (("grid_128px", 78, 128), ("tile_1024px", 2, 1024)):
     M.score_pairs(sr, hr, sizes)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 5
     e0.record()
-    for _ in range(reps):
+    for _ in range(args.reps):
         M.score_pairs(sr, hr, sizes)
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    ms = e0.elapsed_time(e1) / args.reps
     algo = 8.0 * px * px * n * len(sizes)
-    print(f"{tag}: {ms:.3f} ms, {algo / ms / 1e6:.1f} GB/s algorithmic", flush=True)
+    print(f"{tag}: {ms:.3f} ms, {algo / ms / 1e6:.1f} GB/s algorithmic, calls={args.reps + 1} pairs={n} px={px} window_sizes={len(sizes)}", flush=True)

@@ -1,7 +1,12 @@
-# per-kernel durations (rocprofv3) of tools/scorer_bench.py
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-rm -rf $R/gpurun_out/sct
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/sct -o w -- python3 $R/tools/scorer_bench.py > /dev/null 2>&1
-python3 $R/tools/trace_by_grid.py $R/gpurun_out/sct "_kernel" | grep -E "sat_|ssim_|mse_"
-rm -rf $R/gpurun_out/sct
+#!/bin/bash
+# Per-kernel times of the scorer at bench.py's two shapes (rocprofv3 kernel trace of tools/scorer_bench.py).  Run on the GPU box.
+set -e -o pipefail
+OUT=${1:-gpurun_out/scorer_trace}
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+mkdir -p "$OUT"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -- python3 tools/scorer_bench.py > "$OUT.log" 2>&1
+f=$(find "$OUT" -name "*kernel_stats.csv" | head -1)
+cp "$f" "$OUT.kernel_stats.csv"
+rm -rf "$OUT"
+head -12 "$OUT.kernel_stats.csv"
