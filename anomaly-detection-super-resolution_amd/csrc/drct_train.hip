@@ -119,7 +119,9 @@ BlockPlan plan_block(const srad_drct* h, const SwinW& sw, int H, int W, int T, i
   const srad_drct_config& c = h->cfg;
   const int prec = h->pt.prec, d = sw.d, hd = d / sw.heads;
   const TrainState& ts = h->ts;
-  const bool fused_bwd = prec == SRAD_PREC_BF16 && getenv("SRAD_NO_FUSE") == nullptr;
+  // (windows other than 8 x 8 - the 32 / 64 / 256 px presets of src/main.py:218-219,286 - take the unfused forward, so they take
+  // the unfused backward with it: fp32 saves, the general attention backward kernel)
+  const bool fused_bwd = prec == SRAD_PREC_BF16 && c.window_size == 8 && getenv("SRAD_NO_FUSE") == nullptr;
   auto tf = [&](int w) { return !ts.tf_off.empty() && ts.tf_off[w] >= 0; };
   BlockPlan b{};
   b.xh = h->fuse_mlp && srad_qkv_attn_supported(prec, c.window_size, H, W, d, sw.heads) && srad_mlp_block_supported(prec, T, d, sw.hidden, KA);
@@ -139,8 +141,9 @@ int attn_hp(const SwinW& sw) { return srad_round_up(sw.d / sw.heads, 8); }
 int train_check(const srad_drct* h, int B, int H, int W) {
   SRAD_REQUIRE(h->ts.ready, "drct training: call srad_drct_train_bind() and srad_drct_sync_params() first");
   SRAD_REQUIRE(B > 0 && H > 0 && W > 0, "drct training: empty input");
-  SRAD_REQUIRE(h->cfg.window_size == 8, "drct training: window size 8 only (got %d)", h->cfg.window_size);
-  SRAD_REQUIRE(H % 8 == 0 && W % 8 == 0, "drct training: input %dx%d is not a multiple of the window size 8", H, W);
+  const int ws = h->cfg.window_size;
+  SRAD_REQUIRE(ws >= 1 && ws <= 16, "drct training: window sizes 1 .. 16 (got %d; the reference's presets build 2, 4, 8 and 16)", ws);
+  SRAD_REQUIRE(H % ws == 0 && W % ws == 0, "drct training: input %dx%d is not a multiple of the window size %d", H, W, ws);
   SRAD_REQUIRE((double)B * H * W * h->cfg.upscale * h->cfg.upscale * h->cfg.num_feat * 4.0 < 3.9e9 &&
                (double)B * H * W * 3 * h->dmax * 4.0 < 3.9e9, "drct training: batch too large for 32-bit offsets");
   return SRAD_OK;

@@ -1387,6 +1387,260 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const AttnBwdParam
 }
 
 // ------------------------------------------------------------------------------------------
+// The same backward for ANY window size up to 16 (N = ws^2 <= 256 tokens; the reference's CLI presets build windows of
+// 2, 4, 8 and 16: window_size = img_size // 4, src/main.py:286 - the 8 x 8 case has its own kernels above).  One workgroup
+// per (window, head); the window's tokens are padded to NB blocks of 64 (padding keys get probability 0, padding queries
+// are never written).  For each block of 64 queries the whole score row block (64 x 64 NB) and dP stay in MFMA
+// accumulators, so the softmax is exact in one pass as above; then key block after key block the P / dS tiles go to LDS
+// and feed dq (accumulated in registers over the key blocks), dk and dv (accumulated over the query blocks by
+// read-add-write of the workgroup's own rows: one owner, fixed order).  The bias-table gradient is collected in LDS over
+// the tiles.  All MFMAs are v_mfma_f32_16x16x4_f32 in every precision mode: these presets are small images, the kernel is
+// for coverage, not for the benchmarked configuration.
+// ------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(256) void window_attn_bwd_gen_kernel(const AttnBwdParams p, float* __restrict__ tpart) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Qs = reinterpret_cast<float*>(smem);
+  float* Ks = Qs + 64 * AB_HS;
+  float* Vs = Ks + 64 * AB_HS;
+  float* Gs = Vs + 64 * AB_HS;
+  float* Pm = Gs + 64 * AB_HS;
+  float* Dm = Pm + 64 * AB_PS;
+  float* tbl = Dm + 64 * AB_PS;      // [(2 ws - 1)^2] <= 961 (1024 reserved)
+  float* dtb = tbl + 1024;           // its gradient
+  int* tok = reinterpret_cast<int*>(dtb + 1024);   // [64 NB]
+  int* inf = tok + 64 * NB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int ws = p.ws, N = ws * ws, d = p.d, heads = p.heads, hd = d / heads, hdp = p.hdp;
+  const int ldq = 3 * heads * hdp;
+  const int nWx = p.W / ws, nW = (p.H / ws) * nWx;
+  const int win = blockIdx.x / heads, h = blockIdx.x - win * heads;
+  const int b = win / nW, widx = win - b * nW;
+  const int wy = widx / nWx, wx = widx - wy * nWx;
+  const float scale = rsqrtf((float)hd);
+  const int tw = 2 * ws - 1, ntbl = tw * tw;
+
+  for (int t = tid; t < 64 * NB; t += 256) {
+    const int tc = min(t, N - 1);                                 // padding rows point at a real token and are masked
+    const int py = tc / ws, px = tc - py * ws;
+    const int r = wy * ws + py, c = wx * ws + px;
+    int orr = r + p.shift; if (orr >= p.H) orr -= p.H;
+    int occ = c + p.shift; if (occ >= p.W) occ -= p.W;
+    tok[t] = (b * p.H + orr) * p.W + occ;
+    const int rh = r < p.H - ws ? 0 : (r < p.H - p.shift ? 1 : 2);
+    const int rw = c < p.W - ws ? 0 : (c < p.W - p.shift ? 1 : 2);
+    inf[t] = ((rh * 3 + rw) << 16) | (py << 8) | px;
+  }
+  for (int t = tid; t < ntbl; t += 256) { tbl[t] = p.table[(size_t)t * heads + h]; dtb[t] = 0.f; }
+  __syncthreads();
+
+  // stage a 32-column chunk of 64 rows (block `blk` of the window's tokens) of q*scale / k / v / dO into its LDS tile
+  auto stage_rows = [&](float* dst, int blk, int ch, int which /* 0 q, 1 k, 2 v */) {
+    const int col0 = ch * AB_HC;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx >> 3, c = col0 + (idx & 7) * 4;
+      const float* base = p.qkv + (size_t)tok[blk * 64 + row] * ldq + (which * heads + h) * hdp + min(c, hdp - 4);
+      f32x4 v4 = *reinterpret_cast<const f32x4*>(base);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v4[e] = c + e < hd ? (which == 0 ? v4[e] * scale : v4[e]) : 0.f;
+      *reinterpret_cast<f32x4*>(dst + row * AB_HS + (idx & 7) * 4) = v4;
+    }
+  };
+  auto stage_g = [&](int blk, int ch) {
+    const int col0 = ch * AB_HC;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx >> 5, cl = idx & 31, c = col0 + cl;
+      const float g = p.dout[(size_t)tok[blk * 64 + row] * d + h * hd + min(c, hd - 1)];
+      Gs[row * AB_HS + cl] = c < hd ? g : 0.f;
+    }
+  };
+
+  const int nch = (hd + AB_HC - 1) / AB_HC;                        // <= 4 (head dims up to 128)
+  for (int qb = 0; qb < NB; ++qb) {
+    if (qb * 64 >= N) break;
+    // ---- S = (q scale) k^T and dP = dO v^T for this query block against every key block ----
+    f32x4 s[NB][4], dp[NB][4];
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s[kb][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kb][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int ch = 0; ch < nch; ++ch) {
+      __syncthreads();
+      stage_rows(Qs, qb, ch, 0);
+      stage_g(qb, ch);
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
+        if (kb > 0) __syncthreads();
+        stage_rows(Ks, kb, ch, 1);
+        stage_rows(Vs, kb, ch, 2);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < AB_HC; kk += 16) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(Qs + (wave * 16 + fr) * AB_HS + kk + 4 * fq);
+          const f32x4 g = *reinterpret_cast<const f32x4*>(Gs + (wave * 16 + fr) * AB_HS + kk + 4 * fq);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 kbv = *reinterpret_cast<const f32x4*>(Ks + (j * 16 + fr) * AB_HS + kk + 4 * fq);
+            const f32x4 vb = *reinterpret_cast<const f32x4*>(Vs + (j * 16 + fr) * AB_HS + kk + 4 * fq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              s[kb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], kbv[e], s[kb][j], 0, 0, 0);
+              dp[kb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[e], vb[e], dp[kb][j], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    // ---- softmax over the window's N keys (row = 64 qb + 16 wave + 4 fq + e, key = 64 kb + 16 j + fr), dS in place of dp ----
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int qi = inf[qb * 64 + wave * 16 + fq * 4 + e];
+      const int qy = (qi >> 8) & 0xff, qx = qi & 0xff, qr = qi >> 16;
+      float mx = -1e30f;
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int key = kb * 64 + j * 16 + fr;
+          const int ki = inf[key];
+          const int kyy = (ki >> 8) & 0xff, kxx = ki & 0xff, kr = ki >> 16;
+          float v = s[kb][j][e] + tbl[(qy - kyy + ws - 1) * tw + (qx - kxx + ws - 1)];
+          if (p.shift > 0 && qr != kr) v += -100.0f;
+          if (key >= N) v = -1e30f;
+          s[kb][j][e] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = srad_row16_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float pv = kb * 64 + j * 16 + fr < N ? expf(s[kb][j][e] - mx) : 0.f;
+          s[kb][j][e] = pv;
+          sum += pv;
+        }
+      sum = srad_row16_sum(sum);
+      const float inv = 1.0f / sum;
+      float dl = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[kb][j][e] *= inv; dl += s[kb][j][e] * dp[kb][j][e]; }
+      dl = srad_row16_sum(dl);
+      const bool qreal = qb * 64 + wave * 16 + fq * 4 + e < N;      // a padding query contributes nothing to dk / dv / the table
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dp[kb][j][e] = qreal ? s[kb][j][e] * (dp[kb][j][e] - dl) : 0.f;
+          if (!qreal) s[kb][j][e] = 0.f;
+        }
+    }
+    // ---- key block after key block: P / dS tiles -> LDS, table gradient, dq (registers), dk / dv (read-add-write) ----
+    f32x4 dq[4][2];
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) { dq[ch][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dq[ch][1] = dq[ch][0]; }
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+      if (kb * 64 >= N) continue;
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          Pm[(wave * 16 + fq * 4 + e) * AB_PS + j * 16 + fr] = s[kb][j][e];
+          Dm[(wave * 16 + fq * 4 + e) * AB_PS + j * 16 + fr] = dp[kb][j][e];
+        }
+      __syncthreads();
+      // table entry t = (dy + ws - 1) (2 ws - 1) + (dx + ws - 1): the dS of every (query, key = query - (dy, dx)) pair of this tile
+      for (int t = tid; t < ntbl; t += 256) {
+        const int dy = t / tw - (ws - 1), dx = t - (t / tw) * tw - (ws - 1);
+        float acc = 0.f;
+        for (int qy = max(0, dy); qy < min(ws, ws + dy); ++qy)
+          for (int qx = max(0, dx); qx < min(ws, ws + dx); ++qx) {
+            const int qn = qy * ws + qx - qb * 64, kn = (qy - dy) * ws + (qx - dx) - kb * 64;
+            if (qn >= 0 && qn < 64 && kn >= 0 && kn < 64) acc += Dm[qn * AB_PS + kn];
+          }
+        dtb[t] += acc;                                              // (one thread per entry: no race)
+      }
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) {
+        if (ch >= nch) continue;
+        __syncthreads();
+        stage_rows(Ks, kb, ch, 1);
+        stage_rows(Qs, qb, ch, 0);
+        stage_g(qb, ch);
+        __syncthreads();
+        f32x4 dk[2], dv[2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) { dk[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[jt] = dk[jt]; }
+#pragma unroll
+        for (int kk = 0; kk < 64; kk += 16) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(Dm + (wave * 16 + fr) * AB_PS + kk + 4 * fq);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int kr = kk + 4 * fq + e;
+            const float at = Dm[kr * AB_PS + wave * 16 + fr];     // dS^T
+            const float pt = Pm[kr * AB_PS + wave * 16 + fr];     // P^T
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+              const float kbv = Ks[kr * AB_HS + jt * 16 + fr];
+              const float qbv = Qs[kr * AB_HS + jt * 16 + fr];
+              const float gb = Gs[kr * AB_HS + jt * 16 + fr];
+              dq[ch][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], kbv, dq[ch][jt], 0, 0, 0);
+              dk[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, qbv, dk[jt], 0, 0, 0);
+              dv[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pt, gb, dv[jt], 0, 0, 0);
+            }
+          }
+        }
+        // dk / dv rows of key block kb (row = 64 kb + 16 wave + 4 fq + e): first query block writes, later ones add
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int key = kb * 64 + wave * 16 + fq * 4 + e;
+          if (key >= N) continue;
+          float* dst = p.dqkv + (size_t)tok[key] * (3 * d) + h * hd;
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) {
+            const int c = ch * AB_HC + jt * 16 + fr;
+            if (c < hd) {
+              if (qb == 0) { dst[d + c] = dk[jt][e]; dst[2 * d + c] = dv[jt][e]; }
+              else { dst[d + c] += dk[jt][e]; dst[2 * d + c] += dv[jt][e]; }
+            }
+          }
+        }
+      }
+    }
+    // dq rows of this query block
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      if (ch >= nch) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int qrow = qb * 64 + wave * 16 + fq * 4 + e;
+        if (qrow >= N) continue;
+        float* dst = p.dqkv + (size_t)tok[qrow] * (3 * d) + h * hd;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          const int c = ch * AB_HC + jt * 16 + fr;
+          if (c < hd) dst[c] = dq[ch][jt][e] * scale;
+        }
+      }
+    }
+    __threadfence_block();
+  }
+  __syncthreads();
+  for (int t = tid; t < ntbl; t += 256) tpart[(size_t)win * (ntbl * heads) + (size_t)t * heads + h] = dtb[t];
+}
+constexpr size_t ABG_LDS(int nb) { return (size_t)(4 * 64 * AB_HS + 2 * 64 * AB_PS + 2 * 1024) * sizeof(float) + 2 * 64 * nb * sizeof(int); }
+
+// ------------------------------------------------------------------------------------------
 // The same backward with bf16 MFMA operands (v_mfma_f32_16x16x32_bf16, fp32 accumulation) for the bf16 precision
 // mode: q, k, v, dO chunks are staged as bf16; P and dS leave the softmax as bf16 tiles - dS in both orientations
 // (row-major for dq = dS k, transposed for dk = dS^T q), P transposed (dv = P^T dO) - and the second operand of
@@ -2036,9 +2290,44 @@ int srad_launch_ln_bwd(const LnBwdParams& p, WgradQueue& q, hipStream_t stream) 
   return SRAD_OK;
 }
 
+// windows other than 8 x 8 (N = ws^2 <= 256): window_attn_bwd_gen_kernel, fp32 operands and results in every precision mode
+static int launch_attn_bwd_gen(const AttnBwdParams& p, WgradQueue& q, hipStream_t stream) {
+  SRAD_REQUIRE(p.ws >= 1 && p.ws <= 16, "window_attn_bwd: window sizes 1 .. 16 train (got %d)", p.ws);
+  SRAD_REQUIRE(p.qkv && p.dout && p.dqkv && !p.qkv_h && !p.dqkv_h, "window_attn_bwd: window sizes other than 8 take fp32 q | k | v, dO and dqkv");
+  SRAD_REQUIRE(p.d / p.heads <= 128, "window_attn_bwd: head dims up to 128 (got %d)", p.d / p.heads);
+  const int nW = (p.H / p.ws) * (p.W / p.ws), tw = 2 * p.ws - 1;
+  const int ncols = tw * tw * p.heads, nwin = p.B * nW;
+  const size_t need = (size_t)nwin * ncols;
+  SRAD_REQUIRE(q.ws && need <= q.ws_floats, "window_attn_bwd: workspace too small");
+  if (q.used + need > q.ws_floats) SRAD_TRY(srad_wgrad_flush(q, stream));
+  float* tpart = q.ws + q.used;
+  q.used += need;
+  SRAD_TRY(queue_colsum(q, p.dtable, tpart, ncols, ncols, nwin, 1.f, stream));
+  const double T = (double)p.B * p.H * p.W;
+  SradProfScope prof(stream, SRAD_K_ATTN_BWD, 10.0 * T * p.ws * p.ws * p.d, 4.0 * T * 8 * p.d);
+  const int nb = (p.ws * p.ws + 63) / 64;
+  auto go = [&](auto kern, size_t lds) -> int {
+    static bool configured = false;                    // (one per kernel instance)
+    if (!configured) {
+      SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nwin * p.heads), dim3(256), lds, stream, p, tpart);
+    return SRAD_OK;
+  };
+  if (nb == 1) SRAD_TRY(go(window_attn_bwd_gen_kernel<1>, ABG_LDS(1)));
+  else if (nb == 2) SRAD_TRY(go(window_attn_bwd_gen_kernel<2>, ABG_LDS(2)));
+  else if (nb == 3) SRAD_TRY(go(window_attn_bwd_gen_kernel<3>, ABG_LDS(3)));
+  else SRAD_TRY(go(window_attn_bwd_gen_kernel<4>, ABG_LDS(4)));
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}
+
 int srad_launch_window_attn_bwd(int prec, const AttnBwdParams& p, WgradQueue& q, hipStream_t stream) {
-  SRAD_REQUIRE(p.ws == 8, "window_attn_bwd: the training path supports window size 8 only (got %d)", p.ws);
   SRAD_REQUIRE(p.H % p.ws == 0 && p.W % p.ws == 0, "window_attn_bwd: %dx%d not a multiple of the window", p.H, p.W);
+  SRAD_REQUIRE(p.d % p.heads == 0 && p.hdp % 4 == 0 && p.hdp >= p.d / p.heads, "window_attn_bwd: bad head geometry");
+  SRAD_REQUIRE(p.shift >= 0 && p.shift < (p.ws > 0 ? p.ws : 1), "window_attn_bwd: bad shift %d", p.shift);
+  if (p.ws != 8) return launch_attn_bwd_gen(p, q, stream);
   SRAD_REQUIRE(p.d % p.heads == 0 && p.hdp % 4 == 0 && p.hdp >= p.d / p.heads, "window_attn_bwd: bad head geometry");
   SRAD_REQUIRE(p.shift >= 0 && p.shift < p.ws, "window_attn_bwd: bad shift %d", p.shift);
   static bool configured = false;

@@ -249,7 +249,7 @@ int srad_launch_conv80(const GemmParams& p, hipStream_t stream) {
     configured = true;
   }
   const double K = 9.0 * 80;
-  SradProfScope prof(stream, SRAD_K_GEMM_BN64, 2.0 * p.M * 80 * K, 4.0 * p.M * 80 * (p.R ? 3 : 2) + 2.0 * 80 * K);
+  SradProfScope prof(stream, SRAD_K_CONV80, 2.0 * p.M * 80 * K, 4.0 * p.M * 80 * (p.R ? 3 : 2) + 2.0 * 80 * K);
   if (p.Xh) hipLaunchKernelGGL(conv80_kernel<true>, dim3(ntiles < 256 ? ntiles : 256), dim3(C80_NT), C80_LDS, stream, p, ntiles, tiles_x, tiles_per_img);
   else hipLaunchKernelGGL(conv80_kernel<false>, dim3(ntiles < 256 ? ntiles : 256), dim3(C80_NT), C80_LDS, stream, p, ntiles, tiles_x, tiles_per_img);
   SRAD_CHECK_HIP(hipGetLastError());

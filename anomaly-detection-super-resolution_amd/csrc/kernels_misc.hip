@@ -34,7 +34,7 @@ struct Prof {
 } g_prof;
 const char* const kClassNames[SRAD_K_COUNT] = {"gemm_bn64", "gemm_bn32", "gemm_bn16", "window_attn", "layernorm",
                                                "layout", "pack_weight", "score", "misc", "mlp_block", "qkv_attn",
-                                               "wgrad", "window_attn_bwd", "layernorm_bwd", "optim", "wgrad_reduce", "mlp_bwd", "ln_qkv"};
+                                               "wgrad", "window_attn_bwd", "layernorm_bwd", "optim", "wgrad_reduce", "mlp_bwd", "ln_qkv", "conv80"};
 }  // namespace
 
 bool srad_no_xcd_map() {

@@ -455,7 +455,7 @@ int srad_launch_nhwc_to_nchw(const float* x, int ldx, float* y, int B, int C, in
 enum {
   SRAD_K_GEMM_BN64 = 0, SRAD_K_GEMM_BN32, SRAD_K_GEMM_BN16, SRAD_K_ATTN, SRAD_K_LAYERNORM,
   SRAD_K_LAYOUT, SRAD_K_PACK, SRAD_K_SCORE, SRAD_K_MISC, SRAD_K_MLP_BLOCK, SRAD_K_QKV_ATTN,
-  SRAD_K_WGRAD, SRAD_K_ATTN_BWD, SRAD_K_LN_BWD, SRAD_K_OPTIM, SRAD_K_WGRAD_REDUCE, SRAD_K_MLP_BWD, SRAD_K_LN_QKV, SRAD_K_COUNT
+  SRAD_K_WGRAD, SRAD_K_ATTN_BWD, SRAD_K_LN_BWD, SRAD_K_OPTIM, SRAD_K_WGRAD_REDUCE, SRAD_K_MLP_BWD, SRAD_K_LN_QKV, SRAD_K_CONV80, SRAD_K_COUNT
 };
 struct SradProfScope {
   hipStream_t s; int active;

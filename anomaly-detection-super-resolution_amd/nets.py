@@ -415,7 +415,9 @@ class DRCT(_EngineModule):
 
     # -- training (C ABI srad_drct_forward_train / srad_drct_backward) ------------------------
     def _can_train(self) -> bool:
-        return self.window_size == 8        # the attention backward is built for 8 x 8 windows (128 px / x4: C2, C4)
+        # every window size the reference's CLI builds (window_size = img_size // 4 in {2, 4, 8, 16}, src/main.py:218-219,286):
+        # 8 x 8 windows (C2, C4) take the fused kernels, the others the unfused launches and the general attention backward
+        return 1 <= self.window_size <= 16
 
     def enable_training(self) -> "DRCT":
         super().enable_training()
@@ -484,8 +486,8 @@ class DRCT(_EngineModule):
             if not x.is_cuda:
                 raise RuntimeError("srad_amd runs on the GPU only (HIP engine); got a CPU tensor - there is no CPU fallback")
             if not self._can_train():
-                raise NotImplementedError(f"DRCT: the HIP backward pass is built for window size 8 (got {self.window_size}); "
-                                          "run other window sizes under torch.no_grad() / .eval()")
+                raise NotImplementedError(f"DRCT: the HIP backward pass is built for window sizes up to 16 (got {self.window_size}); "
+                                          "run larger windows under torch.no_grad() / .eval()")
             if x.dim() != 4 or x.shape[1] != self.cfg.in_chans:
                 raise ValueError(f"expected a [B, {self.cfg.in_chans}, H, W] tensor")
             if x.shape[2] % self.window_size or x.shape[3] % self.window_size:

@@ -38,11 +38,13 @@ def kernel_source_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def pmc_profile(kernel: str):
-    """(counters of `kernel`, file, stale?) from the newest profiles/r*_pmc_counters.json (tools/pmc_summary.py: separate
-    rocprofv3 --pmc passes of `bench.py --no-graph --no-train --no-eval`)."""
+def pmc_profile(kernel: str, leg: str = "c2"):
+    """(counters of `kernel`, file, stale?) from the newest profiles/r*_<leg>_pmc_counters.json (tools/pmc_summary.py: separate
+    rocprofv3 --pmc passes of `bench.py --only <leg>`, tools/pmc_passes.sh)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_counters.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{leg}_pmc_counters.json")))
+    if not files and leg == "c2":
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_counters.json")))
     if not files:
         return None, None, None
     try:
@@ -50,6 +52,53 @@ def pmc_profile(kernel: str):
         return pmc["kernels"].get(kernel), os.path.relpath(files[-1], ROOT), pmc.get("kernel_source_sha") != kernel_source_sha()
     except Exception:
         return None, None, None
+
+
+def kernel_roofline(prof: dict, reps: int, leg: str, peak: float, dtype_note: str = ""):
+    """`roofline` object of a leg from its per-class HIP-event profile (L.prof_collect): the class with the most device time,
+    its algorithmic FLOPs (2 M N K per launch, summed by the launchers) over its summed launch durations, against the dense MFMA
+    peak of the leg's dtype; counters from the leg's own PMC passes when their source hash still matches."""
+    if not prof:
+        return None
+    total_ms = sum(v["ms"] for v in prof.values())
+    dom = max(prof, key=lambda k: prof[k]["ms"])
+    d = prof[dom]
+    ach = d["flops"] / (d["ms"] * 1e-3)
+    roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": d["launches"] // reps,
+            "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 3),
+            "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 4),
+            "share_of_kernel_time": round(d["ms"] / total_ms, 3)}
+    pmc, pmc_file, stale = pmc_profile(dom, leg)
+    if pmc is not None:
+        roof["pmc_source"], roof["pmc_stale"] = pmc_file, bool(stale)
+        if not stale:
+            roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+            for k in ("mfma_busy", "valu_busy", "wait_frac", "lds_bank_conflict_frac", "dispatch_us"):
+                if k in pmc:
+                    roof[k] = pmc[k]
+    return roof
+
+
+def profile_eager(fn, reps: int):
+    """HIP-event class profile of `reps` eager calls of fn (one untimed call first)."""
+    import torch
+    from srad_amd import _lib as L
+    L.prof_enable(True)
+    fn()
+    torch.cuda.synchronize()
+    L.prof_collect()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    prof = L.prof_collect()
+    L.prof_enable(False)
+    return prof
+
+
+def kernel_table(prof: dict, reps: int):
+    return {k: {"launches_per_step": v["launches"] // reps, "avg_us": round(v["ms"] * 1e3 / v["launches"], 2), "ms_per_step": round(v["ms"] / reps, 3),
+                "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
 
 
 def usable_cores() -> int:
@@ -230,6 +279,7 @@ def train_leg(args, torch, dist, dev, world, rank):
         fl = 3.0 * m.flops(B, 32, 32)
         out["algorithmic_gflop_per_step"] = round(fl / 1e9, 1)
         out["model_tflops"] = round(fl * world / (el / steps) / 1e12, 2)
+        out["roofline"] = kernel_roofline(prof, reps, "c4", PEAK[args.dtype])
     del m, opt
     torch.cuda.empty_cache()
     return out
@@ -315,7 +365,8 @@ def c5_leg(args, torch, dev):
            "hr_mpixels_per_s": round(1024 * 1024 / dt / 1e6, 2), "algorithmic_gflop": round(fl / 1e9, 1),
            "model_tflops": round(fl / dt / 1e12, 1),
            "kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
-                       for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}
+                       for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+           "roofline": kernel_roofline(prof, 1, "c5", PEAK[args.dtype])}
     del m
     torch.cuda.empty_cache()
     return out
@@ -324,6 +375,7 @@ def c5_leg(args, torch, dev):
 def c3_leg(args, torch, dev):
     """BASELINE config C3: DRN-L x4 forward, carpet-shaped RGB input, 256 px HR, batch 8 (LR [8,3,64,64])."""
     from srad_amd.nets import DRN
+    from srad_amd import _lib as L      # noqa: F401  (profile_eager)
 
     class DrnOpt:
         n_colors, n_blocks, n_feats, negval, rgb_range, scale = 3, 40, 20, 0.2, 255.0, [2, 4]
@@ -341,10 +393,34 @@ def c3_leg(args, torch, dev):
             m(x)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        m.use_graph = False
+        prof = profile_eager(lambda: m(x), 5)
     fl = m.flops(8, 64, 64)
     out = {"workload": "C3: DRN-L x4 forward, RGB, 256 px HR, batch 8 (LR [8,3,64,64])", "ms_per_batch": round(dt * 1e3, 3),
            "hr_mpixels_per_s": round(8 * 256 * 256 / dt / 1e6, 2), "algorithmic_gflop": round(fl / 1e9, 1),
-           "model_tflops": round(fl / dt / 1e12, 1)}
+           "model_tflops": round(fl / dt / 1e12, 1), "kernels": kernel_table(prof, 5),
+           "roofline": kernel_roofline(prof, 5, "c3", PEAK[args.dtype])}
+    if not args.no_cpu_baseline:
+        # the reference's --device cpu path beside every config - the oracle's DRN forward (stock torch CPU
+        # kernels, fp32) on a bounded sample: ONE image of the same batch (the batch of 8 would take ~10 s per forward)
+        from oracle import sr_ref as R
+        torch.set_num_threads(usable_cores())
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        xc = x[:1].cpu()
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            ref = R.drn_forward(sd, xc, m.cfg)
+            first = time.perf_counter() - t0
+            n = max(1, min(10, int(args.cpu_seconds / max(first, 1e-3))))
+            t0 = time.perf_counter()
+            for _ in range(n):
+                R.drn_forward(sd, xc, m.cfg)
+            cpu_t = (time.perf_counter() - t0) / n
+            got = m(x[:1])[-1].cpu()
+        out["cpu_baseline"] = {"value": round(256 * 256 / cpu_t / 1e6, 4), "unit": "HR Mpixels/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{n} forwards of ONE image of the C3 batch (fp32, torch CPU kernels via oracle/sr_ref.py), {cpu_t * 1e3:.0f} ms each"}
+        out["speedup_vs_cpu"] = round(out["hr_mpixels_per_s"] / out["cpu_baseline"]["value"], 1)
+        out["max_rel_err_vs_cpu_fp32"] = float(f"{float((got - ref[-1]).abs().max() / ref[-1].abs().max()):.3e}")
     del m
     torch.cuda.empty_cache()
     return out
@@ -354,7 +430,7 @@ def drn_train_leg(args, torch, dev):
     """DRN-L x4 training step at the C3 shape (src/trainer.py:161-205 with dual_model=True): SR net + two dual regression
     models, composite loss, one fused Adam for the SR net and a torch Adam per dual model; batch 8, RGB, 256 px HR."""
     from srad_amd.nets import DRN, DownBlock
-    from srad_amd.train import FusedAdam, drn_train_step
+    from srad_amd.train import FusedAdam, TensorAdam, drn_train_step
 
     class DrnOpt:
         n_colors, n_blocks, n_feats, negval, rgb_range, scale = 3, 40, 20, 0.2, 255.0, [2, 4]
@@ -364,7 +440,7 @@ def drn_train_leg(args, torch, dev):
     m.enable_training()
     duals = [DownBlock(DrnOpt()).to(dev) for _ in DrnOpt.scale]
     opt = FusedAdam(m, lr=1e-4, weight_decay=1e-8)
-    dopts = [torch.optim.Adam(d.parameters(), lr=1e-4, weight_decay=1e-8) for d in duals]
+    dopts = [TensorAdam(d.parameters(), lr=1e-4, weight_decay=1e-8) for d in duals]      # the engine's Adam kernel, as the Trainer uses it
     B = 8
     lrs = [torch.rand(B, 3, 64, 64, device=dev) * 255, torch.rand(B, 3, 128, 128, device=dev) * 255]
     hr = torch.rand(B, 3, 256, 256, device=dev) * 255
@@ -378,9 +454,11 @@ def drn_train_leg(args, torch, dev):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     fl = 3.0 * m.flops(B, 64, 64)
+    prof = profile_eager(lambda: drn_train_step(m, duals, lrs, hr, opt, dopts), 3)
     out = {"workload": "DRN-L x4 train step (SR net + 2 dual models, composite loss, Adam), RGB, 256 px HR, batch 8",
            "ms_per_step": round(dt * 1e3, 2), "images_per_s": round(B / dt, 1), "hr_mpixels_per_s": round(B * 256 * 256 / dt / 1e6, 2),
-           "model_tflops": round(fl / dt / 1e12, 1), "loss": round(float(loss), 4)}
+           "model_tflops": round(fl / dt / 1e12, 1), "loss": round(float(loss), 4), "kernels": kernel_table(prof, 3),
+           "roofline": kernel_roofline(prof, 3, "drn_train", PEAK[args.dtype])}
     del m, duals, opt, dopts
     torch.cuda.empty_cache()
     return out
@@ -401,6 +479,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-train-graph", action="store_true", help="C4 leg: eager launches instead of one hipGraph per step")
     ap.add_argument("--train-batch", type=int, default=8)
     ap.add_argument("--train-steps", type=int, default=10)
+    ap.add_argument("--only", default="", choices=["", "c3", "c4", "c5", "drn_train", "scorer"],
+                    help="run ONE secondary leg and print its object (the program of the per-leg counter passes, tools/pmc_passes.sh)")
     return ap.parse_args(argv)
 
 
@@ -464,6 +544,27 @@ def parity_mode_leg(model, x, y_bf16, args, torch, dev, mode="bf16x3"):
                         "launches_per_step": d["launches"] // reps, "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 3)},
            "headline_bf16_vs_this_mode_max_rel": float(f"{float((y_bf16 - y32).abs().max() / y32.abs().max()):.3e}")}
     return out, y32, m32
+
+
+def run_only(args):
+    """One secondary leg on one GPU, eager where that matters to a profiler (counter passes: tools/pmc_passes.sh)."""
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    args.no_cpu_baseline = True
+    if args.only == "c3":
+        out = c3_leg(args, torch, dev)
+    elif args.only == "c5":
+        out = c5_leg(args, torch, dev)
+    elif args.only == "c4":
+        args.no_train_graph, args.train_steps = True, 3
+        out = train_leg(args, torch, dist, dev, 1, 0)
+    elif args.only == "drn_train":
+        out = drn_train_leg(args, torch, dev)
+    else:
+        out = scorer_leg(torch, dev)
+    print(json.dumps({args.only: out}), flush=True)
 
 
 def run_rank(args):
@@ -659,6 +760,8 @@ def run_rank(args):
 
 def main(argv=None):
     args = parse_args(argv)
+    if args.only:
+        return run_only(args)
     plan = rank_plan(args)
     if plan:
         # --gpus N without a launcher: start N ranks from THIS process, which has not touched the GPU (no torch.cuda call

@@ -172,7 +172,38 @@ def main():
         with torch.no_grad():
             out[name + "/dual"] = d(ys[-1]).numpy()
 
-    np.savez_compressed(os.path.join(HERE, "sr_golden.npz"), **out)
+    if "--grad-only" not in sys.argv:
+        np.savez_compressed(os.path.join(HERE, "sr_golden.npz"), **out)
+
+    # ---------------------------------------------------------------- G7 for the other window sizes (round 3): sr_grad_golden.npz
+    # The reference's remaining CLI presets build windows of 2, 4 and 16 (window_size = img_size // 4, src/main.py:218-219,286);
+    # the same cases as above (1 RDG; x8 for the window-2 one), gradients of the reference's autograd under nn.L1Loss, eval
+    # mode (DropPath off): dLoss/dx, the L2 norm of every parameter gradient and a few whole tensors.
+    gr = {}
+    for name in ("drct_r1_gray_x4_ws4", "drct_r1_gray_x8_ws2", "drct_r1_gray_x4_ws16"):
+        cfg, B, H, W, seed = drct_cases[name]
+        m, sp = ref_drct(cfg)
+        load_synth(m, sp, seed, cfg)
+        m.eval()
+        x = torch.from_numpy(S.synth_image(name, (B, cfg.in_chans, H, W), seed=1))
+        xg = x.clone().requires_grad_(True)
+        hr = torch.from_numpy(S.synth_image(name + "/hr", (B, cfg.in_chans, H * cfg.upscale, W * cfg.upscale), seed=2))
+        loss = torch.nn.L1Loss(reduction="mean")(m(xg), hr)
+        loss.backward()
+        gn = {k: p.grad for k, p in m.named_parameters()}
+        gr[name + "/hr"] = hr.numpy()
+        gr[name + "/loss"] = np.array(loss.item(), dtype=np.float64)
+        gr[name + "/grad_x"] = xg.grad.numpy()
+        for k in ["conv_first.weight", "layers.0.swin2.attn.relative_position_bias_table", "layers.0.swin4.attn.relative_position_bias_table",
+                  "layers.0.swin1.attn.qkv.weight", "layers.0.swin3.attn.proj.weight", "layers.0.swin5.mlp.fc2.bias",
+                  "layers.0.adjust1.weight", "layers.0.swin1.norm1.weight", "conv_last.weight"]:
+            gr[f"{name}/grad/{k}"] = gn[k].numpy()
+        gr[name + "/grad_names"] = np.array(list(gn.keys()))
+        gr[name + "/grad_l2"] = np.array([float(g.double().pow(2).sum().sqrt()) for g in gn.values()])
+        print(name, "loss %.5f" % loss.item(), "grad_x absmax %.3e" % xg.grad.abs().max())
+    np.savez_compressed(os.path.join(HERE, "sr_grad_golden.npz"), **gr)
+    if "--grad-only" in sys.argv:
+        return
 
     # ---------------------------------------------------------------- scorer goldens (G9, G10)
     sc = {}

@@ -239,6 +239,38 @@ def test_window_attention_bwd(dev, d, heads, shift, prec):
     assert _rel(dtable, table.grad) < tol
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("ws,shift,B,H,W,d,heads", [(2, 1, 2, 8, 6, 180, 6), (2, 0, 1, 4, 4, 212, 4), (4, 2, 2, 8, 12, 180, 6), (4, 0, 1, 8, 8, 244, 2),
+                                                    (16, 8, 1, 32, 48, 180, 6), (16, 0, 1, 16, 32, 212, 4), (16, 8, 1, 32, 32, 244, 2),
+                                                    (16, 8, 1, 32, 16, 276, 6), (16, 0, 1, 16, 16, 308, 4), (12, 6, 1, 24, 24, 60, 2),
+                                                    (3, 1, 1, 9, 6, 32, 2), (1, 0, 1, 4, 4, 32, 2)])
+def test_window_attention_bwd_other_window_sizes(dev, prec, ws, shift, B, H, W, d, heads):
+    """The reference's CLI builds windows of 2, 4, 8 and 16 (window_size = img_size // 4, src/main.py:218-219,286): the general
+    attention backward (window_attn_bwd_gen_kernel: N = ws^2 tokens padded to blocks of 64, one to four blocks) against autograd
+    of the oracle's attention; several windows per side with the shift mask, every DRCT-L head dim.  fp32 MFMAs in both modes."""
+    from oracle import sr_ref as R
+    from srad_amd import ops
+    g = torch.Generator().manual_seed(ws * 1000 + d + shift)
+    T, N, hd = B * H * W, ws * ws, d // heads
+    qkv = (torch.randn(T, 3 * d, generator=g) * 0.7).requires_grad_(True)
+    table = (torch.randn((2 * ws - 1) ** 2, heads, generator=g) * 0.5).requires_grad_(True)
+    dout = torch.randn(T, d, generator=g)
+    x = qkv.view(B, H, W, 3 * d)
+    if shift:
+        x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))
+    xw = R.window_partition(x, ws).view(-1, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    mask = R.calculate_mask(H, W, ws, shift) if shift else None
+    o = R.attention_from_qkv(xw[0] * hd ** -0.5, xw[1], xw[2], table, ws, mask)             # src/drct.py:282-299
+    o = R.window_reverse(o.transpose(1, 2).reshape(-1, ws, ws, d), ws, H, W)
+    if shift:
+        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+    o.reshape(T, d).backward(dout)
+    dqkv, dtable = ops.window_attention_bwd(qkv.detach().to(dev), dout.to(dev), table.detach().to(dev), B, H, W, ws, shift, heads, precision=prec)
+    e1, e2 = _rel(dqkv, qkv.grad), _rel(dtable, table.grad)
+    print(f"attention backward ws={ws} shift={shift} d={d} heads={heads} {prec}: dqkv {e1:.2e} dtable {e2:.2e}")
+    assert e1 < 2e-4 and e2 < 2e-4
+
+
 def test_adam_and_l1_grad_match_torch(dev):
     import ctypes as C
     from srad_amd import _lib as L

@@ -57,6 +57,35 @@ def test_gradients_match_reference_autograd_golden(sr_golden):
     print("worst relative L2-norm error over", len(names), "parameter tensors:", worst)
 
 
+@pytest.mark.parametrize("name", ["drct_r1_gray_x4_ws4", "drct_r1_gray_x8_ws2", "drct_r1_gray_x4_ws16"])
+def test_gradients_match_reference_autograd_golden_other_window_sizes(sr_golden, name):
+    """G7 extended (round 3, tests/golden/sr_grad_golden.npz from tests/golden/make_golden.py --grad-only): the reference's own
+    autograd under nn.L1Loss for the window-4, window-2 (x8) and window-16 presets of its CLI (src/main.py:218-219,286)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sr_grad_golden.npz"))
+    cfg, sd, x, y = drct_case(sr_golden, name)
+    m = build_train(cfg, sd, "fp32")
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    hr = torch.from_numpy(g[name + "/hr"]).cuda()
+    out = m(xt)
+    assert rel_err(out.detach().cpu().numpy(), y) < 2e-4
+    loss = F.l1_loss(out, hr)
+    assert abs(float(loss.detach()) - float(g[name + "/loss"])) < 1e-5 * abs(float(g[name + "/loss"]))
+    loss.backward()
+    assert rel_err(xt.grad.cpu().numpy(), g[name + "/grad_x"]) < 1e-3
+    grads = dict(m.named_parameters())
+    for k in [k for k in g.files if k.startswith(name + "/grad/")]:
+        pname = k[len(name + "/grad/"):]
+        e = rel_err(grads[pname].grad.cpu().numpy(), g[k])
+        assert e < 1e-3, (pname, e)
+    worst = 0.0
+    for n, ref in zip([str(n) for n in g[name + "/grad_names"]], g[name + "/grad_l2"]):
+        mine = float(grads[n].grad.double().pow(2).sum().sqrt())
+        worst = max(worst, abs(mine - ref) / max(ref, 1e-12))
+        assert abs(mine - ref) <= 1e-3 * max(ref, 1e-9), (n, mine, ref)
+    print(name, "worst relative L2-norm error over the parameter tensors:", worst)
+
+
 @pytest.mark.parametrize("gray", [True, False])
 def test_training_forward_backward_with_droppath_matches_oracle(gray):
     from oracle import sr_ref as R
@@ -96,6 +125,48 @@ def test_training_forward_backward_with_droppath_matches_oracle(gray):
     assert float((m.flat_grads - 2 * g1).abs().max()) <= 1e-4 * float(g1.abs().max())
     m.zero_grad()
     assert float(m.flat_grads.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("ws,img,up,B,H,W", [(2, 8, 4, 2, 8, 6), (4, 16, 4, 2, 16, 8), (16, 64, 4, 1, 32, 32), (2, 8, 8, 1, 8, 8)])
+def test_training_other_window_sizes_matches_oracle_autograd(ws, img, up, B, H, W, prec):
+    """The reference's other CLI presets (window_size = img_size // 4 in {2, 4, 16}; src/main.py:218-219,286 - x8 at 64 px builds
+    window 2 as well): training forward + backward with DropPath masks against autograd of the oracle.  These take the unfused
+    launches and the general attention backward (fp32 MFMAs); bf16 mode rounds the GEMM operands (bar as the ws-8 bf16 test)."""
+    from oracle import sr_ref as R
+    from srad_amd import spec as S
+    cfg = S.DRCTConfig(in_chans=1, img_size=img, window_size=ws, upscale=up, n_rdg=2)
+    sd = S.synth_state(S.drct_spec(cfg), seed=70 + ws, gain=1.0, cfg=cfg)
+    x = S.synth_image("trws", (B, 1, H, W), seed=5)
+    hr = S.synth_image("trws/hr", (B, 1, H * up, W * up), seed=6)
+    gen = torch.Generator().manual_seed(2)
+    keep = torch.floor(0.8 + torch.rand(2 * cfg.n_rdg * 5, B, generator=gen)) / 0.8
+    sdt = {k: torch.from_numpy(np.asarray(v)).clone().requires_grad_(np.asarray(v).dtype == np.float32) for k, v in sd.items()}
+    keeps = [[(keep[2 * (i * 5 + k)], keep[2 * (i * 5 + k) + 1]) for k in range(5)] for i in range(cfg.n_rdg)]
+    xr = torch.from_numpy(x).requires_grad_(True)
+    ref = R.drct_forward(sdt, xr, cfg, keeps=keeps)
+    F.l1_loss(ref, torch.from_numpy(hr)).backward()
+    m = build_train(cfg, sd, prec, drop_path_rate=0.1)
+    assert m._can_train()
+    m.keep_scale_override = keep.cuda()
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    out = m(xt)
+    F.l1_loss(out, torch.from_numpy(hr).cuda()).backward()
+    if prec == "fp32":
+        assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < 2e-4
+        assert rel_err(xt.grad.cpu().numpy(), xr.grad.numpy()) < 1e-3
+        worst = ("", 0.0)
+        for n, p in m.named_parameters():
+            e = rel_err(p.grad.cpu().numpy(), sdt[n].grad.numpy())
+            worst = max(worst, (n, e), key=lambda t: t[1])
+            assert e < 1e-3, (n, e)
+        print(f"window {ws}: worst parameter-gradient error {worst}")
+    else:
+        a = torch.cat([sdt[n].grad.reshape(-1) for n, _ in m.named_parameters()]).double()
+        b = torch.cat([p.grad.reshape(-1).cpu() for _, p in m.named_parameters()]).double()
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        print(f"window {ws} bf16: cosine(oracle fp32 grad, engine bf16 grad) = {cos}, norm ratio {float(b.norm() / a.norm())}")
+        assert cos > 0.99 and 0.9 < float(b.norm() / a.norm()) < 1.1
 
 
 def test_random_droppath_masks_have_reference_statistics():
@@ -168,12 +239,12 @@ def test_bf16_training_gradients_close_to_fp32(sr_golden):
 def test_training_errors_are_reported():
     from srad_amd import spec as S
     from srad_amd.nets import DRCT
-    cfg = S.DRCTConfig(in_chans=1, img_size=16, window_size=4, upscale=2, n_rdg=1)
+    cfg = S.DRCTConfig(in_chans=1, img_size=80, window_size=20, upscale=2, n_rdg=1)      # no CLI preset builds windows above 16
     o = Opt(cfg, "fp32")
     m = DRCT(o).cuda().train()
-    assert not m._can_train()                                # the Trainer refuses this preset up front
-    with pytest.raises(NotImplementedError, match="window size 8"):
-        m(torch.zeros(1, 1, 8, 8, device="cuda"))
+    assert not m._can_train()                                # the Trainer refuses this up front
+    with pytest.raises(NotImplementedError, match="window sizes up to 16"):
+        m(torch.zeros(1, 1, 20, 20, device="cuda"))
     with pytest.raises(RuntimeError, match="GPU only"):
         DRCT(o).train()(torch.zeros(1, 1, 8, 8))
 

@@ -55,7 +55,8 @@ def classify(name: str) -> str:
                      ("window_attn_bwd", "window_attn_bwd"), ("window_attn_kernel", "window_attn"), ("layernorm_kernel", "layernorm"),
                      ("wgrad_multi", "wgrad"), ("conv80_kernel", "conv80"), ("wgrad_kernel", "wgrad"), ("wgrad_reduce_kernel", "wgrad_reduce"),
                      ("ln_bwd_kernel", "layernorm_bwd"), ("mlp_bwd_kernel", "mlp_bwd"), ("lin_ln_bwd_kernel", "lin_ln_bwd"),
-                     ("sat_", "scorer"), ("ssim_eval", "scorer")):
+                     ("ln_qkv_kernel", "ln_qkv"), ("wgrad_conv9", "wgrad"), ("wgrad80", "wgrad"), ("adam", "optim"), ("pack_", "pack_weight"), ("sync_params", "pack_weight"),
+                     ("sat_", "scorer"), ("ssim_", "scorer"), ("mse_", "scorer")):
         if key in name:
             return cls
     return "other"
@@ -119,8 +120,8 @@ def main():
                 out["grbm_cycles"] = round(avg["GRBM_GUI_ACTIVE"] / 8.0)
         return out
 
-    res = {"source": "rocprofv3 --pmc passes (one counter group per process) of `bench.py --no-graph --no-train --no-eval "
-                     "--no-cpu-baseline`: the C2 forward, eager launches",
+    res = {"source": "rocprofv3 --pmc passes (one counter group per process) of " + os.environ.get("PMC_BENCH", "`bench.py --no-graph --no-train "
+                     "--no-eval --no-cpu-baseline`: the C2 forward") + ", eager launches",
            "corrections": "FETCH_SIZE/WRITE_SIZE KiB -> bytes; FETCH_SIZE x2 (16 B/lane coalesced loads: 128-B requests tallied at 64 B)",
            "kernel_source_sha": kernel_source_sha(), "kernels": {}, "instances": {}}
     for k, ctrs in cls_sum.items():
