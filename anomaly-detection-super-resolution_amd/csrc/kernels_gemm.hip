@@ -596,6 +596,11 @@ int launch_one(const GemmParams& p, hipStream_t s) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = true;
   }
+  // pool_part rows are summed per image by callers that size them with srad_gemm_tile_rows(): a tile choice that drifts from that
+  // mirror, or an image that is not a whole number of tiles, must fail here instead of averaging the wrong rows
+  if (p.pool_part)
+    SRAD_REQUIRE(BM == srad_gemm_tile_rows(PREC, p) && p.Ho > 0 && (p.Ho * p.Wo) % BM == 0,
+                 "gemm: pool_part with %d-row tiles, but srad_gemm_tile_rows says %d and an image has %d rows", BM, srad_gemm_tile_rows(PREC, p), p.Ho * p.Wo);
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
   const int cls = BN >= 64 ? SRAD_K_GEMM_BN64 : (BN == 32 ? SRAD_K_GEMM_BN32 : SRAD_K_GEMM_BN16);
   // algorithmic work: 2*M*N*K flops; bytes = A rows once + packed W once + Y once (+ residual)

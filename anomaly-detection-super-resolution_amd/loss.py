@@ -177,8 +177,21 @@ class Loss(nn.modules.loss._Loss):
         self._acc = None
 
     def _flush(self):
+        """Fold this rank's running sums into the log row.  Under data parallelism every rank has accumulated the loss of ITS
+        slice of each global minibatch: the rows are averaged over the ranks first, so the log (rank 0 writes it) is the loss of
+        the global minibatch, which is what the reference's single process logs.  Collective: every rank flushes at the same
+        points (display_loss / end_log are called by all of them)."""
         if self._acc is not None and self.log.numel():
-            self.log[-1] += self._acc.float().cpu()
+            acc = self._acc
+            try:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                    acc = acc.clone()
+                    dist.all_reduce(acc)
+                    acc /= dist.get_world_size()
+            except ImportError:
+                pass
+            self.log[-1] += acc.float().cpu()
             self._acc = None
 
     def end_log(self, n_batches):

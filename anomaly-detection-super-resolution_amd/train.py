@@ -302,10 +302,12 @@ def drn_train_step(model, dual_models, lr_list, hr, optimizer, dual_optimizers, 
     scale = 1.0
     if reducer is not None:
         reducer.reduce_all(model.flat_grads, [(0, model.flat_grads.numel())])
-        for dm in dual_models:
+        scale = reducer.grad_scale
+        for dm, o in zip(dual_models, dual_optimizers):
             for p in dm.parameters():
                 reducer.dist.all_reduce(p.grad, group=reducer.group)
-        scale = reducer.grad_scale
+                if not isinstance(o, TensorAdam):
+                    p.grad.mul_(scale)               # an optimizer without a grad_scale argument sees the mean itself
     optimizer.step(grad_scale=scale)
     for o in dual_optimizers:
         o.step(scale) if isinstance(o, TensorAdam) else o.step()
@@ -325,6 +327,11 @@ class GraphedDrnTrainStep:
         for o in dual_optimizers:
             if not isinstance(o, TensorAdam):
                 raise TypeError("GraphedDrnTrainStep needs TensorAdam dual optimizers (torch.optim steps read host scalars)")
+        if hasattr(loss_fn, "note"):
+            # a loss.Loss keeps its log by calling note() from Python on every forward: inside a capture that runs once, and the
+            # replays would re-add the capture-time values.  The Trainer logs through the eager step.
+            raise TypeError("GraphedDrnTrainStep takes loss_fn=None (the reference's 1*L1) or a plain callable, not a logging loss.Loss; "
+                            "use drn_train_step for that")
         self.model, self.duals, self.optimizer, self.dual_optimizers = model, list(dual_models), optimizer, list(dual_optimizers)
         self.dual_weight, self.loss_fn, self.warmup = float(dual_weight), loss_fn, int(warmup)
         self._graphs = {}

@@ -155,6 +155,104 @@ def test_gradient_buckets_allreduce_gloo_world2():
         assert np.array_equal(res[r][1], res[r][2])
 
 
+class _FlatNet(torch.nn.Module):
+    """A CPU stand-in with the engine modules' training surface: parameters and gradients are views of two flat buffers."""
+
+    def __init__(self, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        shapes = [(2, 1, 3, 3), (2,), (1, 2, 3, 3)]
+        n = sum(int(np.prod(s)) for s in shapes)
+        self.flat_params = torch.randn(n, generator=g) * 0.3
+        self.flat_grads = torch.zeros(n)
+        self.ps, off = torch.nn.ParameterList(), 0
+        for s in shapes:
+            k = int(np.prod(s))
+            p = torch.nn.Parameter(self.flat_params[off:off + k].view(s))
+            p.grad = self.flat_grads[off:off + k].view(s)
+            self.ps.append(p)
+            off += k
+
+    def forward(self, x):
+        import torch.nn.functional as F
+        y = F.conv2d(F.relu(F.conv2d(x, self.ps[0], self.ps[1], padding=1)), self.ps[2], padding=1)
+        return [y, F.interpolate(y, scale_factor=2.0)]
+
+
+class _Sgd:
+    def __init__(self, params):
+        self.params, self.scales = list(params), []
+
+    def zero_grad(self):
+        for p in self.params:
+            if p.grad is not None:
+                p.grad.zero_()
+
+    def step(self, grad_scale=1.0):
+        self.scales.append(grad_scale)
+        with torch.no_grad():
+            for p in self.params:
+                p -= 0.1 * grad_scale * p.grad
+
+
+def _drn_dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from srad_amd.loss import Loss
+    from srad_amd.train import GradReducer, drn_train_step
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = _FlatNet(1)                                              # identical replicas
+    dual = torch.nn.Conv2d(1, 1, 3, stride=2, padding=1, bias=False)
+    with torch.no_grad():
+        dual.weight.fill_(0.1)
+    red = GradReducer(overlap=False)
+    g = torch.Generator().manual_seed(5)
+    lr_all, hr_all = torch.rand(4, 1, 8, 8, generator=g), torch.rand(4, 1, 16, 16, generator=g)
+    sl = slice(rank, None, world) if world > 1 else slice(None)
+    opt, dopt = _Sgd(net.parameters()), _Sgd(dual.parameters())
+    loss = drn_train_step(net, [dual], [lr_all[sl]], hr_all[sl], opt, [dopt], 0.1, red if world > 1 else None,
+                          torch.nn.functional.l1_loss)            # (the engine's L1 reduction is GPU-only; the step's plumbing is what runs here)
+    # the logging Loss: every rank notes its slice's loss, the flushed row is the global minibatch's mean
+    class A: loss, rgb_range, batch_size, print_every, save = "1*L1", 255, 2, 1, "."
+    L_ = Loss.__new__(Loss)
+    L_.loss, L_.log, L_._acc = [{"type": "L1", "weight": 1.0, "function": None}], torch.zeros(1, 1), None
+    L_.note([loss])
+    L_._flush()
+    q.put((rank, net.flat_params.tolist(), dual.weight.detach().reshape(-1).tolist(), float(loss), float(L_.log[-1, 0]), opt.scales))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_drn_data_parallel_step_and_loss_log_gloo_world2():
+    """``drn_train_step``'s reducer branch (gradients of the SR net's flat buffer and of the dual models all-reduced, 1 / world into
+    the optimizers) and ``Loss._flush`` under world 2 over gloo: two ranks on half batches end with the parameters of one rank
+    on the full batch, and the logged loss is the mean over the ranks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = {}
+    for world in (1, 2):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_drn_dp_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=180) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        out[world] = sorted(res)
+    one = out[1][0]
+    for r in (0, 1):
+        rank, params, dw, loss, logged, scales = out[2][r]
+        assert np.allclose(params, one[1], atol=1e-6) and np.allclose(dw, one[2], atol=1e-6)       # half batches, summed, / 2 == the full batch
+        assert scales == [0.5]
+        assert abs(logged - 0.5 * (out[2][0][3] + out[2][1][3])) < 1e-6                           # the log row: mean over the ranks
+    assert abs(out[2][0][4] - one[4]) < 1e-5                                                        # == the one-rank log of the full batch (L1 is a mean)
+
+
 def test_cosine_schedule_matches_torch():
     from srad_amd.train import cosine_lr
     p = torch.nn.Parameter(torch.zeros(1))
