@@ -128,11 +128,15 @@ def gather_score_rows(mine: Sequence[int], rows: np.ndarray, total: int, rank: i
 
 
 @torch.no_grad()
-def super_resolve_u8(model, lr_u8: Sequence[np.ndarray], hr_u8: Sequence[np.ndarray], rgb_range: float, batch: int = 8
+def super_resolve_u8(model, lr_u8: Sequence[np.ndarray], hr_u8: Sequence[np.ndarray], rgb_range: float, batch: int = 0
                      ) -> Tuple[torch.Tensor, torch.Tensor]:
     """collect_pairs (src/evaluate.py:204-224): forward, crop to the HR size, truncate to u8.
-    Returns (sr, hr) uint8 stacks [n,H,W,C] on the GPU."""
+    Returns (sr, hr) uint8 stacks [n,H,W,C] on the GPU.  ``batch`` images per forward; 0 = as many as make ~64 k LR pixels
+    (64 images at 128 px / x4, one 1024 px tile): the reference forwards one image at a time, the outputs per image are the same
+    and the chip is only filled from a few thousand tokens up (78 pairs at 128 px: 1830 -> 2120 images/s in split-bf16 mode)."""
     dev = model.device if hasattr(model, 'device') else next(model.parameters()).device
+    if batch <= 0 and len(lr_u8):
+        batch = max(1, min(64, 65536 // max(1, lr_u8[0].shape[0] * lr_u8[0].shape[1])))
     sr_out: List[torch.Tensor] = []
     for i in range(0, len(lr_u8), batch):
         lr = torch.from_numpy(np.stack(lr_u8[i:i + batch])).to(dev).permute(0, 3, 1, 2).float() * (rgb_range / 255.0)   # np2Tensor

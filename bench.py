@@ -400,30 +400,43 @@ def c3_leg(args, torch, dev):
            "hr_mpixels_per_s": round(8 * 256 * 256 / dt / 1e6, 2), "algorithmic_gflop": round(fl / 1e9, 1),
            "model_tflops": round(fl / dt / 1e12, 1), "kernels": kernel_table(prof, 5),
            "roofline": kernel_roofline(prof, 5, "c3", PEAK[args.dtype])}
-    if not args.no_cpu_baseline:
-        # the reference's --device cpu path beside every config - the oracle's DRN forward (stock torch CPU
-        # kernels, fp32) on a bounded sample: ONE image of the same batch (the batch of 8 would take ~10 s per forward)
-        from oracle import sr_ref as R
-        torch.set_num_threads(usable_cores())
-        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
-        xc = x[:1].cpu()
-        with torch.no_grad():
-            t0 = time.perf_counter()
-            ref = R.drn_forward(sd, xc, m.cfg)
-            first = time.perf_counter() - t0
-            n = max(1, min(10, int(args.cpu_seconds / max(first, 1e-3))))
-            t0 = time.perf_counter()
-            for _ in range(n):
-                R.drn_forward(sd, xc, m.cfg)
-            cpu_t = (time.perf_counter() - t0) / n
-            got = m(x[:1])[-1].cpu()
-        out["cpu_baseline"] = {"value": round(256 * 256 / cpu_t / 1e6, 4), "unit": "HR Mpixels/s", "cores": torch.get_num_threads(), "kind": "port",
-                               "sample": f"{n} forwards of ONE image of the C3 batch (fp32, torch CPU kernels via oracle/sr_ref.py), {cpu_t * 1e3:.0f} ms each"}
-        out["speedup_vs_cpu"] = round(out["hr_mpixels_per_s"] / out["cpu_baseline"]["value"], 1)
-        out["max_rel_err_vs_cpu_fp32"] = float(f"{float((got - ref[-1]).abs().max() / ref[-1].abs().max()):.3e}")
     del m
     torch.cuda.empty_cache()
     return out
+
+
+def c3_cpu_baseline(args, torch, dev, c3):
+    """the reference's --device cpu path beside every config - the oracle's DRN forward (stock torch CPU kernels,
+    fp32) on a bounded sample: ONE image of the C3 batch (the batch of 8 would take ~1 s per forward).  Runs after every GPU leg:
+    a CPU thread pool left spinning slows the host-side launch loops of the eager legs (seen: DRN training 22 -> 26 ms)."""
+    from oracle import sr_ref as R
+    from srad_amd.nets import DRN
+
+    class DrnOpt:
+        n_colors, n_blocks, n_feats, negval, rgb_range, scale = 3, 40, 20, 0.2, 255.0, [2, 4]
+        precision, use_graph = args.dtype, False
+    torch.manual_seed(1)
+    m = DRN(DrnOpt()).to(dev).eval()
+    x = torch.rand(8, 3, 64, 64, device=dev) * 255.0
+    torch.set_num_threads(usable_cores())
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    xc = x[:1].cpu()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        ref = R.drn_forward(sd, xc, m.cfg)
+        first = time.perf_counter() - t0
+        n = max(1, min(10, int(args.cpu_seconds / max(first, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            R.drn_forward(sd, xc, m.cfg)
+        cpu_t = (time.perf_counter() - t0) / n
+        got = m(x[:1])[-1].cpu()
+    c3["cpu_baseline"] = {"value": round(256 * 256 / cpu_t / 1e6, 4), "unit": "HR Mpixels/s", "cores": torch.get_num_threads(), "kind": "port",
+                          "sample": f"{n} forwards of ONE image of the C3 shape (fp32, torch CPU kernels via oracle/sr_ref.py), {cpu_t * 1e3:.0f} ms each"}
+    c3["speedup_vs_cpu"] = round(c3["hr_mpixels_per_s"] / c3["cpu_baseline"]["value"], 1)
+    c3["max_rel_err_vs_cpu_fp32"] = float(f"{float((got - ref[-1]).abs().max() / ref[-1].abs().max()):.3e}")
+    del m
+    torch.cuda.empty_cache()
 
 
 def drn_train_leg(args, torch, dev):
@@ -752,6 +765,11 @@ def run_rank(args):
                     result["drn_train"] = drn_train_leg(args, torch, dev)
                 except Exception as e:                    # a secondary leg never takes the headline line down
                     result["drn_train"] = {"error": f"{type(e).__name__}: {e}"}
+            if not args.no_cpu_baseline:
+                try:
+                    c3_cpu_baseline(args, torch, dev, result["drn_forward"])
+                except Exception as e:
+                    result["drn_forward"]["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

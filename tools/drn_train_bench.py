@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--graph", action="store_true", help="time the step as one replayed hipGraph (train.GraphedDrnTrainStep)")
+    ap.add_argument("--tensor-adam", action="store_true", help="the engine's Adam kernel for the dual models (what the Trainer uses) instead of torch.optim.Adam")
     a = ap.parse_args()
     o = Opt()
     o.precision = a.dtype
@@ -35,6 +36,9 @@ def main():
     duals = [DownBlock(o).cuda() for _ in o.scale]
     opt = FusedAdam(m, lr=1e-4, weight_decay=1e-8)
     dopts = [torch.optim.Adam(d.parameters(), lr=1e-4, weight_decay=1e-8) for d in duals]
+    if a.tensor_adam:
+        from srad_amd.train import TensorAdam
+        dopts = [TensorAdam(d.parameters(), lr=1e-4, weight_decay=1e-8) for d in duals]
     B = a.batch
     lrs = [torch.rand(B, 3, 64, 64, device="cuda") * 255, torch.rand(B, 3, 128, 128, device="cuda") * 255]
     hr = torch.rand(B, 3, 256, 256, device="cuda") * 255
