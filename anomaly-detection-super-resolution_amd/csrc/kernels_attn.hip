@@ -419,7 +419,8 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
       lds = base + (size_t)4 * 128 * 4;            // a four-row ring of the bias table
     }
   }
-  static size_t configured[6] = {0, 0, 0, 0, 0, 0};
+  static size_t configured_dev[16][6] = {};          // per device (hipFuncSetAttribute applies to the current one)
+  size_t (&configured)[6] = configured_dev[srad_device_slot()];
   const int slot = row64 ? (p.qkv_h ? 5 : 4) : tbl_in_lds * 2 + full;
   if (lds > configured[slot]) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -951,10 +951,10 @@ int launch_wgrad80(const WgradParams& p, WgradQueue& q, hipStream_t s) {
   }
   SradProfScope prof(s, SRAD_K_WGRAD, 2.0 * p.M * 80.0 * 80.0 * p.ntaps, 4.0 * p.M * 160.0 + 8.0 * 6400.0 * p.ntaps);
   auto launch = [&](auto kern) -> int {
-    static bool configured = false;
-    if (!configured) {
+    static SradOncePerDevice configured;
+    if (configured.need()) {
       SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)W80_LDS));
-      configured = true;
+      configured.done();
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.ntaps * ksplit)), dim3(256), W80_LDS, s, p, (int)ksplit, part);
     return SRAD_OK;
@@ -1001,15 +1001,15 @@ int launch_wgrad_conv9(const WgradParams& p, WgradQueue& q, hipStream_t s) {
   it.ksplit = ksplit; it.tile0 = q.tiles; it.alpha = p.alpha;
   q.tiles += square_reduce_tiles(it, C);
   SradProfScope prof(s, SRAD_K_WGRAD, 2.0 * p.M * C * C * 9.0, 4.0 * p.M * 2.0 * C + 8.0 * 9.0 * PART * ksplit);
-  auto launch = [&](auto kern, const size_t lds, bool& configured) -> int {
-    if (!configured) {
+  auto launch = [&](auto kern, const size_t lds, SradOncePerDevice& configured) -> int {
+    if (configured.need()) {
       SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      configured = true;
+      configured.done();
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)ksplit), dim3(WC9S_THREADS), lds, s, p, cpw, nchunks, ksplit, part);
     return SRAD_OK;
   };
-  static bool cfg[6] = {false, false, false, false, false, false};
+  static SradOncePerDevice cfg[6];
   int rc = SRAD_OK;
   switch (nt) {
     case 1: rc = launch(wgrad_conv9_kernel<1>, Wc9<1>::LDS, cfg[1]); break;
@@ -1036,10 +1036,10 @@ int launch_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s) {
   const double K = (double)p.ntaps * p.cin_real;
   SradProfScope prof(s, SRAD_K_WGRAD, 2.0 * p.M * p.n_real * K, 4.0 * p.M * ((double)p.N + p.Cin) + 8.0 * p.n_real * K);
   auto launch = [&](auto kern) -> int {
-    static bool configured = false;
-    if (!configured) {
+    static SradOncePerDevice configured;
+    if (configured.need()) {
       SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS));
-      configured = true;
+      configured.done();
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), WG_LDS, s, p, pl.ksplit, pl.tn, pl.tc, pl.part);
     return SRAD_OK;
@@ -2189,10 +2189,10 @@ int srad_wgrad_launch_deferred(int prec, WgradQueue& q, hipStream_t stream) {
   {
     SradProfScope prof(stream, SRAD_K_WGRAD, q.multi_flops, q.multi_bytes);
     auto launch = [&](auto kern) -> int {
-      static bool configured = false;
-      if (!configured) {
+      static SradOncePerDevice configured;
+      if (configured.need()) {
         SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS));
-        configured = true;
+        configured.done();
       }
       hipLaunchKernelGGL(kern, dim3(total), dim3(256), WG_LDS, stream, m);
       return SRAD_OK;
@@ -2209,10 +2209,10 @@ int srad_wgrad_launch_deferred(int prec, WgradQueue& q, hipStream_t stream) {
     for (int i = 0; i < m.count && all_hh; ++i) all_hh = m.p[i].x_bf16 && m.p[i].dy_bf16;
     static const bool no_hh = getenv("SRAD_WGRAD_NO_HH") != nullptr;
     if (all_hh && !no_hh) {
-      static bool configured_hh = false;
-      if (!configured_hh) {
+      static SradOncePerDevice configured_hh;
+      if (configured_hh.need()) {
         SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_multi_hh_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS2));
-        configured_hh = true;
+        configured_hh.done();
       }
       hipLaunchKernelGGL(wgrad_multi_hh_kernel, dim3(total), dim3(256), WG_LDS2, stream, m);
     } else {
@@ -2307,10 +2307,10 @@ static int launch_attn_bwd_gen(const AttnBwdParams& p, WgradQueue& q, hipStream_
   SradProfScope prof(stream, SRAD_K_ATTN_BWD, 10.0 * T * p.ws * p.ws * p.d, 4.0 * T * 8 * p.d);
   const int nb = (p.ws * p.ws + 63) / 64;
   auto go = [&](auto kern, size_t lds) -> int {
-    static bool configured = false;                    // (one per kernel instance)
-    if (!configured) {
+    static SradOncePerDevice configured;                    // (one per kernel instance)
+    if (configured.need()) {
       SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      configured = true;
+      configured.done();
     }
     hipLaunchKernelGGL(kern, dim3(nwin * p.heads), dim3(256), lds, stream, p, tpart);
     return SRAD_OK;
@@ -2330,11 +2330,11 @@ int srad_launch_window_attn_bwd(int prec, const AttnBwdParams& p, WgradQueue& q,
   if (p.ws != 8) return launch_attn_bwd_gen(p, q, stream);
   SRAD_REQUIRE(p.d % p.heads == 0 && p.hdp % 4 == 0 && p.hdp >= p.d / p.heads, "window_attn_bwd: bad head geometry");
   SRAD_REQUIRE(p.shift >= 0 && p.shift < p.ws, "window_attn_bwd: bad shift %d", p.shift);
-  static bool configured = false;
-  if (!configured) {
+  static SradOncePerDevice configured;
+  if (configured.need()) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)AB_LDS));
-    configured = true;
+    configured.done();
   }
   const int nW = (p.H / p.ws) * (p.W / p.ws);
   const double T = (double)p.B * p.H * p.W;
@@ -2352,10 +2352,10 @@ int srad_launch_window_attn_bwd(int prec, const AttnBwdParams& p, WgradQueue& q,
                      (((uintptr_t)p.qkv_h | (uintptr_t)p.dout_h) & 15) == 0,
                  "window_attn_bwd: the all-bf16 form takes head dims <= 128 in 16-byte aligned slots of hp columns, and writes bf16");
     auto go = [&](auto kern, size_t lds) -> int {
-      static bool configured = false;                  // (one per instantiation of this lambda = per kernel instance)
-      if (!configured) {
+      static SradOncePerDevice configured;                  // (one per instantiation of this lambda = per kernel instance)
+      if (configured.need()) {
         SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
+        configured.done();
       }
       hipLaunchKernelGGL(kern, dim3(p.B * nW * p.heads), dim3(256), lds, stream, p, tpart);
       return SRAD_OK;
@@ -2366,11 +2366,11 @@ int srad_launch_window_attn_bwd(int prec, const AttnBwdParams& p, WgradQueue& q,
     else if (nch == 3) SRAD_TRY(go(window_attn_bwd_h_kernel<3>, ag_lds_bytes<3>()));
     else SRAD_TRY(go(window_attn_bwd_h_kernel<4>, ag_lds_bytes<4>()));
   } else if (prec == SRAD_PREC_BF16) {
-    static bool configured16 = false;
-    if (!configured16) {
+    static SradOncePerDevice configured16;
+    if (configured16.need()) {
       SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_bf16_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)AH_LDS));
-      configured16 = true;
+      configured16.done();
     }
     hipLaunchKernelGGL(window_attn_bwd_bf16_kernel, dim3(p.B * nW * p.heads), dim3(256), AH_LDS, stream, p, tpart);
   } else {

@@ -242,11 +242,11 @@ int srad_launch_conv80(const GemmParams& p, hipStream_t stream) {
   SRAD_REQUIRE(srad_conv80_supported(SRAD_PREC_BF16, p), "conv80: unsupported problem");
   const int tiles_x = p.Wi / C80_TW, tiles_per_img = (p.Hi / C80_TH) * tiles_x;
   const int B = p.M / (p.Hi * p.Wi), ntiles = B * tiles_per_img;
-  static bool configured = false;
-  if (!configured) {
+  static SradOncePerDevice configured;
+  if (configured.need()) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv80_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C80_LDS));
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv80_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C80_LDS));
-    configured = true;
+    configured.done();
   }
   const double K = 9.0 * 80;
   SradProfScope prof(stream, SRAD_K_CONV80, 2.0 * p.M * 80 * K, 4.0 * p.M * 80 * (p.R ? 3 : 2) + 2.0 * 80 * K);

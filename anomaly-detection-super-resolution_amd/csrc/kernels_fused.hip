@@ -481,10 +481,10 @@ template <int FM, int GD, int KGD, int GM, int KGM, int GN, int KCD, int KCM, bo
 int launch_mlp_fm(const MlpBlockParams& p, hipStream_t stream) {
   constexpr size_t lds = (size_t)(FM * F_LDA + FM * F_LDH) * 2 * (SPLIT ? 2 : 1) + (F_NV + FM * 16) * sizeof(float);
   auto kern = mlp_block_kernel<FM, GD, KGD, GM, KGM, GN, KCD, KCM, STAMP, SPLIT>;
-  static bool configured = false;
-  if (!configured) {
+  static SradOncePerDevice configured;
+  if (configured.need()) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
+    configured.done();
   }
   const double flops = 2.0 * p.M * ((double)p.d * p.d + 2.0 * p.d * p.m + (double)p.no * p.d);
   const double bytes = 4.0 * p.M * (2.0 * p.d + p.no) + 2.0 * ((double)p.d * p.d + 2.0 * p.d * p.m + (double)p.no * p.d);

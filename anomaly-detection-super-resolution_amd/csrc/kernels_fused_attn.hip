@@ -424,10 +424,10 @@ int launch_qa(const QkvAttnParams& p, hipStream_t stream) {
                          (size_t)(640 + 3 * HDP + 232 + 256 + 64 * QA_LDB) * sizeof(float) + 128 * sizeof(int);
   static_assert(lds <= 160 * 1024, "qkv_attn: LDS budget");
   auto kern = qkv_attn_kernel<HDT, KC, STAMP, SPLIT>;
-  static bool configured = false;
-  if (!configured) {
+  static SradOncePerDevice configured;
+  if (configured.need()) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
+    configured.done();
   }
   const double T = (double)p.B * p.H * p.W;
   const double flops = 2.0 * T * 3.0 * p.d * p.d + 4.0 * T * 64.0 * p.d;
@@ -593,10 +593,10 @@ template <int HDT, int KC, int HEADS>
 int launch_ln_qkv(const LnQkvParams& p, hipStream_t stream) {
   constexpr size_t lds = (size_t)64 * (KC * 32 + 8) * 2 + (size_t)(640 + HEADS * 3 * 16 * HDT) * sizeof(float);
   auto kern = ln_qkv_kernel<HDT, KC, HEADS>;
-  static bool configured = false;
-  if (!configured) {
+  static SradOncePerDevice configured;
+  if (configured.need()) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
+    configured.done();
   }
   SradProfScope prof(stream, SRAD_K_LN_QKV, 2.0 * p.M * 3.0 * p.d * p.d, 4.0 * p.M * p.d + 2.0 * p.M * 3.0 * p.d + 2.0 * 3.0 * p.d * p.d);
   hipLaunchKernelGGL(kern, dim3(p.M / 64), dim3(512), lds, stream, p);

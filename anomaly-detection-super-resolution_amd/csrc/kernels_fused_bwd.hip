@@ -590,10 +590,10 @@ int launch_lin_fm(const LinLnBwdParams& p, WgradQueue& q, hipStream_t stream) {
   constexpr int KG = (KC + 7) / 8;
   constexpr size_t lds = (size_t)FM * (KG * 256 + 8) * 2 + (384 + FM * 16) * sizeof(float);
   auto kern = p.dy_bf16 ? lin_ln_bwd_kernel<FM, GD, KC, true> : lin_ln_bwd_kernel<FM, GD, KC, false>;
-  static bool configured[2] = {false, false};
-  if (!configured[p.dy_bf16 ? 1 : 0]) {
+  static SradOncePerDevice configured[2];
+  if (configured[p.dy_bf16 ? 1 : 0].need()) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured[p.dy_bf16 ? 1 : 0] = true;
+    configured[p.dy_bf16 ? 1 : 0].done();
   }
   float* part = nullptr;
   SRAD_TRY(srad_wgrad_queue_ln_partials(q, p.dgamma, p.dbeta, p.d, p.M / FM, stream, &part));
@@ -619,10 +619,10 @@ int launch_bwd_fm(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream) {
   constexpr size_t lds = (size_t)(FM * FB_LDA + FM * FB_LDH) * 2 + (384 + FM * 16) * sizeof(float) +
                          (KCA > 0 ? (size_t)FM * (KCA * 32 + 8) * 2 : 0);
   auto kern = mlp_bwd_kernel<FM, GD, KCD, GM, KCM, KCA, HOUT>;
-  static bool configured = false;
-  if (!configured) {
+  static SradOncePerDevice configured;
+  if (configured.need()) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
+    configured.done();
   }
   float* part = nullptr;
   SRAD_TRY(srad_wgrad_queue_ln_partials(q, p.dgamma, p.dbeta, p.d, p.M / FM, stream, &part));

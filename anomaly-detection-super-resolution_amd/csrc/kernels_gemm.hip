@@ -591,10 +591,10 @@ int launch_one(const GemmParams& p, hipStream_t s) {
                              (PREC == SRAD_PREC_BF16X3 ? 2 : 1) +
                          (LN ? 2 * (size_t)CPA * 32 * sizeof(float) : 0);
   auto kern = gemm_kernel<PREC, BM, BN, WMV, WNV, CPS, LN, CONV, SPECIAL>;
-  static bool configured = false;
-  if (!configured) {
+  static SradOncePerDevice configured;
+  if (configured.need()) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
+    configured.done();
   }
   // pool_part rows are summed per image by callers that size them with srad_gemm_tile_rows(): a tile choice that drifts from that
   // mirror, or an image that is not a whole number of tiles, must fail here instead of averaging the wrong rows

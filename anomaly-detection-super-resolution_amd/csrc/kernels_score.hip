@@ -637,10 +637,10 @@ int srad_score_pairs(const uint8_t* sr, const uint8_t* hr, int n_img, int H, int
           for (int k = 1; k < g; ++k) { pmin = std::min(pmin, wl.ws[k] / 2); pmax = std::max(pmax, wl.ws[k] / 2); }
           const int rb = 1024 / W, t_first = -pmax, nt = H - 1 - pmin - t_first + 1, nt_blocks = (nt + rb - 1) / rb;
           const size_t lds = ((size_t)2 * kQ * rb * (W + 1) + 32) * sizeof(double);
-          static bool configured = false;
-          if (!configured) {
+          static SradOncePerDevice configured;
+          if (configured.need()) {
             SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ssim_rows_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            configured = true;
+            configured.done();
           }
           int lw = 0;
           while ((1 << lw) < W) ++lw;

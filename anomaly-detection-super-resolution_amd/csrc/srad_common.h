@@ -75,6 +75,15 @@ __device__ __forceinline__ float srad_wave_sum(float v) {
   return v;
 }
 #endif
+// "dynamic LDS limit of this kernel instance is set" - per DEVICE: hipFuncSetAttribute applies to the current device only, so a
+// process that drives two devices (not how this build runs - one rank per process - but legal) configures each once.
+struct SradOncePerDevice {
+  unsigned long long mask = 0, cur = 0;
+  bool need() { int d = 0; (void)hipGetDevice(&d); cur = 1ull << (d & 63); return (mask & cur) == 0; }
+  void done() { mask |= cur; }
+};
+static inline int srad_device_slot() { int d = 0; (void)hipGetDevice(&d); return d & 15; }
+
 #define SRAD_CHECK_HIP(expr)                                                              \
   do {                                                                                    \
     hipError_t _e = (expr);                                                               \
