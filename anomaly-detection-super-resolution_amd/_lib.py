@@ -85,7 +85,9 @@ _SIG = {
     "srad_drn_sync_params": (C.c_int, [_P, _P, _P]),
     "srad_drn_train_workspace_bytes": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "srad_drn_forward_train": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P), C.c_int, _P, C.c_size_t, _P]),
-    "srad_drn_backward": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
+    "srad_drn_num_buckets": (C.c_int, [_P]),
+    "srad_drn_bucket_range": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "srad_drn_backward": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P, _P, _P]),
     "srad_dual_backward_workspace_bytes": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "srad_dual_backward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P,
                                      C.c_size_t, C.c_int, _P]),

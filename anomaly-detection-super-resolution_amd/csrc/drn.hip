@@ -886,15 +886,17 @@ struct DrnTrainWs {
 DrnTrainWs plan_train_ws(const srad_drn* h, int B, int H, int W, void* base, size_t cap) {
   const srad_drn_config& c = h->cfg;
   const int P = h->phase, F = c.n_feats, s = c.scale, top = F << P;
+  const int F0 = srad_round_up(F, 4);                    // level 0 as stored (x8 preset: 10 -> 12), pad columns exact zeros
+  auto fw = [&](int L) { return L == 0 ? F0 : F << L; };
   const size_t T0 = (size_t)B * H * s * W * s;
   Bump bp(base, cap);
   DrnTrainWs w;
   w.uraw = bp.take(T0 * SRAD_IMG_CPAD);
   w.up0 = bp.take(T0 * SRAD_IMG_CPAD);
-  for (int L = 0; L < P; ++L) w.cat.push_back(bp.take((T0 >> (2 * L)) * 2 * (F << L)));
+  for (int L = 0; L < P; ++L) w.cat.push_back(bp.take((T0 >> (2 * L)) * 2 * fw(L)));
   const size_t TP = T0 >> (2 * P);
   w.deep = bp.take(TP * top);
-  for (int L = 0; L < P; ++L) w.dtmp.push_back(bp.take((T0 >> (2 * (L + 1))) * (F << L)));
+  for (int L = 0; L < P; ++L) w.dtmp.push_back(bp.take((T0 >> (2 * (L + 1))) * fw(L)));
   size_t rmax = 0, umax = 0;
   w.rc.resize(P);
   for (int idx = 0; idx < P; ++idx) {
@@ -913,13 +915,13 @@ DrnTrainWs plan_train_ws(const srad_drn* h, int B, int H, int W, void* base, siz
   }
   for (int j = 0; j <= P; ++j) w.timg.push_back(bp.take((T0 >> (2 * (P - j))) * SRAD_IMG_CPAD));
   // backward
-  for (int L = 0; L < P; ++L) w.gcat.push_back(bp.take((T0 >> (2 * L)) * 2 * (F << L)));
+  for (int L = 0; L < P; ++L) w.gcat.push_back(bp.take((T0 >> (2 * L)) * 2 * fw(L)));
   w.gdeep = bp.take(TP * top);
   w.ga = bp.take(rmax); w.gb = bp.take(rmax);
   for (int i = 0; i < 2; ++i) { w.dr2[i] = bp.take(rmax); w.dt2[i] = bp.take(rmax); }
   w.dups = bp.take(umax); w.dus = bp.take(umax);
-  w.ddtmp = bp.take((T0 >> 2) * F);
-  w.zup = bp.take(T0 * F);
+  w.ddtmp = bp.take((T0 >> 2) * F0);
+  w.zup = bp.take(T0 * F0);
   w.dtimg = bp.take(T0 * SRAD_IMG_CPAD);
   w.dup0 = bp.take(T0 * SRAD_IMG_CPAD);
   w.ppart = bp.take((size_t)B * DRN_POOL_MAXCHUNKS * top);
@@ -930,7 +932,6 @@ DrnTrainWs plan_train_ws(const srad_drn* h, int B, int H, int W, void* base, siz
 
 int drn_train_check(const srad_drn* h, int B, int H, int W) {
   SRAD_REQUIRE(h->ts.ready, "drn training: call srad_drn_train_bind() and srad_drn_sync_params() first");
-  SRAD_REQUIRE(h->cfg.n_feats % 4 == 0, "drn training: n_feats must be a multiple of 4 (got %d)", h->cfg.n_feats);
   const int top = h->cfg.n_feats << h->phase;
   SRAD_REQUIRE(top * (top / 16) <= 4096 && top <= 512, "drn training: channel attention too wide for the backward kernel");
   return drn_check_shape(h, B, H, W);
@@ -954,7 +955,8 @@ WgradParams drn_wgrad(const srad_drn* h, const ConvW& c, float* G, const float* 
   p.Hi = Hi; p.Wi = Wi; p.Ho = (Hi + 2 * pad - k) / stride + 1; p.Wo = (Wi + 2 * pad - k) / stride + 1; p.stride = stride;
   p.dY = dY; p.ldy = ldy; p.ycol0 = ycol0; p.X = X; p.ldx = ldx; p.M = B * p.Ho * p.Wo;
   p.N = srad_round_up(c.n, 4); p.Cin = srad_round_up(c.cin, 4); p.ntaps = c.ntaps;
-  p.n_real = c.n; p.cin_real = c.cin; p.alpha = 1.f;
+  const ParamEntry& e = h->pt.entries[c.w];             // the flat gradient holds the real tensor; c carries the stored extents
+  p.n_real = e.n; p.cin_real = e.cin; p.grp_real = e.grp_real; p.grp_pad = e.grp_pad; p.alpha = 1.f;
   p.dW = G + h->ts.flat_off[c.w];
   p.db = c.b >= 0 ? G + h->ts.flat_off[c.b] : nullptr;
   return p;
@@ -996,6 +998,26 @@ int srad_drn_train_workspace_bytes(const srad_drn_t* h, int B, int H, int W, siz
   return SRAD_OK;
 }
 
+// Gradient buckets of the flat buffer in the order srad_drn_backward completes them: 0 = the tail convolutions, 1 .. P = the
+// up phases finest first (RCAB chain + upsampler of one level each), P + 1 = everything before them in the table (MeanShift
+// layers, head, down blocks).  A data-parallel trainer starts a bucket's all-reduce from srad_drn_backward's hook.
+int srad_drn_num_buckets(const srad_drn_t* h) { return h ? h->phase + 2 : 0; }
+
+int srad_drn_bucket_range(srad_drn_t* h, int bucket, int64_t* off_floats, int64_t* n_floats) {
+  SRAD_REQUIRE(h && off_floats && n_floats, "drn_bucket_range: null argument");
+  int64_t tot = 0;
+  SRAD_TRY(train_param_floats(h->pt, h->ts, &tot));
+  const int P = h->phase;
+  SRAD_REQUIRE(bucket >= 0 && bucket < P + 2, "drn_bucket_range: bucket %d out of range", bucket);
+  auto start_of_phase = [&](int idx) { return idx < P ? h->ts.flat_off[h->rcab[idx][0].c0.w] : h->ts.flat_off[h->tail[0].w]; };
+  int64_t a, b;
+  if (bucket == 0) { a = start_of_phase(P); b = tot; }
+  else if (bucket <= P) { const int idx = P - bucket; a = start_of_phase(idx); b = start_of_phase(idx + 1); }
+  else { a = 0; b = start_of_phase(0); }
+  *off_floats = a; *n_floats = b - a;
+  return SRAD_OK;
+}
+
 // Training-mode DRN.forward (src/drn.py:241-270): as srad_drn_forward, every tensor the backward needs stays in `workspace`.
 int srad_drn_forward_train(srad_drn_t* h, const float* x, int B, int H, int W, float* const* ys, int n_out, void* workspace,
                            size_t workspace_bytes, void* stream) {
@@ -1009,6 +1031,8 @@ int srad_drn_forward_train(srad_drn_t* h, const float* x, int B, int H, int W, f
   const srad_drn_config& c = h->cfg;
   const int prec = c.precision, P = h->phase, F = c.n_feats, sc = c.scale, C = c.n_colors;
   const int H0 = H * sc, W0 = W * sc, top = F << P;
+  const int F0 = srad_round_up(F, 4);
+  auto fw = [&](int L) { return L == 0 ? F0 : F << L; };  // stored feature width of level L
   {
     const size_t tot = (size_t)B * H0 * W0;
     hipLaunchKernelGGL(bicubic_submean_kernel, dim3(grid1d(tot)), dim3(256), 0, s, x, w.up0, B, C, H, W, sc,
@@ -1016,12 +1040,12 @@ int srad_drn_forward_train(srad_drn_t* h, const float* x, int B, int H, int W, f
     SRAD_CHECK_HIP(hipGetLastError());
   }
   {
-    GemmParams p = conv_params(h, h->head, w.up0, SRAD_IMG_CPAD, B, H0, W0, 1, w.cat[0], 2 * F, F);
+    GemmParams p = conv_params(h, h->head, w.up0, SRAD_IMG_CPAD, B, H0, W0, 1, w.cat[0], 2 * F0, F0);
     p.Cin = SRAD_IMG_CPAD;
     SRAD_TRY(srad_launch_gemm(prec, p, s));
   }
   for (int L = 0; L < P; ++L) {
-    const int f = F << L, Hl = H0 >> L, Wl = W0 >> L;
+    const int f = fw(L), Hl = H0 >> L, Wl = W0 >> L;
     GemmParams p = conv_params(h, h->down_s2[L], w.cat[L] + f, 2 * f, B, Hl, Wl, 2, w.dtmp[L], f, 0);
     p.act = SRAD_ACT_LRELU; p.slope = c.negval;
     SRAD_TRY(srad_launch_gemm(prec, p, s));
@@ -1071,7 +1095,7 @@ int srad_drn_forward_train(srad_drn_t* h, const float* x, int B, int H, int W, f
       SRAD_CHECK_HIP(hipGetLastError());
       xin = sv.xo; ldin = ch;
     }
-    const int cout = F << (lvl - 1);
+    const int cout = fw(lvl - 1);
     {
       GemmParams p = conv_params(h, h->up_conv[idx], xin, ldin, B, Hl, Wl, 1, w.ups[idx], ch, 0);
       p.ps = 2;
@@ -1089,9 +1113,10 @@ int srad_drn_forward_train(srad_drn_t* h, const float* x, int B, int H, int W, f
 }
 
 // Backward of srad_drn_forward_train: dys[j] = dLoss/d(output j) (NCHW, null = this output does not enter the loss);
-// parameter gradients are ACCUMULATED into flat_grad (offsets as the flat parameter buffer).
+// parameter gradients are ACCUMULATED into flat_grad (offsets as the flat parameter buffer).  `on_bucket(user, bucket)`
+// (optional) is called on the host right after the last kernel that writes `bucket` (srad_drn_bucket_range) is enqueued.
 int srad_drn_backward(srad_drn_t* h, const float* const* dys, int n_out, int B, int H, int W, float* flat_grad,
-                      void* workspace, size_t workspace_bytes, void* stream) {
+                      void* workspace, size_t workspace_bytes, void* stream, srad_bucket_fn on_bucket, void* user) {
   SRAD_REQUIRE(h && dys && flat_grad && workspace, "drn_backward: null argument");
   SRAD_REQUIRE(n_out == h->phase + 1, "drn_backward: %d gradients given, the model returns %d outputs", n_out, h->phase + 1);
   SRAD_TRY(drn_train_check(h, B, H, W));
@@ -1101,6 +1126,8 @@ int srad_drn_backward(srad_drn_t* h, const float* const* dys, int n_out, int B, 
   const srad_drn_config& c = h->cfg;
   const int prec = c.precision, P = h->phase, F = c.n_feats, sc = c.scale, C = c.n_colors;
   const int H0 = H * sc, W0 = W * sc, top = F << P;
+  const int F0 = srad_round_up(F, 4);
+  auto fw = [&](int L) { return L == 0 ? F0 : F << L; };  // stored feature width of level L
   const size_t T0 = (size_t)B * H0 * W0;
   float* G = flat_grad;
   WgradQueue wq = train_wgrad_queue(h->ts);
@@ -1134,7 +1161,7 @@ int srad_drn_backward(srad_drn_t* h, const float* const* dys, int n_out, int B, 
   hipEvent_t side_done[2] = {nullptr, nullptr};
   int blk_count = 0;
 
-  for (int L = 0; L < P; ++L) SRAD_CHECK_HIP(hipMemsetAsync(w.gcat[L], 0, (T0 >> (2 * L)) * 2 * (F << L) * sizeof(float), s));
+  for (int L = 0; L < P; ++L) SRAD_CHECK_HIP(hipMemsetAsync(w.gcat[L], 0, (T0 >> (2 * L)) * 2 * fw(L) * sizeof(float), s));
   SRAD_CHECK_HIP(hipMemsetAsync(w.gdeep, 0, (T0 >> (2 * P)) * top * sizeof(float), s));
 
   // ---- tails + add_mean (drn.py:256-258, 265-267): every output's gradient lands in the buffer its tail conv read ----
@@ -1144,7 +1171,7 @@ int srad_drn_backward(srad_drn_t* h, const float* const* dys, int n_out, int B, 
     const int Hh = H0 >> lvl_in, Ww = W0 >> lvl_in;
     const float* X = j == 0 ? w.deep : w.cat[lvl_in];
     float* GX = j == 0 ? w.gdeep : w.gcat[lvl_in];
-    const int ld = j == 0 ? top : 2 * (F << lvl_in);
+    const int ld = j == 0 ? top : 2 * fw(lvl_in);
     const size_t tot = (size_t)B * Hh * Ww;
     hipLaunchKernelGGL(affine_bwd_kernel, dim3(grid1d(tot) > 256 ? 256 : grid1d(tot)), dim3(256), 0, s, dys[j], (const float*)nullptr,
                        w.timg[j], SRAD_IMG_CPAD, w.dtimg, B, C, Hh * Ww, h->pt.fptr(h->add_w), G + h->ts.flat_off[h->add_w],
@@ -1157,13 +1184,14 @@ int srad_drn_backward(srad_drn_t* h, const float* const* dys, int n_out, int B, 
     SRAD_TRY(srad_launch_gemm(prec, p, s));
     SRAD_TRY(srad_wgrad_flush(wq, s));                       // dtimg is reused by the next output
   }
+  if (on_bucket) on_bucket(user, 0);                         // (add_mean's own gradients travel with the last bucket)
 
   // ---- up phases, finest first (drn.py:260-268) ----
   for (int idx = P - 1; idx >= 0; --idx) {
     const int lvl = P - idx, Hl = H0 >> lvl, Wl = W0 >> lvl;
     const int ch = h->rcab[idx][0].ch;
     const size_t T = (size_t)B * Hl * Wl;
-    const int cout = F << (lvl - 1);
+    const int cout = fw(lvl - 1);
     const float* drive = w.gcat[lvl - 1];                    // columns [0, cout): gradient of the 1x1 conv's output
     {
       WgradParams g = drn_wgrad(h, h->up_1x1[idx], G, drive, 2 * cout, 0, w.ups[idx], ch, B, 2 * Hl, 2 * Wl, 1);
@@ -1232,11 +1260,12 @@ int srad_drn_backward(srad_drn_t* h, const float* const* dys, int n_out, int B, 
     float* GX = idx == 0 ? w.gdeep : w.gcat[lvl];
     hipLaunchKernelGGL(add_cols_kernel, dim3(grid1d(T * ch / 4)), dim3(256), 0, s, ga, ch, GX, ch, T, ch);
     SRAD_CHECK_HIP(hipGetLastError());
+    if (on_bucket) on_bucket(user, P - idx);
   }
 
   // ---- down path (drn.py:250-253, DownBlock 83-119) ----
   for (int L = P - 1; L >= 0; --L) {
-    const int f = F << L, f1 = F << (L + 1), Hl = H0 >> L, Wl = W0 >> L;
+    const int f = fw(L), f1 = F << (L + 1), Hl = H0 >> L, Wl = W0 >> L;
     const float* gout = L + 1 < P ? w.gcat[L + 1] + f1 : w.gdeep;
     const int ldg = L + 1 < P ? 2 * f1 : f1;
     {
@@ -1260,9 +1289,9 @@ int srad_drn_backward(srad_drn_t* h, const float* const* dys, int n_out, int B, 
   }
   // ---- head + sub_mean (drn.py:243-247) ----
   {
-    WgradParams g = drn_wgrad(h, h->head, G, w.gcat[0] + F, 2 * F, 0, w.up0, SRAD_IMG_CPAD, B, H0, W0, 1);
+    WgradParams g = drn_wgrad(h, h->head, G, w.gcat[0] + F0, 2 * F0, 0, w.up0, SRAD_IMG_CPAD, B, H0, W0, 1);
     SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
-    GemmParams p = drn_dgrad(h, h->head, w.gcat[0] + F, 2 * F, B, H0, W0, w.dup0, SRAD_IMG_CPAD, 0);
+    GemmParams p = drn_dgrad(h, h->head, w.gcat[0] + F0, 2 * F0, B, H0, W0, w.dup0, SRAD_IMG_CPAD, 0);
     SRAD_TRY(srad_launch_gemm(prec, p, s));
     const size_t tot = (size_t)B * H0 * W0;
     hipLaunchKernelGGL(affine_bwd_kernel, dim3(grid1d(tot) > 256 ? 256 : grid1d(tot)), dim3(256), 0, s, (const float*)nullptr, w.dup0,
@@ -1270,18 +1299,21 @@ int srad_drn_backward(srad_drn_t* h, const float* const* dys, int n_out, int B, 
                        G + h->ts.flat_off[h->sub_b]);
     SRAD_CHECK_HIP(hipGetLastError());
   }
-  return srad_wgrad_flush(wq, s);
+  SRAD_TRY(srad_wgrad_flush(wq, s));
+  if (on_bucket) on_bucket(user, P + 1);
+  return SRAD_OK;
 }
 
 // Backward of the dual regression model (srad_dual_forward): dy [B,C,H/2,W/2] -> dw0 / dw1 accumulated (PyTorch layouts),
-// dx [B,C,H,W] optional.  The hidden activation is recomputed.  n_feats % 4 == 0.
+// dx [B,C,H,W] optional.  The hidden activation is recomputed.  The hidden width is stored rounded up to a multiple of 4
+// (x8 preset: 10 -> 12) with exact-zero pad columns, as in srad_dual_forward.
 int srad_dual_backward_workspace_bytes(int B, int C, int H, int W, int n_feats, size_t* bytes) {
   SRAD_REQUIRE(bytes && B > 0 && C > 0 && H > 0 && W > 0 && n_feats > 0, "dual_backward_workspace_bytes: bad argument");
   const size_t T = (size_t)B * H * W, T2 = (size_t)B * (H / 2) * (W / 2);
   const int fm = srad_round_up(n_feats, 4);
   const size_t pk = srad_align_up(srad_packed_bytes(SRAD_PREC_F32, fm, fm, 9), 256);   // covers [F][4], [4][F] and their transposes
-  *bytes = 2 * srad_align_up(T * SRAD_IMG_CPAD * 4, 256) + 2 * srad_align_up(T2 * n_feats * 4, 256) + srad_align_up(T2 * SRAD_IMG_CPAD * 4, 256) +
-           srad_align_up(T * n_feats * 4, 256) + 4 * pk + srad_align_up(SRAD_WGRAD_WS_BYTES, 256);
+  *bytes = 2 * srad_align_up(T * SRAD_IMG_CPAD * 4, 256) + 2 * srad_align_up(T2 * fm * 4, 256) + srad_align_up(T2 * SRAD_IMG_CPAD * 4, 256) +
+           srad_align_up(T * fm * 4, 256) + 4 * pk + srad_align_up(SRAD_WGRAD_WS_BYTES, 256);
   return SRAD_OK;
 }
 
@@ -1289,13 +1321,13 @@ int srad_dual_backward(const float* w0, const float* w1, int C, int n_feats, flo
                        int W, const float* dy, float* dx, float* dw0, float* dw1, void* workspace, size_t workspace_bytes,
                        int precision, void* stream) {
   SRAD_REQUIRE(w0 && w1 && x && dy && dw0 && dw1 && workspace, "dual_backward: null argument");
-  SRAD_REQUIRE((C == 1 || C == 3) && n_feats % 4 == 0 && H % 2 == 0 && W % 2 == 0, "dual_backward: needs 1 or 3 channels, n_feats %% 4 == 0, even H and W");
+  SRAD_REQUIRE((C == 1 || C == 3) && n_feats > 0 && H % 2 == 0 && W % 2 == 0, "dual_backward: needs 1 or 3 channels, even H and W");
   size_t need = 0;
   SRAD_TRY(srad_dual_backward_workspace_bytes(B, C, H, W, n_feats, &need));
   SRAD_REQUIRE(workspace_bytes >= need && ((uintptr_t)workspace & 255) == 0, "dual_backward: workspace %zu bytes, %zu needed (256-byte aligned)", workspace_bytes, need);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   Bump bp(workspace, workspace_bytes);
-  const int H2 = H / 2, W2 = W / 2, Fh = n_feats;
+  const int H2 = H / 2, W2 = W / 2, Fh = srad_round_up(n_feats, 4);   // hidden width as stored
   const size_t T = (size_t)B * H * W, T2 = (size_t)B * H2 * W2;
   float* xin = bp.take(T * SRAD_IMG_CPAD);
   float* dxin = bp.take(T * SRAD_IMG_CPAD);
@@ -1313,9 +1345,9 @@ int srad_dual_backward(const float* w0, const float* w1, int C, int n_feats, flo
   const float zero3[3] = {0.f, 0.f, 0.f};
   SRAD_TRY(srad_launch_nchw_to_nhwc(x, xin, B, C, SRAD_IMG_CPAD, H, W, zero3, 1.0f, s));
   SRAD_TRY(srad_launch_nchw_to_nhwc(dy, dyn, B, C, SRAD_IMG_CPAD, H2, W2, zero3, 1.0f, s));
-  SRAD_TRY(srad_launch_pack_weight(precision, w0, p0, Fh, C, 9, s));
-  SRAD_TRY(srad_launch_pack_weight_transposed(precision, w1, p1t, C, Fh, 9, SRAD_IMG_CPAD, Fh, s));
-  SRAD_TRY(srad_launch_pack_weight_transposed(precision, w0, p0t, Fh, C, 9, Fh, SRAD_IMG_CPAD, s));
+  SRAD_TRY(srad_launch_pack_weight_padded(precision, w0, p0, n_feats, C, 9, Fh, 0, 0, s));
+  SRAD_TRY(srad_launch_pack_weight_transposed(precision, w1, p1t, C, n_feats, 9, SRAD_IMG_CPAD, Fh, s));
+  SRAD_TRY(srad_launch_pack_weight_transposed(precision, w0, p0t, n_feats, C, 9, Fh, SRAD_IMG_CPAD, s));
   {  // recompute mid = lrelu(conv_s2(x))
     GemmParams a{};
     a.X = xin; a.ldx = SRAD_IMG_CPAD; a.Cin = SRAD_IMG_CPAD; a.Cp = srad_cp(SRAD_IMG_CPAD); a.ntaps = 9;
@@ -1326,7 +1358,7 @@ int srad_dual_backward(const float* w0, const float* w1, int C, int n_feats, flo
   {  // second conv: dw1, dmid = (dy . w1) * lrelu'(mid)
     WgradParams g{};
     g.dY = dyn; g.ldy = SRAD_IMG_CPAD; g.X = mid; g.ldx = Fh; g.M = (int)T2; g.N = SRAD_IMG_CPAD; g.Cin = Fh; g.ntaps = 9;
-    g.n_real = C; g.cin_real = Fh; g.Hi = g.Ho = H2; g.Wi = g.Wo = W2; g.stride = 1; g.alpha = 1.f; g.dW = dw1;
+    g.n_real = C; g.cin_real = n_feats; g.Hi = g.Ho = H2; g.Wi = g.Wo = W2; g.stride = 1; g.alpha = 1.f; g.dW = dw1;
     SRAD_TRY(srad_launch_wgrad(precision, g, wq, s));
     GemmParams p{};
     p.Hi = p.Ho = H2; p.Wi = p.Wo = W2; p.stride = 1; p.X = dyn; p.ldx = SRAD_IMG_CPAD; p.M = (int)T2; p.Cin = SRAD_IMG_CPAD;
@@ -1337,7 +1369,7 @@ int srad_dual_backward(const float* w0, const float* w1, int C, int n_feats, flo
   {  // first conv (stride 2): dw0, dx
     WgradParams g{};
     g.dY = dmid; g.ldy = Fh; g.X = xin; g.ldx = SRAD_IMG_CPAD; g.M = (int)T2; g.N = Fh; g.Cin = SRAD_IMG_CPAD; g.ntaps = 9;
-    g.n_real = Fh; g.cin_real = C; g.Hi = H; g.Wi = W; g.Ho = H2; g.Wo = W2; g.stride = 2; g.alpha = 1.f; g.dW = dw0;
+    g.n_real = n_feats; g.cin_real = C; g.Hi = H; g.Wi = W; g.Ho = H2; g.Wo = W2; g.stride = 2; g.alpha = 1.f; g.dW = dw0;
     SRAD_TRY(srad_launch_wgrad(precision, g, wq, s));
     if (dx) {
       const size_t tot = T * Fh / 4;

@@ -317,7 +317,7 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int kspli
     const int n = n0 + nl;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int c = c0 + cl + e;
+      const int c = srad_real_channel(c0 + cl + e, p.grp_real, p.grp_pad, p.cin_real);
       if (n < p.n_real && c < p.cin_real) {
         float* dst = p.dW + ((size_t)n * p.cin_real + c) * p.ntaps + tap;
         *dst += v[j][e] * p.alpha;
@@ -848,7 +848,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceBatc
   const int n = n0 + (e4 >> 4), cl = (e4 & 15) * 4;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const int c = c0 + cl + e;
+    const int c = srad_real_channel(c0 + cl + e, d.grp_real, d.grp_pad, d.cin_real);
     if (n < d.n_real && c < d.cin_real) {
       float* dst = d.dW + ((size_t)n * d.cin_real + c) * d.ntaps + tap;
       *dst += v[e] * d.alpha;
@@ -904,6 +904,7 @@ int plan_wgrad(const WgradParams& p, WgradQueue& q, hipStream_t s, WgradPlan& pl
     q.used += need;
     WgradReduceItem& it = q.batch.it[q.batch.count++];
     it.dW = p.dW; it.db = p.db; it.part = pl.part; it.n_real = p.n_real; it.cin_real = p.cin_real; it.ntaps = p.ntaps;
+    it.grp_real = p.grp_real; it.grp_pad = p.grp_pad;
     it.tn = pl.tn; it.tc = pl.tc; it.ksplit = (int)ksplit; it.tile0 = q.tiles; it.alpha = p.alpha; it.wc = 0;
     q.tiles += (int)pl.tiles;
   }
@@ -945,7 +946,7 @@ int launch_wgrad80(const WgradParams& p, WgradQueue& q, hipStream_t s) {
     part = q.ws + q.used;
     q.used += need;
     WgradReduceItem& it = q.batch.it[q.batch.count++];
-    it.dW = p.dW; it.db = p.db; it.part = part; it.n_real = 80; it.cin_real = 80; it.ntaps = p.ntaps;
+    it.dW = p.dW; it.db = p.db; it.part = part; it.n_real = 80; it.cin_real = 80; it.ntaps = p.ntaps; it.grp_real = it.grp_pad = 0;
     it.ksplit = (int)ksplit; it.tile0 = q.tiles; it.alpha = p.alpha;
     q.tiles += square_reduce_tiles(it, 80);
   }
@@ -997,7 +998,7 @@ int launch_wgrad_conv9(const WgradParams& p, WgradQueue& q, hipStream_t s) {
   float* const part = q.ws + q.used;
   q.used += need;
   WgradReduceItem& it = q.batch.it[q.batch.count++];
-  it.dW = p.dW; it.db = p.db; it.part = part; it.n_real = C; it.cin_real = C; it.ntaps = 9;
+  it.dW = p.dW; it.db = p.db; it.part = part; it.n_real = C; it.cin_real = C; it.ntaps = 9; it.grp_real = it.grp_pad = 0;
   it.ksplit = ksplit; it.tile0 = q.tiles; it.alpha = p.alpha;
   q.tiles += square_reduce_tiles(it, C);
   SradProfScope prof(s, SRAD_K_WGRAD, 2.0 * p.M * C * C * 9.0, 4.0 * p.M * 2.0 * C + 8.0 * 9.0 * PART * ksplit);
@@ -2233,6 +2234,8 @@ static int check_wgrad(const WgradParams& p) {
                    ((uintptr_t)p.dY & 15) == 0 && ((uintptr_t)p.X & 15) == 0,
                "wgrad: operands need channel counts / strides that are multiples of 4 floats (N=%d Cin=%d ldy=%d ldx=%d)", p.N, p.Cin, p.ldy, p.ldx);
   SRAD_REQUIRE(p.n_real > 0 && p.n_real <= p.N && p.cin_real > 0 && p.cin_real <= p.Cin, "wgrad: bad real extents");
+  SRAD_REQUIRE(p.grp_pad == 0 || (p.grp_real > 0 && p.grp_real <= p.grp_pad && p.cin_real % p.grp_real == 0 &&
+                                  (p.cin_real / p.grp_real) * p.grp_pad <= p.Cin), "wgrad: bad channel groups %d -> %d", p.grp_real, p.grp_pad);
   SRAD_REQUIRE(p.ntaps == 1 || p.ntaps == 9, "wgrad: ntaps must be 1 or 9");
   if (p.ntaps == 9 || p.stride != 1)
     SRAD_REQUIRE(p.Ho > 0 && p.Wo > 0 && p.Hi > 0 && p.Wi > 0 && p.M % (p.Ho * p.Wo) == 0, "wgrad: bad conv geometry");
@@ -2250,7 +2253,7 @@ static int queue_colsum(WgradQueue& q, float* dst, const float* part, int ncols,
                         hipStream_t stream) {
   if (q.batch.count == SRAD_WGRAD_BATCH) SRAD_TRY(srad_wgrad_flush(q, stream));
   WgradReduceItem& it = q.batch.it[q.batch.count++];
-  it.dW = dst; it.db = nullptr; it.part = part; it.n_real = ncols; it.cin_real = row_stride; it.ntaps = 0;   // ntaps 0: column sums
+  it.dW = dst; it.db = nullptr; it.part = part; it.n_real = ncols; it.cin_real = row_stride; it.ntaps = 0; it.grp_real = it.grp_pad = 0;   // ntaps 0: column sums
   it.tn = it.tc = 1; it.ksplit = rows; it.tile0 = q.tiles; it.alpha = alpha; it.wc = 0;
   q.tiles += (ncols + 63) / 64;
   return SRAD_OK;

@@ -289,11 +289,20 @@ int srad_launch_qkv_attn(const QkvAttnParams& p, hipStream_t stream);
 // Weight gradient of a Linear / conv layer, accumulated (+=) into the PyTorch-layout fp32 tensor:
 //   dW[n][c][tap] += alpha * sum_m rs(m) * dY[m][ycol0 + n] * A(m, tap, c),   db[n] += alpha * sum_m rs(m) * dY[m][ycol0 + n]
 // with A the forward's row gather (identity for Linear, the 3x3 / strided window for convs).
+// stored input channel c of a layer whose input is `grp_pad`-wide groups with `grp_real` real channels each -> the real
+// channel index, or `none` for a pad column (grp_pad == 0: the identity)
+__host__ __device__ inline int srad_real_channel(int c, int grp_real, int grp_pad, int none) {
+  if (grp_pad <= 0) return c;
+  const int g = c / grp_pad, r = c - g * grp_pad;
+  return r < grp_real ? g * grp_real + r : none;
+}
+
 struct WgradParams {
   const float* dY; int ldy, ycol0;
   const float* X; int ldx;
   int M, N, Cin, ntaps;        // N, Cin: padded to multiples of 4 as stored in dY / X
   int n_real, cin_real;        // extents of dW (columns/rows beyond are padding and never written)
+  int grp_real, grp_pad;       // grp_pad > 0: X's channels are groups of grp_pad holding grp_real real ones each (DRN x8 level 0)
   int Hi, Wi, Ho, Wo, stride;  // conv geometry (M = B*Ho*Wo); ignored for ntaps == 1 && stride == 1
   const float* row_scale; int rps;
   float alpha;
@@ -309,6 +318,7 @@ struct WgradParams {
 struct WgradReduceItem {
   float* dW; float* db; const float* part;
   int n_real, cin_real, ntaps, tn, tc, ksplit, tile0;
+  int grp_real, grp_pad;         // as WgradParams
   float alpha;
   int wc;                        // C > 0: one C x C partial tile per tap (wgrad80_kernel, wgrad_conv9_kernel), row-major + C bias sums;
                                  // then tn = reduce tiles per tap, tc = float4 per reduce workgroup

@@ -26,6 +26,8 @@ struct SyncDesc {
   long long tfdst_off;  // bytes into the training arena of the fragment-major bf16 pack of the transposed weight (-1: none)
   int packed, n, cin, ntaps, Np, Cp, tRp, tKp;
   int qkv_heads;        // > 0: the fragment pack at fdst_off is the per-head [q | k | v] layout
+  int n_st, cin_st;     // stored extents: output rows zero-padded to n_st, input channels regrouped to cin_st (DRN x8 level 0)
+  int grp_real, grp_pad;
   long long numel;
   unsigned blk0, nblk;
   int tiled, tile_nb;   // bf16 Linear layers: 64 x 64 source tiles through LDS (tile_nb = tiles along n), see sync_linear_tile
@@ -125,8 +127,9 @@ __global__ __launch_bounds__(256) void sync_params_kernel(const SyncDesc* __rest
     const int c = (int)(i % d.Cp);
     const int tap = (int)((i / d.Cp) % d.ntaps);
     const int n = (int)(i / ((long long)d.Cp * d.ntaps));
+    const int cr = srad_real_channel(c, d.grp_real, d.grp_pad, d.cin);
     float v = 0.f;
-    if (n < d.n && c < d.cin) v = src[((long long)n * d.cin + c) * d.ntaps + tap];
+    if (n < d.n && cr < d.cin) v = src[((long long)n * d.cin + cr) * d.ntaps + tap];
     dst[i] = (T)v;
   }
   if (d.fdst_off >= 0 && d.qkv_heads > 0) {   // per-head [q | k | v] fragments (srad_launch_pack_qkv_frag)
@@ -173,12 +176,17 @@ __global__ __launch_bounds__(256) void sync_params_kernel(const SyncDesc* __rest
       const int n = (int)(i % d.tKp);
       const int tap = (int)((i / d.tKp) % d.ntaps);
       const int c = (int)(i / ((long long)d.tKp * d.ntaps));
+      const int cr = srad_real_channel(c, d.grp_real, d.grp_pad, d.cin);
       float v = 0.f;
-      if (n < d.n && c < d.cin) v = src[((long long)n * d.cin + c) * d.ntaps + (d.ntaps - 1 - tap)];
+      if (n < d.n && cr < d.cin) v = src[((long long)n * d.cin + cr) * d.ntaps + (d.ntaps - 1 - tap)];
       tdst[i] = (T)v;
     }
   }
 }
+
+// extents a packed layer is stored with (engine.h add_layer_padded): output rows padded to n_pad, input channels regrouped
+inline int stored_n(const ParamEntry& e) { return e.n_pad > 0 ? e.n_pad : e.n; }
+inline int stored_cin(const ParamEntry& e) { return e.grp_pad > 0 ? (e.cin / e.grp_real) * e.grp_pad : e.cin; }
 
 inline int train_param_floats(const ParamTable& pt, TrainState& ts, int64_t* total) {
   if (ts.flat_off.empty()) {
@@ -201,7 +209,7 @@ inline int train_arena_bytes(const ParamTable& pt, TrainState& ts, size_t* bytes
     size_t off = 0;
     for (const ParamEntry& e : pt.entries) {
       ts.t_off.push_back(off);
-      if (e.packed) off += srad_align_up(srad_packed_bytes(pt.prec, srad_round_up(e.cin, 4), srad_round_up(e.n, 4), e.ntaps), 256);
+      if (e.packed) off += srad_align_up(srad_packed_bytes(pt.prec, srad_round_up(stored_cin(e), 4), srad_round_up(stored_n(e), 4), e.ntaps), 256);
     }
     for (const ParamEntry& e : pt.entries) {      // Linear layers of the fused kernels: W^T as MFMA fragments too
       const bool frag = e.packed && (e.frag_off >= 0 || e.tfrag) && e.ntaps == 1;
@@ -235,10 +243,12 @@ inline int train_bind(const ParamTable& pt, TrainState& ts, void* train_arena, s
     d.packed = e.packed; d.numel = e.numel;
     long long work = e.numel;
     if (e.packed) {
-      SRAD_REQUIRE(e.grp_pad == 0 && (e.n_pad == 0 || e.n_pad == e.n),
-                   "train_bind: zero-padded layers (DRN x8, n_feats = 10) are not trainable");
-      d.n = e.n; d.cin = e.cin; d.ntaps = e.ntaps; d.Np = srad_np(e.n); d.Cp = srad_cp(e.cin);
-      d.tRp = srad_np(srad_round_up(e.cin, 4)); d.tKp = srad_cp(srad_round_up(e.n, 4));
+      // zero-padded layers (DRN x8, n_feats = 10): the packs hold the stored extents, the flat buffers the real tensor
+      d.n = e.n; d.cin = e.cin; d.ntaps = e.ntaps; d.n_st = stored_n(e); d.cin_st = stored_cin(e);
+      d.grp_real = e.grp_real; d.grp_pad = e.grp_pad;
+      SRAD_REQUIRE((d.n_st == d.n && d.cin_st == d.cin) || (e.frag_off < 0 && !e.tfrag), "train_bind: a padded layer cannot carry fragment packs");
+      d.Np = srad_np(d.n_st); d.Cp = srad_cp(d.cin_st);
+      d.tRp = srad_np(srad_round_up(d.cin_st, 4)); d.tKp = srad_cp(srad_round_up(d.n_st, 4));
       d.tdst_off = (long long)ts.t_off[i];
       d.tfdst_off = ts.tf_off[i];
       d.qkv_heads = e.qkv_heads;
@@ -254,7 +264,7 @@ inline int train_bind(const ParamTable& pt, TrainState& ts, void* train_arena, s
     if (d.nblk == 0) d.nblk = 1;
     // bf16 Linear layers go tile by tile (sync_linear_tile); the per-head q | k | v pack's padding rows are not rewritten
     // there - they are zero since the arena was packed at creation and nothing else touches them
-    if (e.packed && pt.prec == SRAD_PREC_BF16 && e.ntaps == 1 && e.cin % 4 == 0 && e.cin >= 4 && getenv("SRAD_SYNC_ELEMENTWISE") == nullptr) {
+    if (e.packed && pt.prec == SRAD_PREC_BF16 && e.ntaps == 1 && e.grp_pad == 0 && e.cin % 4 == 0 && e.cin >= 4 && getenv("SRAD_SYNC_ELEMENTWISE") == nullptr) {
       const int ext_n = d.Np > d.tKp ? d.Np : d.tKp, ext_c = d.Cp > d.tRp ? d.Cp : d.tRp;
       d.tiled = 1; d.tile_nb = (ext_n + 63) / 64;
       d.nblk = (unsigned)(d.tile_nb * ((ext_c + 63) / 64));

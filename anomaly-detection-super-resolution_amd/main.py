@@ -3,7 +3,7 @@
 -> post-training validation PSNR / SSIM on ``val/good`` -> ``checkpoint.save``.
 
 ``--model-type drct`` trains on the HIP engine (forward + L1 + backward + fused Adam); ``--model-type drn-l`` trains
-DRN-L with its dual regression models (x2 / x4; the x8 preset is inference-only); ``--test-only`` evaluates an
+DRN-L with its dual regression models (x2 / x4 / x8); ``--test-only`` evaluates an
 existing run.  Data parallel (BASELINE config C4): ``--gpus N`` starts N ranks (or launch under
 ``python -m torch.distributed.run``); ``--batch-size`` stays the GLOBAL minibatch, every rank takes ``rank::N`` of it
 and the gradients are all-reduced over RCCL while the backward runs.  DropPath draws are seeded ``seed + rank``."""

@@ -552,7 +552,17 @@ class DRN(_EngineModule):
 
     # -- training (C ABI srad_drn_forward_train / srad_drn_backward) -----------------------------
     def _can_train(self) -> bool:
-        return self.cfg.n_feats % 4 == 0        # the x8 preset (n_feats 10, zero-padded layers) is inference-only
+        return True                             # incl. the x8 preset (n_feats 10: level 0 stored zero-padded to 12 channels)
+
+    def enable_training(self) -> "DRN":
+        super().enable_training()
+        self.on_bucket = None               # data-parallel hook: callable(bucket index), see GradReducer
+        a, b = C.c_int64(), C.c_int64()
+        self.grad_buckets = []              # (offset, floats) of the flat gradient buffer, in the order the backward completes them
+        for i in range(L.lib().srad_drn_num_buckets(self._handle)):
+            L.check(L.lib().srad_drn_bucket_range(self._handle, i, C.byref(a), C.byref(b)), "drn_bucket_range")
+            self.grad_buckets.append((a.value, b.value))
+        return self
 
     def _forward_train(self, x: torch.Tensor) -> List[torch.Tensor]:
         dev = x.device
@@ -574,8 +584,19 @@ class DRN(_EngineModule):
         wp, wb = self._train_workspace(B, H, W, self.flat_grads.device)
         keep = [None if g is None else g.to(torch.float32).contiguous() for g in dys]
         ptrs = (C.c_void_p * len(keep))(*[0 if g is None else g.data_ptr() for g in keep])
+        failed = []
+
+        def hook(user, b):                  # ctypes swallows exceptions raised inside a callback: keep the first one
+            try:
+                if not failed:
+                    self.on_bucket(b)
+            except BaseException as e:      # noqa: BLE001 - re-raised below, after the C call has returned
+                failed.append(e)
+        cb = L.BUCKET_FN(hook) if self.on_bucket is not None else L.BUCKET_FN(0)
         L.check(L.lib().srad_drn_backward(self._handle, ptrs, len(keep), B, H, W, L.dptr(self.flat_grads), wp, wb,
-                                          L.current_stream_ptr()), "drn_backward")
+                                          L.current_stream_ptr(), cb, None), "drn_backward")
+        if failed:
+            raise RuntimeError(f"gradient bucket hook failed: {failed[0]!r} - gradients of this step are not reduced") from failed[0]
 
     def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
         if self.training and torch.is_grad_enabled() and self._can_train():
@@ -637,8 +658,8 @@ class DownBlock(nn.Module):
         w0 = self.get_parameter("dual_module.0.0.weight")
         w1 = self.get_parameter("dual_module.1.weight")
         if torch.is_grad_enabled() and (x.requires_grad or w0.requires_grad or w1.requires_grad):
-            if self.n_feats % 4 or x.shape[2] % 2 or x.shape[3] % 2:
-                raise NotImplementedError("DownBlock backward needs n_feats % 4 == 0 and even image sizes")
+            if x.shape[2] % 2 or x.shape[3] % 2:
+                raise NotImplementedError("DownBlock backward needs even image sizes")
             return _DualFn.apply(x, w0, w1, self)
         return self._run_forward(x.detach().to(torch.float32).contiguous(), w0.detach().contiguous(), w1.detach().contiguous())
 

@@ -298,10 +298,18 @@ def drn_train_step(model, dual_models, lr_list, hr, optimizer, dual_optimizers, 
     sr = model(lr_list[0])
     sr2lr = [dual_models[i](sr[i - len(dual_models)]) for i in range(len(dual_models))]
     loss = drn_loss(sr, lr_list, hr, sr2lr, dual_weight, loss_fn)
+    # data parallel: the SR net's buckets (one per level, ``model.grad_buckets``) are all-reduced from the engine's hook while
+    # the backward continues (``GradReducer.attach``); a model without buckets is reduced in one piece afterwards
+    bucketed = reducer is not None and reducer.world > 1 and bool(getattr(model, "grad_buckets", None))
+    if bucketed and reducer.model is not model:
+        reducer.attach(model)
     loss.backward()
     scale = 1.0
     if reducer is not None:
-        reducer.reduce_all(model.flat_grads, [(0, model.flat_grads.numel())])
+        if bucketed:
+            reducer.finish()
+        else:
+            reducer.reduce_all(model.flat_grads, [(0, model.flat_grads.numel())])
         scale = reducer.grad_scale
         for dm, o in zip(dual_models, dual_optimizers):
             for p in dm.parameters():
@@ -356,7 +364,7 @@ class GraphedDrnTrainStep:
         entry = self._graphs.get(key)
         if entry is None:
             n = self._eager_calls.get(key, 0)
-            if n < self.warmup:
+            if n < self.warmup or getattr(m, "on_bucket", None) is not None:   # bucket hooks launch collectives from the host: eager
                 self._eager_calls[key] = n + 1          # allocates workspaces, configures kernels, creates the side stream
                 return drn_train_step(m, self.duals, lr_list, hr, self.optimizer, self.dual_optimizers, self.dual_weight,
                                       None, self.loss_fn)

@@ -132,7 +132,7 @@ class Trainer():
         if not getattr(opt, "test_only", False):
             if not self.net._can_train():
                 raise NotImplementedError(f"{type(self.net).__name__}: this configuration is inference-only on the HIP engine "
-                                          "(DRN x8: n_feats = 10; DRCT: windows larger than 16 x 16, i.e. resolution / scale > 64)")
+                                          "(DRCT: windows larger than 16 x 16, i.e. resolution / scale > 64)")
             if self.world > 1 and (opt.batch_size % self.world or opt.batch_size < self.world):
                 # a rank with an empty slice would skip the step and leave its peers waiting in the bucket all-reduce
                 raise ValueError(f"--batch-size {opt.batch_size} is the GLOBAL minibatch: it must be a positive multiple of the "

@@ -158,11 +158,15 @@ int srad_drn_train_workspace_bytes(const srad_drn_t* h, int B, int H, int W, siz
 int srad_drn_forward_train(srad_drn_t* h, const float* x, int B, int H, int W, float* const* ys, int n_out,
                            void* workspace, size_t workspace_bytes, void* stream);
 /* dys[j] = dLoss/d(output j) (NCHW device pointers, NULL when output j is not in the loss); parameter gradients are
- * ACCUMULATED into dev_flat_grad (incl. the trainable MeanShift layers, hazard H4) */
+ * ACCUMULATED into dev_flat_grad (incl. the trainable MeanShift layers, hazard H4).  on_bucket (optional): as
+ * srad_drct_backward - called on the host when the last kernel writing gradient bucket b has been enqueued; buckets
+ * (srad_drn_bucket_range, completion order): 0 = tail convs, 1..phase = up phases finest first, phase + 1 = the rest. */
+int srad_drn_num_buckets(const srad_drn_t* h);
+int srad_drn_bucket_range(srad_drn_t* h, int bucket, int64_t* off_floats, int64_t* n_floats);
 int srad_drn_backward(srad_drn_t* h, const float* const* dys, int n_out, int B, int H, int W, float* dev_flat_grad,
-                      void* workspace, size_t workspace_bytes, void* stream);
+                      void* workspace, size_t workspace_bytes, void* stream, srad_bucket_fn on_bucket, void* user);
 /* Backward of the dual regression model (srad_dual_forward; src/trainer.py:168-185 back-propagates through it into the
- * SR outputs): dw0 [n_feats,C,3,3] / dw1 [C,n_feats,3,3] accumulated, dx [B,C,H,W] optional; n_feats % 4 == 0 */
+ * SR outputs): dw0 [n_feats,C,3,3] / dw1 [C,n_feats,3,3] accumulated, dx [B,C,H,W] optional; H and W even */
 int srad_dual_backward_workspace_bytes(int B, int C, int H, int W, int n_feats, size_t* bytes);
 int srad_dual_backward(const float* w0, const float* w1, int C, int n_feats, float negval, const float* x, int B, int H,
                        int W, const float* dy, float* dx, float* dw0, float* dw1, void* workspace, size_t workspace_bytes,

@@ -33,7 +33,8 @@ def _setup(scale, n_colors, n_blocks, n_feats, B, H, W, seed=31, prec="fp32"):
     return cfg, sd, duals, lrs, hr, m, dms
 
 
-@pytest.mark.parametrize("scale,n_colors,n_feats,B,H,W", [(4, 1, 20, 2, 8, 12), (2, 3, 8, 1, 16, 16), (4, 3, 20, 1, 8, 8)])
+@pytest.mark.parametrize("scale,n_colors,n_feats,B,H,W", [(4, 1, 20, 2, 8, 12), (2, 3, 8, 1, 16, 16), (4, 3, 20, 1, 8, 8),
+                                                             (8, 1, 10, 2, 4, 6), (8, 3, 10, 1, 4, 4), (2, 1, 10, 1, 8, 8)])
 def test_drn_gradients_match_oracle_autograd(scale, n_colors, n_feats, B, H, W):
     from oracle import sr_ref as R
     from srad_amd.train import drn_loss
@@ -111,13 +112,59 @@ def test_graphed_drn_step_equals_the_eager_steps(prec):
         assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
 
 
-def test_drn_x8_preset_training_is_refused():
-    from srad_amd import spec as S
-    from srad_amd.nets import DRN
-    cfg = S.DRNConfig.for_scale(8, 1)
-    m = DRN(Opt(cfg, "fp32")).cuda().train()
-    with pytest.raises(NotImplementedError, match="backward"):
-        m(torch.zeros(1, 1, 4, 4, device="cuda"))
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_drn_x8_preset_trains(prec):
+    """The x8 preset (src/main.py:297-300: n_feats 10, three phases) stores level 0 zero-padded to 12 channels; the flat
+    parameter / gradient buffers keep the reference's tensors.  Steps reduce the loss, the pad columns stay out of the
+    state dict, and the inference engine sees the trained weights."""
+    from srad_amd.train import FusedAdam, TensorAdam, drn_train_step
+    cfg, sd, duals, lrs, hr, m, dms = _setup(8, 1, 2, 10, 2, 4, 4, prec=prec)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(np.asarray(v).shape) for k, v in sd.items()}
+    opt = FusedAdam(m, lr=1e-4, weight_decay=1e-8)
+    dopts = [TensorAdam(dm.parameters(), lr=1e-4, weight_decay=1e-8) for dm in dms]
+    lr_t = [torch.from_numpy(a).cuda() for a in lrs]
+    hr_t = torch.from_numpy(hr).cuda()
+    losses = [float(drn_train_step(m, dms, lr_t, hr_t, opt, dopts)) for _ in range(5)]
+    print("DRN x8 losses", prec, losses)
+    assert losses[-1] < losses[0]
+    m.eval()
+    with torch.no_grad():
+        y = m(lr_t[0])
+    assert len(y) == 4 and y[-1].shape[-1] == 32 and bool(torch.isfinite(y[-1]).all())
+    if prec == "fp32":                       # eval forward of the trained weights == oracle forward of the same state
+        from oracle import sr_ref as R
+        st = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        ref = R.drn_forward(st, torch.from_numpy(lrs[0]), cfg)
+        assert rel_err(y[-1].cpu().numpy(), ref[-1].numpy()) < 2e-4
+
+
+@pytest.mark.parametrize("scale,n_feats", [(4, 20), (8, 10)])
+def test_drn_gradient_buckets_are_final_when_the_hook_fires(scale, n_feats):
+    """srad_drn_backward's bucket hook (data-parallel all-reduce overlapped with the backward, as DRCT's): the buckets tile the
+    flat gradient buffer, fire in order 0 .. phase + 1, and a stream-ordered copy taken inside the hook already holds the
+    bucket's final values."""
+    from srad_amd.train import drn_loss
+    cfg, sd, duals, lrs, hr, m, dms = _setup(scale, 1, 2, n_feats, 2, 4, 4)
+    tot = m.flat_grads.numel()
+    assert len(m.grad_buckets) == cfg.phase + 2
+    spans = sorted(m.grad_buckets)
+    assert spans[0][0] == 0 and all(a + n == b for (a, n), (b, _) in zip(spans, spans[1:])) and sum(spans[-1]) == tot
+    fired, snaps = [], []
+
+    def hook(b):
+        off, n = m.grad_buckets[b]
+        fired.append(b)
+        snaps.append(m.flat_grads[off:off + n].clone())
+    m.on_bucket = hook
+    lr_t = [torch.from_numpy(a).cuda() for a in lrs]
+    sr = m(lr_t[0])
+    sr2lr = [dms[i](sr[i - len(dms)]) for i in range(len(dms))]
+    drn_loss(sr, lr_t, torch.from_numpy(hr).cuda(), sr2lr).backward()
+    torch.cuda.synchronize()
+    assert fired == list(range(cfg.phase + 2))
+    for b, snap in zip(fired, snaps):
+        off, n = m.grad_buckets[b]
+        assert float(snap.abs().max()) > 0 and torch.equal(snap, m.flat_grads[off:off + n]), b
 
 
 def test_cli_train_drn_writes_run_dir_with_dual_models(tmp_path):

@@ -85,7 +85,7 @@ def test_model_checkpoint_surface(tmp_path):
 
 def test_training_mode_through_the_model_wrapper():
     """Model(opt) in train() mode: DRCT and DRN-L x4 return tensors with a graph and fill the flat gradient buffer;
-    the DRN x8 preset (n_feats = 10, zero-padded layers) has no backward and must say so."""
+    so does the DRN x8 preset (n_feats = 10, level 0 stored zero-padded)."""
     from srad_amd import options as Opt
     from srad_amd.model import Model
     opt = Opt.build_opt('drct', 'grid', 64, 4)
@@ -109,5 +109,7 @@ def test_training_mode_through_the_model_wrapper():
     opt.n_blocks = 2
     m = Model(opt, None)
     m.train()
-    with pytest.raises(NotImplementedError, match="backward"):
-        m(torch.zeros(1, 1, 8, 8, device='cuda'))
+    ys = m(torch.rand(1, 1, 8, 8, device='cuda') * 255)
+    assert len(ys) == 4 and ys[-1].requires_grad and tuple(ys[-1].shape) == (1, 1, 64, 64)
+    (ys[-1].mean() + ys[1].mean()).backward()
+    assert float(m.model.flat_grads.abs().sum()) > 0

@@ -166,12 +166,31 @@ class _FlatNet(torch.nn.Module):
         self.flat_params = torch.randn(n, generator=g) * 0.3
         self.flat_grads = torch.zeros(n)
         self.ps, off = torch.nn.ParameterList(), 0
+        offs = []
         for s in shapes:
             k = int(np.prod(s))
             p = torch.nn.Parameter(self.flat_params[off:off + k].view(s))
             p.grad = self.flat_grads[off:off + k].view(s)
             self.ps.append(p)
+            offs.append(off)
             off += k
+        # the engine's bucket surface (nets.DRN.enable_training): ranges in completion order + a hook fired when a bucket is final
+        self.grad_buckets = [(offs[2], n - offs[2]), (0, offs[2])]
+        self.on_bucket, self.fired = None, []
+        pending = {0: 1, 1: 2}
+
+        def done(b):
+            def hook(_p):
+                pending[b] -= 1
+                if pending[b] == 0:
+                    pending[b] = 1 if b == 0 else 2
+                    self.fired.append(b)
+                    if self.on_bucket is not None:
+                        self.on_bucket(b)
+            return hook
+        self.ps[2].register_post_accumulate_grad_hook(done(0))
+        self.ps[0].register_post_accumulate_grad_hook(done(1))
+        self.ps[1].register_post_accumulate_grad_hook(done(1))
 
     def forward(self, x):
         import torch.nn.functional as F
@@ -219,13 +238,15 @@ def _drn_dp_worker(rank, world, port, q):
     L_.loss, L_.log, L_._acc = [{"type": "L1", "weight": 1.0, "function": None}], torch.zeros(1, 1), None
     L_.note([loss])
     L_._flush()
+    assert net.fired == [0, 1] and (world == 1 or red.model is net)       # world 2: reduced bucket by bucket from the hook
     q.put((rank, net.flat_params.tolist(), dual.weight.detach().reshape(-1).tolist(), float(loss), float(L_.log[-1, 0]), opt.scales))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_drn_data_parallel_step_and_loss_log_gloo_world2():
-    """``drn_train_step``'s reducer branch (gradients of the SR net's flat buffer and of the dual models all-reduced, 1 / world into
+    """``drn_train_step``'s reducer branch (the SR net's gradient buckets all-reduced from the backward's hook as they complete,
+    the dual models' gradients after it, 1 / world into
     the optimizers) and ``Loss._flush`` under world 2 over gloo: two ranks on half batches end with the parameters of one rank
     on the full batch, and the logged loss is the mean over the ranks."""
     import torch.multiprocessing as mp
