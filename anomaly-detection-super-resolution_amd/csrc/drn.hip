@@ -180,7 +180,8 @@ __global__ void scale_add_kernel(const float* __restrict__ r, const float* __res
 // rows - cheaper than a launch boundary, and the lone one-workgroup-per-image gate kernel took 12 us) and then streams
 // its slice of the image: out = r * gate[b] + x.  grid = (slices per image, B); the slice-0 workgroups also write the gate
 // and the pooled sums when the caller keeps them (training).
-template <bool RH>      // RH: r is a bf16 array (the eval path's conv80 wrote it so; half the bytes of this bandwidth-bound pass's largest read)
+template <bool RH, bool XH = false, bool YH = false>   // RH: r is a bf16 array (the eval path's conv80 wrote it so; half the bytes of this
+                                                       // bandwidth-bound pass's largest read); XH / YH: so are the chain tensor read / written
 __global__ __launch_bounds__(256) void ca_scale_add_kernel(const float* __restrict__ part, int nchunk, float inv_hw, int C, int Cr,
                                                            const float* __restrict__ w1, const float* __restrict__ b1,
                                                            const float* __restrict__ w2, const float* __restrict__ b2,
@@ -237,8 +238,21 @@ __global__ __launch_bounds__(256) void ca_scale_add_kernel(const float* __restri
     } else {
       rv = *reinterpret_cast<const f32x4*>(r + pix * C + c);
     }
-    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + pix * ldx + c);
-    *reinterpret_cast<f32x4*>(y + pix * C + c) = rv * *reinterpret_cast<const f32x4*>(gt + c) + xv;
+    f32x4 xv;
+    if constexpr (XH) {
+      const bf16x4 xh = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(x) + pix * ldx + c);
+      xv = f32x4{(float)xh[0], (float)xh[1], (float)xh[2], (float)xh[3]};
+    } else {
+      xv = *reinterpret_cast<const f32x4*>(x + pix * ldx + c);
+    }
+    const f32x4 o = rv * *reinterpret_cast<const f32x4*>(gt + c) + xv;
+    if constexpr (YH) {
+      bf16x4 oh;
+      oh[0] = (__bf16)o[0]; oh[1] = (__bf16)o[1]; oh[2] = (__bf16)o[2]; oh[3] = (__bf16)o[3];
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(y) + pix * C + c) = oh;
+    } else {
+      *reinterpret_cast<f32x4*>(y + pix * C + c) = o;
+    }
   }
 }
 
@@ -407,14 +421,21 @@ int forward_body(srad_drn* h, const float* x, int B, int H, int W, float* const*
     const size_t T = (size_t)B * Hl * Wl;
     float* cur = w.ra;
     float* nxt = w.rb;
+    // bf16 along the chain (bf16 mode, both convolutions on conv80, pool sums from the conv's epilogue): relu(conv), the conv
+    // result AND the chain tensor between the blocks are bf16 arrays - every pass of the chain is bandwidth-side work, and the
+    // MFMA operands are bf16 anyway.  The level's input and its last block's output (the generic GEMMs' operands) stay fp32.
+    static const bool chain_f32 = getenv("SRAD_DRN_CHAIN_F32") != nullptr;
+    bool x_h = false;                                          // xin is a bf16 array
     for (int b = 0; b < c.n_blocks; ++b) {
       const RcabW& r = h->rcab[idx][b];
       bool t_bf16 = false;      // the ReLU output between the two convolutions as bf16 (only the second conv reads it) when both take conv80
       {  // conv + ReLU                                         (drn.py:147-150)
-        GemmParams p = conv_params(h, r.c0, xin, ldin, B, Hl, Wl, 1, w.rt, ch, 0);
+        GemmParams p = conv_params(h, r.c0, x_h ? nullptr : xin, ldin, B, Hl, Wl, 1, w.rt, ch, 0);
+        if (x_h) p.Xh = reinterpret_cast<const __bf16*>(xin);
         p.act = SRAD_ACT_RELU;
         GemmParams q = conv_params(h, r.c1, w.rt, ch, B, Hl, Wl, 1, w.rr, ch, 0);
         t_bf16 = srad_conv80_supported(prec, p) && srad_conv80_supported(prec, q) && getenv("SRAD_DRN_T_F32") == nullptr;
+        SRAD_REQUIRE(t_bf16 || !x_h, "drn_forward: the bf16 chain tensor needs the 80-channel conv kernel");
         if (t_bf16) p.Yh = reinterpret_cast<__bf16*>(w.rt);
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
@@ -435,19 +456,24 @@ int forward_body(srad_drn* h, const float* x, int B, int H, int W, float* const*
         hipLaunchKernelGGL(pool_dot_kernel, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, (const float*)nullptr, w.rr, w.pool, Hl * Wl, ch,
                            DRN_POOL_CHUNKS);
       }
+      const bool r_h = t_bf16 && nchunk_fused;
+      SRAD_REQUIRE(r_h || !x_h, "drn_forward: the bf16 chain tensor needs the conv epilogue's pool sums");
+      const bool y_h = r_h && !chain_f32 && b + 1 < c.n_blocks;   // the next block's conv80 reads it (same shape: supported there too)
       {  // the gate, and res = body(x) * gate + x               (drn.py:128-139, 156-157)
-        SradProfScope prof(s, SRAD_K_MISC, 2.0 * T * ch, 12.0 * T * ch);
-        if (t_bf16 && nchunk_fused)
-          hipLaunchKernelGGL(ca_scale_add_kernel<true>, dim3(ca_slices(Hl * Wl), B), dim3(256), 0, s, w.pool, nchunk,
-                             1.0f / (float)(Hl * Wl), ch, ch / 16, h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2),
-                             (float*)nullptr, (float*)nullptr, w.rr, xin, ldin, cur, Hl * Wl);
-        else
-          hipLaunchKernelGGL(ca_scale_add_kernel<false>, dim3(ca_slices(Hl * Wl), B), dim3(256), 0, s, w.pool, nchunk,
-                             1.0f / (float)(Hl * Wl), ch, ch / 16, h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2),
-                             (float*)nullptr, (float*)nullptr, w.rr, xin, ldin, cur, Hl * Wl);
+        SradProfScope prof(s, SRAD_K_MISC, 2.0 * T * ch, (double)((r_h ? 2 : 4) + (x_h ? 2 : 4) + (y_h ? 2 : 4)) * T * ch);
+        const dim3 grid(ca_slices(Hl * Wl), B);
+        auto launch = [&](auto kern) {
+          hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, w.pool, nchunk, 1.0f / (float)(Hl * Wl), ch, ch / 16, h->pt.fptr(r.w1),
+                             h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2), (float*)nullptr, (float*)nullptr, w.rr, xin, ldin, cur, Hl * Wl);
+        };
+        if (!r_h) launch(ca_scale_add_kernel<false, false, false>);
+        else if (x_h && y_h) launch(ca_scale_add_kernel<true, true, true>);
+        else if (x_h) launch(ca_scale_add_kernel<true, true, false>);
+        else if (y_h) launch(ca_scale_add_kernel<true, false, true>);
+        else launch(ca_scale_add_kernel<true, false, false>);
       }
       SRAD_CHECK_HIP(hipGetLastError());
-      xin = cur; ldin = ch;
+      xin = cur; ldin = ch; x_h = y_h;
       float* t = cur; cur = nxt; nxt = t;
     }
     // Upsampler: conv ch -> 4 ch + PixelShuffle(2), then the 1x1 reducing conv into cat[lvl-1][:, :cout]
