@@ -79,8 +79,17 @@ __global__ void affine_to_nchw_kernel(const float* __restrict__ x, int ldx, floa
 // partial[b][chunk][c] = sum over the chunk's pixels of r[pix][c] (* g[pix][c] when g is given): the global average
 // pool of the channel attention (drn.py:127,136) and, with g, its gate gradient.  Partial rows instead of atomics:
 // float atomicAdd of every conv output element onto B * C addresses made the pooled convolutions 5x slower.
+template <bool RH = false>   // RH: r is a bf16 array (the bf16 training chain's saved conv result)
 __global__ __launch_bounds__(256) void pool_dot_kernel(const float* __restrict__ g, const float* __restrict__ r, float* __restrict__ part,
                                                        int hw, int C, int nchunk) {
+  auto load_r = [&](size_t o) __attribute__((always_inline)) -> f32x4 {
+    if constexpr (RH) {
+      const bf16x4 h = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(r) + o);
+      return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    } else {
+      return *reinterpret_cast<const f32x4*>(r + o);
+    }
+  };
   __shared__ float red[256 * 4];
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int c4n = C / 4, nph = 256 / c4n;
@@ -98,7 +107,7 @@ __global__ __launch_bounds__(256) void pool_dot_kernel(const float* __restrict__
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const size_t o = ((size_t)b * hw + px + u * nph) * C + c4 * 4;
-          rv[u] = *reinterpret_cast<const f32x4*>(r + o);
+          rv[u] = load_r(o);
           gv[u] = *reinterpret_cast<const f32x4*>(g + o);
         }
 #pragma unroll
@@ -108,14 +117,14 @@ __global__ __launch_bounds__(256) void pool_dot_kernel(const float* __restrict__
       for (; px + 3 * nph < p1; px += 4 * nph) {
         f32x4 rv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) rv[u] = *reinterpret_cast<const f32x4*>(r + ((size_t)b * hw + px + u * nph) * C + c4 * 4);
+        for (int u = 0; u < 4; ++u) rv[u] = load_r(((size_t)b * hw + px + u * nph) * C + c4 * 4);
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc += rv[u];
       }
     }
     for (; px < p1; px += nph) {
       const size_t o = ((size_t)b * hw + px) * C + c4 * 4;
-      const f32x4 rv = *reinterpret_cast<const f32x4*>(r + o);
+      const f32x4 rv = load_r(o);
       acc += g ? *reinterpret_cast<const f32x4*>(g + o) * rv : rv;
     }
   }
@@ -190,41 +199,84 @@ __global__ __launch_bounds__(256) void ca_scale_add_kernel(const float* __restri
                                                            float* __restrict__ y, int hw) {
   __shared__ __attribute__((aligned(16))) float gt[512];
   __shared__ float mean[512], hid[64];
+  __shared__ f32x4 red[256];
   const int b = blockIdx.y, tid = threadIdx.x;
-  for (int c = tid; c < C; c += 256) {
-    const float* pp = part + (size_t)b * nchunk * C + c;
-    float sum = 0.f;
-    int k = 0;
-    for (; k + 8 <= nchunk; k += 8) {
-      float t[8];
+  const int c4n = C / 4;
+  // The gate is a chain of dependent steps (pool sums -> hidden units -> gate) in front of a bandwidth-side pass, in every
+  // workgroup: keep its round trips few.  The small weights go to registers before anything else (C <= 96, C / 16 <= 8: every
+  // RCAB of the reference's presets); the partial rows are summed by (row class, channel float4) threads with all of a thread's
+  // rows in flight (one thread per channel walking 32 .. 256 rows eight at a time was 4 .. 32 dependent round trips).
+  const bool small = C <= 96 && Cr <= 8;
+  const int hj = tid >> 5, hl = tid & 31;
+  float w1v[3] = {0.f, 0.f, 0.f}, w2v[8], b1v = 0.f, b2v = 0.f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = pp[(size_t)(k + u) * C];
+  for (int j = 0; j < 8; ++j) w2v[j] = 0.f;
+  if (small) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) sum += t[u];           // same order as ca_gate_kernel: k ascending
+    for (int u = 0; u < 3; ++u) w1v[u] = w1[min(hj, Cr - 1) * C + min(hl + 32 * u, C - 1)];
+    b1v = b1[min(hj, Cr - 1)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w2v[j] = w2[min(tid, C - 1) * Cr + min(j, Cr - 1)];
+    b2v = b2[min(tid, C - 1)];
+  }
+  {
+    const int nparts = 256 / c4n, pt = tid / c4n, c4 = tid - pt * c4n;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (pt < nparts) {
+      const float* pp = part + (size_t)b * nchunk * C + 4 * c4;
+      int k = pt;
+      for (; k + 7 * nparts < nchunk; k += 8 * nparts) {
+        f32x4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4*>(pp + (size_t)(k + u * nparts) * C);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += t[u];
+      }
+      for (; k < nchunk; k += nparts) acc += *reinterpret_cast<const f32x4*>(pp + (size_t)k * C);
+      red[tid] = acc;
     }
-    for (; k < nchunk; ++k) sum += pp[(size_t)k * C];
-    if (pool_out && blockIdx.x == 0) pool_out[(size_t)b * C + c] = sum;
-    mean[c] = sum * inv_hw;
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+      float sum = 0.f;
+      for (int q = 0; q < nparts; ++q) sum += red[q * c4n + (c >> 2)][c & 3];      // fixed order: bit-reproducible
+      if (pool_out && blockIdx.x == 0) pool_out[(size_t)b * C + c] = sum;
+      mean[c] = sum * inv_hw;
+    }
   }
   __syncthreads();
-  for (int j0 = 0; j0 < Cr; j0 += 8) {                     // 8 hidden units per pass, 32 lanes each
-    const int j = j0 + (tid >> 5), l = tid & 31;
+  if (small) {
     float acc = 0.f;
-    if (j < Cr) for (int c = l; c < C; c += 32) acc += w1[j * C + c] * mean[c];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) acc += hl + 32 * u < C ? w1v[u] * mean[hl + 32 * u] : 0.f;
 #pragma unroll
     for (int o = 16; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
-    if (j < Cr && l == 0) hid[j] = fmaxf(acc + b1[j], 0.f);
+    if (hj < Cr && hl == 0) hid[hj] = fmaxf(acc + b1v, 0.f);
+  } else {
+    for (int j0 = 0; j0 < Cr; j0 += 8) {                   // 8 hidden units per pass, 32 lanes each
+      const int j = j0 + hj;
+      float acc = 0.f;
+      if (j < Cr) for (int c = hl; c < C; c += 32) acc += w1[j * C + c] * mean[c];
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+      if (j < Cr && hl == 0) hid[j] = fmaxf(acc + b1[j], 0.f);
+    }
   }
   __syncthreads();
   for (int c = tid; c < C; c += 256) {
-    float acc = b2[c];
-    for (int j = 0; j < Cr; ++j) acc += w2[c * Cr + j] * hid[j];
+    float acc;
+    if (small) {
+      acc = b2v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += j < Cr ? w2v[j] * hid[j] : 0.f;
+    } else {
+      acc = b2[c];
+      for (int j = 0; j < Cr; ++j) acc += w2[c * Cr + j] * hid[j];
+    }
     const float g = 1.0f / (1.0f + expf(-acc));
     gt[c] = g;
     if (gate_out && blockIdx.x == 0) gate_out[(size_t)b * C + c] = g;
   }
   __syncthreads();
-  const int c4n = C / 4;
   const int per = (hw + gridDim.x - 1) / gridDim.x;
   const int p0 = blockIdx.x * per, p1 = min(hw, p0 + per);
   const size_t base = (size_t)b * hw;
@@ -262,6 +314,18 @@ inline int pool_rows_per_image(int prec, const GemmParams& p, int hw) {
   const int bm = srad_gemm_tile_rows(prec, p);
   if (off || bm < 64 || hw % bm != 0 || hw / bm > DRN_POOL_MAXCHUNKS) return 0;
   return hw / bm;
+}
+
+// bf16 along a level's RCAB chain in TRAINING (forward saves and backward operands): both convolutions on the 80-channel
+// kernel, their weight gradients on the nine-tap kernel, the pool sums from the conv's epilogue.  Decided from the shape
+// alone so that the forward and the backward agree; every launch re-checks its kernel's own predicate.
+inline bool drn_level_bf16(int prec, int B, int Hl, int Wl, int ch) {
+  static const bool off = getenv("SRAD_DRN_CHAIN_F32") || getenv("SRAD_NO_CONV80") || getenv("SRAD_NO_WGRAD_CONV9") ||
+                          getenv("SRAD_DRN_NO_POOL_FUSE") || getenv("SRAD_DRN_T_F32");
+  if (off || prec != SRAD_PREC_BF16 || ch != 80 || Hl % 4 || Wl % 32) return false;
+  const size_t M = (size_t)B * Hl * Wl;
+  const int hw = Hl * Wl;
+  return M >= 128 * 64 && M * 80 < ((size_t)1 << 31) && hw % 128 == 0 && hw / 128 <= DRN_POOL_MAXCHUNKS;
 }
 
 inline int ca_slices(int hw) { return hw >= 128 * 128 ? 128 : (hw >= 1024 ? 64 : (hw >= 64 ? 8 : 1)); }
@@ -453,7 +517,7 @@ int forward_body(srad_drn* h, const float* x, int B, int H, int W, float* const*
       if (nchunk == 0) {  // global average pool (partial rows) as a pass of its own                          (drn.py:127-138)
         nchunk = DRN_POOL_CHUNKS;
         SradProfScope prof(s, SRAD_K_MISC, 1.0 * T * ch + 4.0 * B * ch * (ch / 16), 4.0 * T * ch);
-        hipLaunchKernelGGL(pool_dot_kernel, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, (const float*)nullptr, w.rr, w.pool, Hl * Wl, ch,
+        hipLaunchKernelGGL(pool_dot_kernel<false>, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, (const float*)nullptr, w.rr, w.pool, Hl * Wl, ch,
                            DRN_POOL_CHUNKS);
       }
       const bool r_h = t_bf16 && nchunk_fused;
@@ -829,6 +893,7 @@ __global__ __launch_bounds__(256) void ca_bwd_kernel(const float* __restrict__ p
 }
 
 // dr = g * gate[b] + dpool[b]                                                   (RCAB: r * gate + x, drn.py:139,156)
+template <bool YH = false>   // YH: dr is written as a bf16 array (only MFMA operands read it: the conv's data and weight gradients)
 __global__ void ca_apply_bwd_kernel(const float* __restrict__ g, const float* __restrict__ gate, const float* __restrict__ dpool,
                                     float* __restrict__ dr, size_t T, int C, int hw) {
   const int c4n = C / 4;
@@ -837,9 +902,15 @@ __global__ void ca_apply_bwd_kernel(const float* __restrict__ g, const float* __
     const size_t pix = i / c4n;
     const int c = (int)(i - pix * c4n) * 4;
     const int b = (int)(pix / hw);
-    *reinterpret_cast<f32x4*>(dr + pix * C + c) = *reinterpret_cast<const f32x4*>(g + pix * C + c) *
-                                                      *reinterpret_cast<const f32x4*>(gate + (size_t)b * C + c) +
-                                                  *reinterpret_cast<const f32x4*>(dpool + (size_t)b * C + c);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(g + pix * C + c) * *reinterpret_cast<const f32x4*>(gate + (size_t)b * C + c) +
+                    *reinterpret_cast<const f32x4*>(dpool + (size_t)b * C + c);
+    if constexpr (YH) {
+      bf16x4 h;
+      h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dr) + pix * C + c) = h;
+    } else {
+      *reinterpret_cast<f32x4*>(dr + pix * C + c) = v;
+    }
   }
 }
 
@@ -1095,31 +1166,53 @@ int srad_drn_forward_train(srad_drn_t* h, const float* x, int B, int H, int W, f
   for (int idx = 0; idx < P; ++idx) {
     const int lvl = P - idx, Hl = H0 >> lvl, Wl = W0 >> lvl;
     const int ch = h->rcab[idx][0].ch;
+    // bf16 chain (drn_level_bf16): relu(conv), the conv result and the block outputs are saved as bf16 arrays in the same slots
+    // (what the MFMAs of the forward AND of the backward read are these bf16 values either way); the level's input and its last
+    // block's output - operands of the generic GEMMs - stay fp32
+    const bool lh = drn_level_bf16(prec, B, Hl, Wl, ch);
+    bool x_h = false;
     for (int b = 0; b < c.n_blocks; ++b) {
       const RcabW& r = h->rcab[idx][b];
       const RcabSave& sv = w.rc[idx][b];
       {
-        GemmParams p = conv_params(h, r.c0, xin, ldin, B, Hl, Wl, 1, sv.t, ch, 0);
+        GemmParams p = conv_params(h, r.c0, x_h ? nullptr : xin, ldin, B, Hl, Wl, 1, sv.t, ch, 0);
         p.act = SRAD_ACT_RELU;
+        if (lh) {
+          if (x_h) p.Xh = reinterpret_cast<const __bf16*>(xin);
+          p.Yh = reinterpret_cast<__bf16*>(sv.t);
+          SRAD_REQUIRE(srad_conv80_supported(prec, p), "drn_forward_train: bf16 chain without the 80-channel conv kernel");
+        }
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
       int nchunk = DRN_POOL_CHUNKS;
       {
         GemmParams p = conv_params(h, r.c1, sv.t, ch, B, Hl, Wl, 1, sv.r, ch, 0);
+        if (lh) { p.Xh = reinterpret_cast<const __bf16*>(sv.t); p.Yh = reinterpret_cast<__bf16*>(sv.r); }
         nchunk = pool_rows_per_image(prec, p, Hl * Wl);      // the pool's partial rows from the conv's epilogue when the tiles allow
         if (nchunk > 0) p.pool_part = w.ppart;
+        SRAD_REQUIRE(!lh || (nchunk > 0 && srad_conv80_supported(prec, p)), "drn_forward_train: bf16 chain without the conv epilogue's pool sums");
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
       if (nchunk == 0) {
         nchunk = DRN_POOL_CHUNKS;
-        hipLaunchKernelGGL(pool_dot_kernel, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, (const float*)nullptr, sv.r, w.ppart, Hl * Wl, ch,
+        hipLaunchKernelGGL(pool_dot_kernel<false>, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, (const float*)nullptr, sv.r, w.ppart, Hl * Wl, ch,
                            DRN_POOL_CHUNKS);
       }
-      hipLaunchKernelGGL(ca_scale_add_kernel<false>, dim3(ca_slices(Hl * Wl), B), dim3(256), 0, s, w.ppart, nchunk,
-                         1.0f / (float)(Hl * Wl), ch, ch / 16, h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2),
-                         sv.gate, sv.pool, sv.r, xin, ldin, sv.xo, Hl * Wl);
+      const bool y_h = lh && b + 1 < c.n_blocks;
+      {
+        const dim3 grid(ca_slices(Hl * Wl), B);
+        auto launch = [&](auto kern) {
+          hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, w.ppart, nchunk, 1.0f / (float)(Hl * Wl), ch, ch / 16, h->pt.fptr(r.w1),
+                             h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2), sv.gate, sv.pool, sv.r, xin, ldin, sv.xo, Hl * Wl);
+        };
+        if (!lh) launch(ca_scale_add_kernel<false, false, false>);
+        else if (x_h && y_h) launch(ca_scale_add_kernel<true, true, true>);
+        else if (x_h) launch(ca_scale_add_kernel<true, true, false>);
+        else if (y_h) launch(ca_scale_add_kernel<true, false, true>);
+        else launch(ca_scale_add_kernel<true, false, false>);
+      }
       SRAD_CHECK_HIP(hipGetLastError());
-      xin = sv.xo; ldin = ch;
+      xin = sv.xo; ldin = ch; x_h = y_h;
     }
     const int cout = fw(lvl - 1);
     {
@@ -1237,6 +1330,7 @@ int srad_drn_backward(srad_drn_t* h, const float* const* dys, int n_out, int B, 
     float* gb = w.gb;
     const float* x0 = idx == 0 ? w.deep : w.cat[lvl];       // input of the first RCAB
     const int ld0 = idx == 0 ? top : ch;
+    const bool lh = drn_level_bf16(prec, B, Hl, Wl, ch);    // as the forward: bf16 saves along this level's chain
     SRAD_TRY(srad_wgrad_flush(wq, s));                       // the up convs' partials: reduced on the caller's stream
     for (int b = c.n_blocks - 1; b >= 0; --b) {              // RCAB (drn.py:143-158)
       const RcabW& r = h->rcab[idx][b];
@@ -1247,15 +1341,28 @@ int srad_drn_backward(srad_drn_t* h, const float* const* dys, int n_out, int B, 
       if (side != s && side_done[set]) SRAD_CHECK_HIP(hipStreamWaitEvent(s, side_done[set], 0));   // block n - 2 fully consumed
       float* dr = w.dr2[set];
       float* dt = w.dt2[set];
-      hipLaunchKernelGGL(pool_dot_kernel, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, ga, sv.r, w.ppart, Hl * Wl, ch, DRN_POOL_CHUNKS);
+      const bool x_h = lh && b > 0;                            // this block's input is the previous block's bf16 output
+      if (lh) hipLaunchKernelGGL(pool_dot_kernel<true>, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, ga, sv.r, w.ppart, Hl * Wl, ch, DRN_POOL_CHUNKS);
+      else
+      hipLaunchKernelGGL(pool_dot_kernel<false>, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, ga, sv.r, w.ppart, Hl * Wl, ch, DRN_POOL_CHUNKS);
       hipLaunchKernelGGL(ca_bwd_kernel, dim3(1), dim3(256), 0, s, w.ppart, DRN_POOL_CHUNKS, sv.pool, sv.gate, 1.0f / (float)(Hl * Wl), B,
                          ch, ch / 16, h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), G + h->ts.flat_off[r.w1],
                          G + h->ts.flat_off[r.b1], G + h->ts.flat_off[r.w2], G + h->ts.flat_off[r.b2], w.dpool);
-      hipLaunchKernelGGL(ca_apply_bwd_kernel, dim3(grid1d(T * ch / 4)), dim3(256), 0, s, ga, sv.gate, w.dpool, dr, T, ch, Hl * Wl);
+      if (lh) hipLaunchKernelGGL(ca_apply_bwd_kernel<true>, dim3(grid1d(T * ch / 4)), dim3(256), 0, s, ga, sv.gate, w.dpool, dr, T, ch, Hl * Wl);
+      else
+      hipLaunchKernelGGL(ca_apply_bwd_kernel<false>, dim3(grid1d(T * ch / 4)), dim3(256), 0, s, ga, sv.gate, w.dpool, dr, T, ch, Hl * Wl);
       SRAD_CHECK_HIP(hipGetLastError());
       {
         GemmParams p = drn_dgrad(h, r.c1, dr, ch, B, Hl, Wl, dt, ch, 0);
-        p.R = sv.t; p.ldr = ch; p.rmode = SRAD_RMODE_DLRELU; p.slope = 0.f;           // through the ReLU
+        p.ldr = ch; p.rmode = SRAD_RMODE_DLRELU; p.slope = 0.f;                       // through the ReLU
+        if (lh) {     // dr, the saved relu(conv) (only its sign is used) and dt as bf16 arrays: MFMA operands of this conv / the two weight gradients / the next conv
+          p.X = nullptr; p.Xh = reinterpret_cast<const __bf16*>(dr);
+          p.Rh = reinterpret_cast<const __bf16*>(sv.t);
+          p.Yh = reinterpret_cast<__bf16*>(dt);
+          SRAD_REQUIRE(srad_conv80_supported(prec, p), "drn_backward: bf16 chain without the 80-channel conv kernel");
+        } else {
+          p.R = sv.t;
+        }
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
       // both weight gradients of the block + their reduce on the side stream (dr and dt exist now)
@@ -1263,8 +1370,12 @@ int srad_drn_backward(srad_drn_t* h, const float* const* dys, int n_out, int B, 
       wq.ws = wq_base + (size_t)set * wq_half; wq.ws_floats = wq_half;
       {
         WgradParams g = drn_wgrad(h, r.c1, G, dr, ch, 0, sv.t, ch, B, Hl, Wl, 1);
-        SRAD_TRY(srad_launch_wgrad(prec, g, wq, side));
         WgradParams g0 = drn_wgrad(h, r.c0, G, dt, ch, 0, xin, ldin, B, Hl, Wl, 1);
+        if (lh) {
+          g.dy_bf16 = 1; g.x_bf16 = 1; g0.dy_bf16 = 1; g0.x_bf16 = x_h ? 1 : 0;
+          SRAD_REQUIRE(srad_wgrad_conv9_supported(g) && srad_wgrad_conv9_supported(g0), "drn_backward: bf16 chain without the nine-tap weight-gradient kernel");
+        }
+        SRAD_TRY(srad_launch_wgrad(prec, g, wq, side));
         SRAD_TRY(srad_launch_wgrad(prec, g0, wq, side));
         SRAD_TRY(srad_wgrad_flush(wq, side));
       }
@@ -1275,6 +1386,7 @@ int srad_drn_backward(srad_drn_t* h, const float* const* dys, int n_out, int B, 
       {
         GemmParams p = drn_dgrad(h, r.c0, dt, ch, B, Hl, Wl, gb, ch, 0);
         p.R = ga; p.ldr = ch;                                                        // + the skip path
+        if (lh) { p.X = nullptr; p.Xh = reinterpret_cast<const __bf16*>(dt); }
         SRAD_TRY(srad_launch_gemm(prec, p, s));
       }
       float* t = ga; ga = gb; gb = t;

@@ -511,7 +511,9 @@ template <int NT> struct Wc9 {
 // before and one after the loop); each role has a loop of its own so that the loaders' outstanding loads never meet a join.
 constexpr int WC9S_THREADS = 768, WC9S_LOADERS = 256;
 
-template <int NT>
+// YH / XH: dY / X are bf16 arrays (DRN's bf16 training chain: the loaders move half the bytes and convert nothing; the MFMA
+// operands are these bf16 values either way, only the bias sums see the rounded gradient)
+template <int NT, bool YH = false, bool XH = false>
 __global__ __launch_bounds__(WC9S_THREADS) void wgrad_conv9_kernel(const WgradParams p, const int cpw, const int nchunks,
                                                                     const int ksplit, float* __restrict__ part) {
   constexpr int HS = Wc9<NT>::HS, PT = WC9_PT, HT = WC9_HT, HW = WC9_HW;
@@ -553,9 +555,12 @@ __global__ __launch_bounds__(WC9S_THREADS) void wgrad_conv9_kernel(const WgradPa
 #pragma unroll
       for (int i = 0; i < NX; ++i) if (ro.qx < nqx && ro.qx + nqx * i < WC9_HW) st |= 1u << (NY + i);
     }
-    const float* const dYb = p.dY + p.ycol0;
-    const float* const Xb = p.X;
-    f32x4 vy[NY], vx[NX];
+    typedef typename std::conditional<YH, u32x2, f32x4>::type vy_t;
+    typedef typename std::conditional<XH, u32x2, f32x4>::type vx_t;
+    const vy_t* const dYb = reinterpret_cast<const vy_t*>(reinterpret_cast<const char*>(p.dY) + (size_t)p.ycol0 * (YH ? 2 : 4));
+    const vx_t* const Xb = reinterpret_cast<const vx_t*>(p.X);
+    vy_t vy[NY];
+    vx_t vx[NX];
     f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
     unsigned okm = 0u;
     auto issue = [&](const int chunk) __attribute__((always_inline)) {
@@ -574,7 +579,7 @@ __global__ __launch_bounds__(WC9S_THREADS) void wgrad_conv9_kernel(const WgradPa
 #pragma unroll
       for (int i = 0; i < NY; ++i) {
         const unsigned off = ((st >> i) & 1u) ? oy + i * sy : oy;
-        vy[i] = *reinterpret_cast<const f32x4*>(dYb + off);
+        vy[i] = dYb[off >> 2];                                   // off: elements, a multiple of 4
       }
       const unsigned rowx = (img + min(max(iy, 0), H - 1)) * W;
       const bool rok = iy >= 0 && iy < H;
@@ -583,7 +588,7 @@ __global__ __launch_bounds__(WC9S_THREADS) void wgrad_conv9_kernel(const WgradPa
         const int ix = x0 - 1 + qx + nqx_o * i;
         if (rok && (unsigned)ix < (unsigned)W) okm |= st & (1u << (NY + i));
         const unsigned off = (rowx + min(max(ix, 0), W - 1)) * p.ldx + 4 * sch;
-        vx[i] = *reinterpret_cast<const f32x4*>(Xb + off);
+        vx[i] = Xb[off >> 2];
       }
     };
     auto to_h4 = [](const f32x4 v) __attribute__((always_inline)) -> bf16x4 {
@@ -600,14 +605,26 @@ __global__ __launch_bounds__(WC9S_THREADS) void wgrad_conv9_kernel(const WgradPa
       asm volatile("" : "+v"(ysl), "+v"(xsl));
 #pragma unroll
       for (int i = 0; i < NY; ++i) {
-        const f32x4 v = ((okm >> i) & 1u) ? vy[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-        bsum += v;
-        if ((st >> i) & 1u) *reinterpret_cast<bf16x4*>(yrow + i * ysl) = to_h4(v);
+        if constexpr (YH) {
+          const u32x2 v = ((okm >> i) & 1u) ? vy[i] : u32x2{0u, 0u};
+          const bf16x4 h = __builtin_bit_cast(bf16x4, v);
+          bsum += f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+          if ((st >> i) & 1u) *reinterpret_cast<u32x2*>(yrow + i * ysl) = v;
+        } else {
+          const f32x4 v = ((okm >> i) & 1u) ? vy[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+          bsum += v;
+          if ((st >> i) & 1u) *reinterpret_cast<bf16x4*>(yrow + i * ysl) = to_h4(v);
+        }
       }
 #pragma unroll
       for (int i = 0; i < NX; ++i) {
-        const f32x4 v = ((okm >> (NY + i)) & 1u) ? vx[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-        if ((st >> (NY + i)) & 1u) *reinterpret_cast<bf16x4*>(xrow + i * xsl) = to_h4(v);
+        if constexpr (XH) {
+          const u32x2 v = ((okm >> (NY + i)) & 1u) ? vx[i] : u32x2{0u, 0u};
+          if ((st >> (NY + i)) & 1u) *reinterpret_cast<u32x2*>(xrow + i * xsl) = v;
+        } else {
+          const f32x4 v = ((okm >> (NY + i)) & 1u) ? vx[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+          if ((st >> (NY + i)) & 1u) *reinterpret_cast<bf16x4*>(xrow + i * xsl) = to_h4(v);
+        }
       }
     };
     issue(c0);
@@ -969,7 +986,7 @@ int launch_wgrad80(const WgradParams& p, WgradQueue& q, hipStream_t s) {
 // 3x3 stride-1 C -> C convolution, all nine taps per workgroup (wgrad_conv9_kernel); false: not this layer's kernel
 static bool conv9_supported(const WgradParams& p) {
   if (p.ntaps != 9 || p.stride != 1 || p.N != p.Cin || p.n_real != p.N || p.cin_real != p.Cin || p.N > 80 || (p.N & 3) || p.row_scale ||
-      p.x_bf16 || p.dy_bf16 || p.Hi != p.Ho || p.Wi != p.Wo || (p.Wo % WC9_TW) || (p.ldy & 3) || (p.ldx & 3) || (p.ycol0 & 3) ||
+      ((p.x_bf16 || p.dy_bf16) && !(p.N == 80 && p.dy_bf16)) || p.Hi != p.Ho || p.Wi != p.Wo || (p.Wo % WC9_TW) || (p.ldy & 3) || (p.ldx & 3) || (p.ycol0 & 3) ||
       (size_t)p.M < 8192 || (size_t)p.M * (size_t)std::max(p.ldy, p.ldx) >= ((size_t)1 << 31) || getenv("SRAD_NO_WGRAD_CONV9") != nullptr)
     return false;
   return ((reinterpret_cast<uintptr_t>(p.dY) | reinterpret_cast<uintptr_t>(p.X)) & 15) == 0;
@@ -1001,7 +1018,7 @@ int launch_wgrad_conv9(const WgradParams& p, WgradQueue& q, hipStream_t s) {
   it.dW = p.dW; it.db = p.db; it.part = part; it.n_real = C; it.cin_real = C; it.ntaps = 9; it.grp_real = it.grp_pad = 0;
   it.ksplit = ksplit; it.tile0 = q.tiles; it.alpha = p.alpha;
   q.tiles += square_reduce_tiles(it, C);
-  SradProfScope prof(s, SRAD_K_WGRAD, 2.0 * p.M * C * C * 9.0, 4.0 * p.M * 2.0 * C + 8.0 * 9.0 * PART * ksplit);
+  SradProfScope prof(s, SRAD_K_WGRAD, 2.0 * p.M * C * C * 9.0, (double)p.M * C * ((p.dy_bf16 ? 2 : 4) + (p.x_bf16 ? 2 : 4)) + 8.0 * 9.0 * PART * ksplit);
   auto launch = [&](auto kern, const size_t lds, SradOncePerDevice& configured) -> int {
     if (configured.need()) {
       SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1010,8 +1027,14 @@ int launch_wgrad_conv9(const WgradParams& p, WgradQueue& q, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((unsigned)ksplit), dim3(WC9S_THREADS), lds, s, p, cpw, nchunks, ksplit, part);
     return SRAD_OK;
   };
-  static SradOncePerDevice cfg[6];
+  static SradOncePerDevice cfg[6], cfg_h[2];
   int rc = SRAD_OK;
+  if (p.dy_bf16) {                                              // 80 channels only (conv9_supported): DRN's bf16 training chain
+    rc = p.x_bf16 ? launch(wgrad_conv9_kernel<5, true, true>, Wc9<5>::LDS, cfg_h[1]) : launch(wgrad_conv9_kernel<5, true, false>, Wc9<5>::LDS, cfg_h[0]);
+    if (rc) return rc;
+    SRAD_CHECK_HIP(hipGetLastError());
+    return SRAD_OK;
+  }
   switch (nt) {
     case 1: rc = launch(wgrad_conv9_kernel<1>, Wc9<1>::LDS, cfg[1]); break;
     case 2: rc = launch(wgrad_conv9_kernel<2>, Wc9<2>::LDS, cfg[2]); break;
@@ -2243,9 +2266,12 @@ static int check_wgrad(const WgradParams& p) {
   return SRAD_OK;
 }
 
+bool srad_wgrad_conv9_supported(const WgradParams& p) { return conv9_supported(p); }
+
 int srad_launch_wgrad(int prec, const WgradParams& p, WgradQueue& q, hipStream_t stream) {
   SRAD_TRY(check_wgrad(p));
-  SRAD_REQUIRE(!p.x_bf16 && !p.dy_bf16, "wgrad: bf16 operand storage is for deferred Linear layers only");
+  SRAD_REQUIRE((!p.x_bf16 && !p.dy_bf16) || (prec == SRAD_PREC_BF16 && conv9_supported(p)),
+               "wgrad: bf16 operand storage is for deferred Linear layers and the nine-tap 80-channel convolution kernel only");
   return prec == SRAD_PREC_BF16 ? launch_wgrad<SRAD_PREC_BF16>(p, q, stream) : launch_wgrad<SRAD_PREC_F32>(p, q, stream);
 }
 

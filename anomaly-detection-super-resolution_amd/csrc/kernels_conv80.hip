@@ -181,8 +181,14 @@ __global__ __launch_bounds__(C80_NT) void conv80_kernel(const GemmParams p, cons
           for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
         }
         v = v * p.alpha;
-        if (p.R) {
-          const f32x4 r = *reinterpret_cast<const f32x4*>(p.R + pix * p.ldr + c);
+        if (p.R || p.Rh) {
+          f32x4 r;
+          if (p.Rh) {
+            const bf16x4 rh = *reinterpret_cast<const bf16x4*>(p.Rh + pix * p.ldr + c);
+            r = f32x4{(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
+          } else {
+            r = *reinterpret_cast<const f32x4*>(p.R + pix * p.ldr + c);
+          }
           if (p.rmode == SRAD_RMODE_ADD) v += r;
           else {
 #pragma unroll
@@ -232,8 +238,8 @@ bool srad_conv80_supported(int prec, const GemmParams& p) {
   return !off && prec == SRAD_PREC_BF16 && p.ntaps == 9 && p.stride == 1 && p.Cin == 80 && p.N == 80 && !p.ln_g && p.ps == 0 &&
          p.hsplit_hd == 0 && !p.row_scale && !p.Ypre && (p.act == SRAD_ACT_NONE || p.act == SRAD_ACT_RELU || p.act == SRAD_ACT_LRELU) &&   // the epilogue has no GELU: such a call stays on the tiled GEMM
          p.Hi == p.Ho && p.Wi == p.Wo && p.Hi % C80_TH == 0 && p.Wi % C80_TW == 0 &&
-         (!p.R || p.rmode == SRAD_RMODE_ADD || p.rmode == SRAD_RMODE_DLRELU) && (p.ldx & 3) == 0 && (p.ldy & 3) == 0 && (p.yoff & 3) == 0 &&
-         (!p.R || (p.ldr & 3) == 0) && (((uintptr_t)p.X | (uintptr_t)p.Y | (uintptr_t)p.R | (uintptr_t)p.bias | (uintptr_t)p.Wp) & 15) == 0 &&
+         ((!p.R && !p.Rh) || p.rmode == SRAD_RMODE_ADD || p.rmode == SRAD_RMODE_DLRELU) && !(p.R && p.Rh) && (p.ldx & 3) == 0 && (p.ldy & 3) == 0 &&
+         (p.yoff & 3) == 0 && ((!p.R && !p.Rh) || (p.ldr & 3) == 0) && ((uintptr_t)p.Rh & 7) == 0 && (((uintptr_t)p.X | (uintptr_t)p.Y | (uintptr_t)p.R | (uintptr_t)p.bias | (uintptr_t)p.Wp) & 15) == 0 &&
          (((uintptr_t)p.Xh | (uintptr_t)p.Yh) & 7) == 0 &&
          p.M >= 128 * 64;                                        // small launches stay on the tiled GEMM (one tile per workgroup anyway)
 }
@@ -249,7 +255,7 @@ int srad_launch_conv80(const GemmParams& p, hipStream_t stream) {
     configured.done();
   }
   const double K = 9.0 * 80;
-  SradProfScope prof(stream, SRAD_K_CONV80, 2.0 * p.M * 80 * K, 4.0 * p.M * 80 * (p.R ? 3 : 2) + 2.0 * 80 * K);
+  SradProfScope prof(stream, SRAD_K_CONV80, 2.0 * p.M * 80 * K, (double)p.M * 80 * ((p.Xh ? 2 : 4) + (p.Yh ? 2 : 4) + (p.R ? 4 : p.Rh ? 2 : 0)) + 2.0 * 80 * K);
   if (p.Xh) hipLaunchKernelGGL(conv80_kernel<true>, dim3(ntiles < 256 ? ntiles : 256), dim3(C80_NT), C80_LDS, stream, p, ntiles, tiles_x, tiles_per_img);
   else hipLaunchKernelGGL(conv80_kernel<false>, dim3(ntiles < 256 ? ntiles : 256), dim3(C80_NT), C80_LDS, stream, p, ntiles, tiles_x, tiles_per_img);
   SRAD_CHECK_HIP(hipGetLastError());

@@ -150,6 +150,7 @@ struct GemmParams {
   // conv80 only (srad_conv80_supported): the input as bf16 (same ldx, in elements) / the output as bf16 through Yh without
   // hsplit - the ReLU output between an RCAB's two convolutions, which only the second one reads
   const __bf16* Xh = nullptr;
+  const __bf16* Rh = nullptr;   // conv80 only: R as a bf16 array (ldr in elements) - the saved ReLU output as the backward's mask
   // ---- training extensions (all off when zero) ----
   int rmode;                 // how R enters: 0 v = act(acc)*alpha*rs + R (residual); 1 v = acc*alpha*rs * gelu'(R);
                              //               2 v = acc*alpha*rs * (R > 0 ? 1 : slope)   (backward through an activation)
@@ -343,6 +344,7 @@ struct WgradQueue {
 int srad_launch_wgrad_deferred(int prec, const WgradParams& p, WgradQueue& q, hipStream_t stream);
 int srad_wgrad_launch_deferred(int prec, WgradQueue& q, hipStream_t stream);
 int srad_launch_wgrad(int prec, const WgradParams& p, WgradQueue& q, hipStream_t stream);
+bool srad_wgrad_conv9_supported(const WgradParams& p);   // the nine-tap kernel takes this layer (bf16 mode; the only one with bf16 conv operands)
 int srad_wgrad_flush(WgradQueue& q, hipStream_t stream);
 
 #define SRAD_WGRAD_WS_BYTES ((size_t)256 << 20)   /* what the engines give the queue */
