@@ -893,17 +893,77 @@ __global__ __launch_bounds__(256) void ca_bwd_kernel(const float* __restrict__ p
 }
 
 // dr = g * gate[b] + dpool[b]                                                   (RCAB: r * gate + x, drn.py:139,156)
+// with dpool recomputed per workgroup from the pool_dot partial rows (as the forward's ca_scale_add recomputes the gate): the
+// channel attention's data gradient - sigmoid, the two 1x1 convs, the ReLU, back to the mean - is C * C/16 * 3 MACs per image,
+// while the one-workgroup ca_bwd_kernel that used to hand it over sat on the critical path of every block (16 us x 80 per
+// step); that kernel now only produces the weight gradients, on the side stream.  grid = (slices per image, B).
 template <bool YH = false>   // YH: dr is written as a bf16 array (only MFMA operands read it: the conv's data and weight gradients)
-__global__ void ca_apply_bwd_kernel(const float* __restrict__ g, const float* __restrict__ gate, const float* __restrict__ dpool,
-                                    float* __restrict__ dr, size_t T, int C, int hw) {
+__global__ __launch_bounds__(256) void ca_apply_bwd_kernel(const float* __restrict__ g, const float* __restrict__ gate,
+                                                           const float* __restrict__ part, int nchunk, const float* __restrict__ pool,
+                                                           float inv_hw, int C, int Cr, const float* __restrict__ w1,
+                                                           const float* __restrict__ b1, const float* __restrict__ w2,
+                                                           float* __restrict__ dr, int hw) {
+  __shared__ __attribute__((aligned(16))) float gt[512], dpl[512];
+  __shared__ float sg[512], mean[512], dhid[64];
+  __shared__ f32x4 red[256];
+  const int b = blockIdx.y, tid = threadIdx.x;
   const int c4n = C / 4;
-  const size_t total = T * c4n;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t pix = i / c4n;
-    const int c = (int)(i - pix * c4n) * 4;
-    const int b = (int)(pix / hw);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(g + pix * C + c) * *reinterpret_cast<const f32x4*>(gate + (size_t)b * C + c) +
-                    *reinterpret_cast<const f32x4*>(dpool + (size_t)b * C + c);
+  const int hj = tid >> 5, hl = tid & 31;
+  {  // dgate = sum of the partial rows, all of a thread's rows in flight (see ca_scale_add_kernel)
+    const int nparts = 256 / c4n, pt = tid / c4n, c4 = tid - pt * c4n;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (pt < nparts) {
+      const float* pp = part + (size_t)b * nchunk * C + 4 * c4;
+      int k = pt;
+      for (; k + 3 * nparts < nchunk; k += 4 * nparts) {
+        f32x4 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const f32x4*>(pp + (size_t)(k + u * nparts) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += t[u];
+      }
+      for (; k < nchunk; k += nparts) acc += *reinterpret_cast<const f32x4*>(pp + (size_t)k * C);
+      red[tid] = acc;
+    }
+    for (int c = tid; c < C; c += 256) {
+      gt[c] = gate[(size_t)b * C + c];
+      mean[c] = pool[(size_t)b * C + c] * inv_hw;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+      float dg = 0.f;
+      for (int q = 0; q < nparts; ++q) dg += red[q * c4n + (c >> 2)][c & 3];
+      sg[c] = dg * gt[c] * (1.f - gt[c]);                  // through the sigmoid
+    }
+  }
+  __syncthreads();
+  for (int j0 = 0; j0 < Cr; j0 += 8) {                     // hidden units: pre-activation (its sign is the ReLU's mask) and gradient
+    const int j = j0 + hj;
+    float acc = 0.f, dh = 0.f;
+    if (j < Cr)
+      for (int c = hl; c < C; c += 32) {
+        acc += w1[j * C + c] * mean[c];
+        dh += sg[c] * w2[c * Cr + j];
+      }
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) { acc += __shfl_xor(acc, o); dh += __shfl_xor(dh, o); }
+    if (j < Cr && hl == 0) dhid[j] = acc + b1[j] > 0.f ? dh : 0.f;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {                     // back to the pooled mean
+    float dm = 0.f;
+    for (int j = 0; j < Cr; ++j) dm += dhid[j] * w1[j * C + c];
+    dpl[c] = dm * inv_hw;
+  }
+  __syncthreads();
+  const int per = (hw + gridDim.x - 1) / gridDim.x;
+  const int p0 = blockIdx.x * per, p1 = min(hw, p0 + per);
+  const size_t base = (size_t)b * hw;
+  for (int i = tid; i < (p1 - p0) * c4n; i += 256) {
+    const int pl = i / c4n, c = (i - pl * c4n) * 4;
+    const size_t pix = base + p0 + pl;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(g + pix * C + c) * *reinterpret_cast<const f32x4*>(gt + c) +
+                    *reinterpret_cast<const f32x4*>(dpl + c);
     if constexpr (YH) {
       bf16x4 h;
       h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
@@ -975,7 +1035,7 @@ struct DrnTrainWs {
   std::vector<float*> cat, dtmp, ups, timg;
   std::vector<std::vector<RcabSave>> rc;
   // backward
-  float *gdeep, *ga, *gb, *dr2[2], *dt2[2], *dups, *dus, *ddtmp, *zup, *dtimg, *dup0, *ppart, *dpool;   // dr / dt double-buffered (two streams)
+  float *gdeep, *ga, *gb, *dr2[2], *dt2[2], *dups, *dus, *ddtmp, *zup, *dtimg, *dup0, *ppart, *ppart2[2], *dpool2[2];   // dr / dt / pool_dot rows double-buffered (two streams)
   std::vector<float*> gcat;
   size_t bytes;
 };
@@ -1022,7 +1082,9 @@ DrnTrainWs plan_train_ws(const srad_drn* h, int B, int H, int W, void* base, siz
   w.dtimg = bp.take(T0 * SRAD_IMG_CPAD);
   w.dup0 = bp.take(T0 * SRAD_IMG_CPAD);
   w.ppart = bp.take((size_t)B * DRN_POOL_MAXCHUNKS * top);
-  w.dpool = bp.take((size_t)B * top);
+  w.ppart2[0] = w.ppart;                                   // the backward's pool_dot rows (DRN_POOL_CHUNKS per image): the forward's are spent
+  w.ppart2[1] = bp.take((size_t)B * DRN_POOL_CHUNKS * top);
+  for (int i = 0; i < 2; ++i) w.dpool2[i] = bp.take((size_t)B * top);
   w.bytes = bp.used;
   return w;
 }
@@ -1321,8 +1383,21 @@ int srad_drn_backward(srad_drn_t* h, const float* const* dys, int n_out, int B, 
     SRAD_TRY(srad_launch_unshuffle(w.dups, w.dus, B, Hl, Wl, ch, s));
     const float* chain_out = w.rc[idx][c.n_blocks - 1].xo;
     {
+      // ch -> 4 ch, nine taps: four ch -> ch column blocks of dY when the nine-tap kernel takes them (the tiled kernel runs this
+      // layer at ~90 TFLOP/s: 0.64 ms at 128 px against 4 x 45 us)
       WgradParams g = drn_wgrad(h, h->up_conv[idx], G, w.dus, 4 * ch, 0, chain_out, ch, B, Hl, Wl, 1);
-      SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
+      WgradParams gq = g;
+      gq.N = gq.n_real = ch;
+      if (prec == SRAD_PREC_BF16 && g.N == 4 * ch && g.n_real == g.N && g.cin_real == ch && srad_wgrad_conv9_supported(gq)) {
+        for (int q = 0; q < 4; ++q) {
+          gq.ycol0 = q * ch;
+          gq.dW = g.dW + (size_t)q * ch * ch * 9;
+          gq.db = g.db ? g.db + q * ch : nullptr;
+          SRAD_TRY(srad_launch_wgrad(prec, gq, wq, s));
+        }
+      } else {
+        SRAD_TRY(srad_launch_wgrad(prec, g, wq, s));
+      }
       GemmParams p = drn_dgrad(h, h->up_conv[idx], w.dus, 4 * ch, B, Hl, Wl, w.ga, ch, 0);
       SRAD_TRY(srad_launch_gemm(prec, p, s));
     }
@@ -1342,15 +1417,18 @@ int srad_drn_backward(srad_drn_t* h, const float* const* dys, int n_out, int B, 
       float* dr = w.dr2[set];
       float* dt = w.dt2[set];
       const bool x_h = lh && b > 0;                            // this block's input is the previous block's bf16 output
-      if (lh) hipLaunchKernelGGL(pool_dot_kernel<true>, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, ga, sv.r, w.ppart, Hl * Wl, ch, DRN_POOL_CHUNKS);
-      else
-      hipLaunchKernelGGL(pool_dot_kernel<false>, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, ga, sv.r, w.ppart, Hl * Wl, ch, DRN_POOL_CHUNKS);
-      hipLaunchKernelGGL(ca_bwd_kernel, dim3(1), dim3(256), 0, s, w.ppart, DRN_POOL_CHUNKS, sv.pool, sv.gate, 1.0f / (float)(Hl * Wl), B,
-                         ch, ch / 16, h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), G + h->ts.flat_off[r.w1],
-                         G + h->ts.flat_off[r.b1], G + h->ts.flat_off[r.w2], G + h->ts.flat_off[r.b2], w.dpool);
-      if (lh) hipLaunchKernelGGL(ca_apply_bwd_kernel<true>, dim3(grid1d(T * ch / 4)), dim3(256), 0, s, ga, sv.gate, w.dpool, dr, T, ch, Hl * Wl);
-      else
-      hipLaunchKernelGGL(ca_apply_bwd_kernel<false>, dim3(grid1d(T * ch / 4)), dim3(256), 0, s, ga, sv.gate, w.dpool, dr, T, ch, Hl * Wl);
+      float* const pp = w.ppart2[set];
+      if (lh) hipLaunchKernelGGL(pool_dot_kernel<true>, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, ga, sv.r, pp, Hl * Wl, ch, DRN_POOL_CHUNKS);
+      else hipLaunchKernelGGL(pool_dot_kernel<false>, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, ga, sv.r, pp, Hl * Wl, ch, DRN_POOL_CHUNKS);
+      {
+        const dim3 grid(ca_slices(Hl * Wl), B);
+        auto launch = [&](auto kern) {
+          hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, ga, sv.gate, pp, DRN_POOL_CHUNKS, sv.pool, 1.0f / (float)(Hl * Wl), ch, ch / 16,
+                             h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), dr, Hl * Wl);
+        };
+        if (lh) launch(ca_apply_bwd_kernel<true>);
+        else launch(ca_apply_bwd_kernel<false>);
+      }
       SRAD_CHECK_HIP(hipGetLastError());
       {
         GemmParams p = drn_dgrad(h, r.c1, dr, ch, B, Hl, Wl, dt, ch, 0);
@@ -1368,6 +1446,11 @@ int srad_drn_backward(srad_drn_t* h, const float* const* dys, int n_out, int B, 
       // both weight gradients of the block + their reduce on the side stream (dr and dt exist now)
       SRAD_TRY(a_waits_b(side, s));
       wq.ws = wq_base + (size_t)set * wq_half; wq.ws_floats = wq_half;
+      // the channel attention's weight / bias gradients (one workgroup, all images): nothing on the data path waits for them
+      hipLaunchKernelGGL(ca_bwd_kernel, dim3(1), dim3(256), 0, side, pp, DRN_POOL_CHUNKS, sv.pool, sv.gate, 1.0f / (float)(Hl * Wl), B,
+                         ch, ch / 16, h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), G + h->ts.flat_off[r.w1],
+                         G + h->ts.flat_off[r.b1], G + h->ts.flat_off[r.w2], G + h->ts.flat_off[r.b2], w.dpool2[set]);
+      SRAD_CHECK_HIP(hipGetLastError());
       {
         WgradParams g = drn_wgrad(h, r.c1, G, dr, ch, 0, sv.t, ch, B, Hl, Wl, 1);
         WgradParams g0 = drn_wgrad(h, r.c0, G, dt, ch, 0, xin, ldin, B, Hl, Wl, 1);
