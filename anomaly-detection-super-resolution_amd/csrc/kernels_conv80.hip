@@ -148,9 +148,27 @@ __global__ __launch_bounds__(C80_NT) void conv80_kernel(const GemmParams p, cons
   stamp();                                                                  // 3
 
   const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int row = wave & 3, nh = wave >> 2;                   // this wave: tile row, and output channel tiles {0, 1, 2} or {3, 4}
-  // One tile: NTW channel tiles from nt0 on.  The k walk is incremental: a lane's first k of chunk kc is 32 kc + 8 fq, i.e.
-  // (tap, ch) advances by 32 channels per chunk and wraps into the next tap at 80.
+  const int row = wave & 3, nh = wave >> 2;
+  // A lane's first k of chunk kc is 32 kc + 8 fq: (tap, channel) advances by 32 channels per chunk and wraps into the next tap
+  // at 80.  The 23 halo-tile offsets this gives do not depend on the tile: they live in registers for the kernel's lifetime, and
+  // the MFMA loop issues no address arithmetic at all (the incremental walk was ~12 VALU instructions per chunk and wave on the
+  // port the MFMAs issue through).
+  constexpr int C80_NCH = C80_K / 32;
+  int aoff[C80_NCH];
+  {
+    int ch = 8 * fq, dx = 0, rowoff = (row * C80_HW + fr) * C80_PLD;
+#pragma unroll
+    for (int kc = 0; kc < C80_NCH; ++kc) {
+      aoff[kc] = rowoff + dx * C80_PLD + ch;
+      if (kc == C80_NCH - 1 && fq >= 2) aoff[kc] = (row * C80_HW + fr) * C80_PLD;   // k >= 720: the weights are zero there, any valid address does
+      ch += 32;
+      if (ch >= 80) {
+        ch -= 80;
+        if (++dx == 3) { dx = 0; rowoff += C80_HW * C80_PLD; }
+      }
+    }
+  }                   // this wave: tile row, and output channel tiles {0, 1, 2} or {3, 4}
+  // One tile: NTW channel tiles from nt0 on.
   auto tile = [&](auto NTW_c, const int nt0, const int t) __attribute__((always_inline)) {
     constexpr int NTW = decltype(NTW_c)::value;
     f32x4 acc[2][NTW];
@@ -174,27 +192,19 @@ __global__ __launch_bounds__(C80_NT) void conv80_kernel(const GemmParams p, cons
           else rres[rt][nt] = *reinterpret_cast<const f32x4*>(p.R + o);
         }
     }
-    int ch = 8 * fq, dx = 0, rowoff = (row * C80_HW + fr) * C80_PLD;
     const __bf16* const wrow = Ws + (nt0 * 16 + fr) * C80_WLD + 8 * fq;
     // fragments of chunk kc + DEPTH are requested before chunk kc is multiplied (three register sets): with two waves per SIMD
     // and the compiler's one-chunk look-ahead the waves spent 59 % of their time parked on LDS latency (SQ_WAIT_ANY)
-    constexpr int NCH = C80_K / 32, DEPTH = 2;
+    constexpr int NCH = C80_NCH, DEPTH = 2;
     bf16x8 fa[DEPTH + 1][2], fw[DEPTH + 1][NTW];
     auto fetch = [&](auto KC) __attribute__((always_inline)) {
       constexpr int kc = decltype(KC)::value;
       if constexpr (kc < NCH) {
         constexpr int st = kc % (DEPTH + 1);
-        int off = rowoff + dx * C80_PLD + ch;
-        if (kc == NCH - 1 && fq >= 2) off = (row * C80_HW + fr) * C80_PLD;      // k >= 720: the weights are zero there, any valid address does
-        fa[st][0] = *reinterpret_cast<const bf16x8*>(Hs + off);
-        fa[st][1] = *reinterpret_cast<const bf16x8*>(Hs + off + 16 * C80_PLD);
+        fa[st][0] = *reinterpret_cast<const bf16x8*>(Hs + aoff[kc]);
+        fa[st][1] = *reinterpret_cast<const bf16x8*>(Hs + aoff[kc] + 16 * C80_PLD);
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) fw[st][nt] = *reinterpret_cast<const bf16x8*>(wrow + nt * 16 * C80_WLD + 32 * kc);
-        ch += 32;
-        if (ch >= 80) {
-          ch -= 80;
-          if (++dx == 3) { dx = 0; rowoff += C80_HW * C80_PLD; }
-        }
       }
     };
     c80_static_for<0, DEPTH>([&](auto K) { fetch(K); });
@@ -206,6 +216,18 @@ __global__ __launch_bounds__(C80_NT) void conv80_kernel(const GemmParams p, cons
         acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[st][nt], fa[st][0], acc[0][nt], 0, 0, 0);
         acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[st][nt], fa[st][1], acc[1][nt], 0, 0, 0);
       }
+      // Pin the software pipeline: this step's LDS reads (chunk kc + DEPTH) go out one behind each of its MFMAs (chunk kc) and
+      // nothing crosses the step.  Left alone the scheduler sinks every read to just above its first use (s_waitcnt lgkmcnt(1)
+      // in front of most MFMAs): the LDS latency of every chunk was exposed, MFMA and LDS time ADDED (7 300 cycles per tile for
+      // 3 700 cycles of MFMA and 3 300 of LDS reads).
+      constexpr int nrd = kc + DEPTH < NCH ? 2 + NTW : 0, nmf = 2 * NTW;
+#pragma unroll
+      for (int i = 0; i < nrd; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
+      }
+      if constexpr (nmf > nrd) __builtin_amdgcn_sched_group_barrier(0x008, nmf - nrd, 0);
+      __builtin_amdgcn_sched_barrier(0);
     });
     stamp();                                                                // 4 + 5 i: MFMAs of tile i done
     // ---- epilogue: + bias -> activation -> * alpha -> residual mode -> store (GemmParams semantics) ----
@@ -213,11 +235,11 @@ __global__ __launch_bounds__(C80_NT) void conv80_kernel(const GemmParams p, cons
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) csum[nt] = z4;
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      const size_t pix = pix0 + 16 * rt;
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int c = (nt0 + nt) * 16 + 4 * fq;
+      f32x4 vv[2];
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) {
-        const int c = (nt0 + nt) * 16 + 4 * fq;
+      for (int rt = 0; rt < 2; ++rt) {
         f32x4 v = acc[rt][nt] + bias_r[nt];
         if (p.act == SRAD_ACT_RELU) {
 #pragma unroll
@@ -241,14 +263,25 @@ __global__ __launch_bounds__(C80_NT) void conv80_kernel(const GemmParams p, cons
             for (int e = 0; e < 4; ++e) v[e] *= r[e] > 0.f ? 1.f : p.slope;
           }
         }
-        if (p.Yh) {
-          bf16x4 h;
-          h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-          *reinterpret_cast<bf16x4*>(p.Yh + pix * p.ldy + p.yoff + c) = h;
-        } else {
-          *reinterpret_cast<f32x4*>(p.Y + pix * p.ldy + p.yoff + c) = v;
-        }
         csum[nt] += v;
+        vv[rt] = v;
+      }
+      if (p.Yh) {
+        // bf16 output: a lane holds 4 channels (8 bytes) of pixel fr and of pixel 16 + fr.  8-byte stores are issue-bound (six
+        // of them were 2 800 of a tile's 8 000 cycles): the lane pair (fq, fq ^ 1) trades halves with v_permlane16_swap - rows of
+        // 16 lanes ARE the fq groups - so that the even lane ends with 8 consecutive channels of pixel fr, the odd lane with
+        // the same 8 channels of pixel 16 + fr: one 16-byte store each.
+        bf16x4 h0, h1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h0[e] = (__bf16)vv[0][e]; h1[e] = (__bf16)vv[1][e]; }
+        const u32x2 a = __builtin_bit_cast(u32x2, h0), bq = __builtin_bit_cast(u32x2, h1);
+        const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], bq[0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], bq[1], false, false);
+        const size_t pix = pix0 + 16 * (fq & 1);
+        *reinterpret_cast<u32x4*>(p.Yh + pix * p.ldy + p.yoff + (nt0 + nt) * 16 + 4 * (fq & ~1)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+      } else {
+        *reinterpret_cast<f32x4*>(p.Y + pix0 * p.ldy + p.yoff + c) = vv[0];
+        *reinterpret_cast<f32x4*>(p.Y + (pix0 + 16) * p.ldy + p.yoff + c) = vv[1];
       }
     }
     if (p.pool_part) {                                        // the tile's column sums: 16 pixels per lane group, then the four rows
@@ -290,7 +323,7 @@ bool srad_conv80_supported(int prec, const GemmParams& p) {
          p.Hi == p.Ho && p.Wi == p.Wo && p.Hi % C80_TH == 0 && p.Wi % C80_TW == 0 &&
          ((!p.R && !p.Rh) || p.rmode == SRAD_RMODE_ADD || p.rmode == SRAD_RMODE_DLRELU) && !(p.R && p.Rh) && (p.ldx & 3) == 0 && (p.ldy & 3) == 0 &&
          (p.yoff & 3) == 0 && ((!p.R && !p.Rh) || (p.ldr & 3) == 0) && ((uintptr_t)p.Rh & 7) == 0 && (((uintptr_t)p.X | (uintptr_t)p.Y | (uintptr_t)p.R | (uintptr_t)p.bias | (uintptr_t)p.Wp) & 15) == 0 &&
-         (((uintptr_t)p.Xh | (uintptr_t)p.Yh) & 7) == 0 &&
+         ((uintptr_t)p.Xh & 7) == 0 && ((uintptr_t)p.Yh & 15) == 0 && (!p.Yh || ((p.ldy & 7) == 0 && (p.yoff & 7) == 0)) &&
          p.M >= 128 * 64;                                        // small launches stay on the tiled GEMM (one tile per workgroup anyway)
 }
 
