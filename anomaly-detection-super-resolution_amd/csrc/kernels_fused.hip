@@ -189,14 +189,41 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
             }
           }
         }
-        // operands swapped (W as the MFMA "A", activations as "B"): the result tile is transposed, so a lane
-        // holds 4 CONSECUTIVE OUTPUT COLUMNS (4*fq + e) of one token row (fr) - exactly the k-contiguous
-        // quad the next GEMM's A operand, the bias/residual vectors and the global store want.
+        if constexpr (SPLIT) {
+          // operands swapped (W as the MFMA "A", activations as "B"): the result tile is transposed, so a lane
+          // holds 4 CONSECUTIVE OUTPUT COLUMNS (4*fq + e) of one token row (fr) - exactly the k-contiguous
+          // quad the next GEMM's A operand, the bias/residual vectors and the global store want.
 #pragma unroll
-        for (int rt = 0; rt < NRT; ++rt) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + rt * 16 * lda + cc * 32);
-          c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, c[rt], 0, 0, 0);
+          for (int rt = 0; rt < NRT; ++rt) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + rt * 16 * lda + cc * 32);
+            c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, c[rt], 0, 0, 0);
+          }
         }
+      }
+    }
+    if constexpr (!SPLIT) {
+      // bf16: the activation fragments of G chunks are requested together, THEN multiplied (sched_barrier: left alone the
+      // scheduler sinks every LDS read to just above its MFMA - s_waitcnt lgkmcnt(0 / 1) in front of each of a stage's eight
+      // dependent MFMAs, i.e. the LDS latency exposed four to eight times per stage and ten to sixteen stages per launch)
+      constexpr int G = NRT == 1 ? 8 : (NRT == 2 ? 4 : 2);
+#pragma unroll
+      for (int cc0 = 0; cc0 < 8; cc0 += G) {
+        bf16x8 af[G][NRT];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          if (cc0 + g < nch) {
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) af[g][rt] = *reinterpret_cast<const bf16x8*>(ar + rt * 16 * lda + (cc0 + g) * 32);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          if (cc0 + g < nch) {
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, reg[cc0 + g]);
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, af[g][rt], c[rt], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   };

@@ -279,20 +279,44 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
     }
     if (live) {
       const __bf16* ar = XN + fr * QA_LDX + kg * 256 + 8 * fq;
+      if constexpr (SPLIT) {
 #pragma unroll
-      for (int cc = 0; cc < nch; ++cc) {
-        const bf16x8 b0 = __builtin_bit_cast(bf16x8, reg[cc]);
-        if constexpr (SPLIT && part == 0) {
+        for (int cc = 0; cc < nch; ++cc) {
+          const bf16x8 b0 = __builtin_bit_cast(bf16x8, reg[cc]);
+          if constexpr (part == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + XN_E + t * 16 * QA_LDX + cc * 32);
+              ac[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, ac[t], 0, 0, 0);
+            }
+          }
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + XN_E + t * 16 * QA_LDX + cc * 32);
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + t * 16 * QA_LDX + cc * 32);
             ac[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, ac[t], 0, 0, 0);
           }
         }
+      } else {
+        // the window fragments of two chunks are requested together, THEN multiplied (sched_barrier: the scheduler otherwise
+        // sinks each LDS read to just above its MFMA and the LDS latency is paid per MFMA; see mlp_block_kernel)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + t * 16 * QA_LDX + cc * 32);
-          ac[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, ac[t], 0, 0, 0);
+        for (int cc0 = 0; cc0 < nch; cc0 += 2) {
+          bf16x8 af[2][4];
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+            if (cc0 + g < nch) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t) af[g][t] = *reinterpret_cast<const bf16x8*>(ar + t * 16 * QA_LDX + (cc0 + g) * 32);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+            if (cc0 + g < nch) {
+              const bf16x8 b0 = __builtin_bit_cast(bf16x8, reg[cc0 + g]);
+#pragma unroll
+              for (int t = 0; t < 4; ++t) ac[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, af[g][t], ac[t], 0, 0, 0);
+            }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
