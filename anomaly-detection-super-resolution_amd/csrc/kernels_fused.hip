@@ -43,8 +43,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 #ifndef SRAD_X3_FULLSTAGE
 #define SRAD_X3_FULLSTAGE 1
 #endif
-constexpr int F_LDA = 392;         // LDS row stride of the <=384-wide bf16 activation tile
-constexpr int F_LDH = 520;         // LDS row stride of the <=512-wide hidden tile
+constexpr int F_LDA = 400;         // LDS row stride of the <=384-wide bf16 activation tile (2 mod 4 sixteen-byte units: conflict-free for the lane groups of ds_read_b128, see kernels_conv80.hip)
+constexpr int F_LDH = 528;         // LDS row stride of the <=512-wide hidden tile
 constexpr int F_SC = 128;          // output columns per weight stage
 constexpr int F_NV = 2560;         // floats of bias / gamma / beta staged in LDS (10 per thread)
 

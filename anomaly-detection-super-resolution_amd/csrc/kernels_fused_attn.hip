@@ -24,7 +24,7 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-constexpr int QA_LDP = 72;     // probability tile row stride
+constexpr int QA_LDP = 80;     // probability tile row stride (2 mod 4 sixteen-byte units: conflict-free for the lane groups of ds_read_b128, see kernels_conv80.hip)
 constexpr int QA_LDB = 68;     // bias table row stride (floats): the 16 keys a float4 read group touches fall on 16 different bank quads
 
 // HDT = ceil(head_dim / 16) (2, 3, 4, 5 or 8), KC = ceil(d / 32) 32-wide k chunks (<= 10)
@@ -36,10 +36,10 @@ constexpr int QA_LDB = 68;     // bias table row stride (floats): the 16 keys a 
 template <int HDT, int KC, bool STAMP = false, bool SPLIT = false>
 __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
   constexpr int KG = (KC + 7) / 8;         // 256-wide k groups per weight stage
-  constexpr int QA_LDX = KC * 32 + 8;      // LDS row stride of the normalised window tile
+  constexpr int QA_LDX = KC * 32 + 16;     // LDS row stride of the normalised window tile
   constexpr int HDP = 16 * HDT;            // padded head dim
   constexpr int HDP32 = (HDP + 31) & ~31;  // k extent of the q.k^T MFMA steps
-  constexpr int HS = HDP32 + 8;            // q/k/v LDS row stride
+  constexpr int HS = HDP32 + 16;           // q/k/v LDS row stride
   constexpr int NV = 3 * HDP;              // virtual output columns [q | k | v]
   constexpr int NS = (NV + 127) / 128;     // 128-column stages: each of the 8 waves owns 16 of them
   constexpr int n_stages = NS * KG;
@@ -442,8 +442,8 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
 
 template <int HDT, int KC, bool STAMP = false, bool SPLIT = false>
 int launch_qa(const QkvAttnParams& p, hipStream_t stream) {
-  constexpr int HDP = 16 * HDT, HS = ((HDP + 31) & ~31) + 8;
-  constexpr int XN_E = 64 * (KC * 32 + 8), QP_E = 3 * 64 * HS + 64 * QA_LDP;
+  constexpr int HDP = 16 * HDT, HS = ((HDP + 31) & ~31) + 16;
+  constexpr int XN_E = 64 * (KC * 32 + 16), QP_E = 3 * 64 * HS + 64 * QA_LDP;
   constexpr size_t lds = (size_t)(SPLIT ? 2 * (XN_E > QP_E ? XN_E : QP_E) : XN_E + QP_E) * 2 +
                          (size_t)(640 + 3 * HDP + 232 + 256 + 64 * QA_LDB) * sizeof(float) + 128 * sizeof(int);
   static_assert(lds <= 160 * 1024, "qkv_attn: LDS budget");
@@ -475,7 +475,7 @@ int launch_qa(const QkvAttnParams& p, hipStream_t stream) {
 template <int HDT, int KC, int HEADS>
 __global__ __launch_bounds__(512) void ln_qkv_kernel(const LnQkvParams p) {
   constexpr int KG = (KC + 7) / 8;
-  constexpr int LDX = KC * 32 + 8;
+  constexpr int LDX = KC * 32 + 16;
   constexpr int HDP = 16 * HDT;
   constexpr int NV = 3 * HDP;
   constexpr int NS = (NV + 127) / 128;
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(512) void ln_qkv_kernel(const LnQkvParams p) {
 
 template <int HDT, int KC, int HEADS>
 int launch_ln_qkv(const LnQkvParams& p, hipStream_t stream) {
-  constexpr size_t lds = (size_t)64 * (KC * 32 + 8) * 2 + (size_t)(640 + HEADS * 3 * 16 * HDT) * sizeof(float);
+  constexpr size_t lds = (size_t)64 * (KC * 32 + 16) * 2 + (size_t)(640 + HEADS * 3 * 16 * HDT) * sizeof(float);
   auto kern = ln_qkv_kernel<HDT, KC, HEADS>;
   static SradOncePerDevice configured;
   if (configured.need()) {

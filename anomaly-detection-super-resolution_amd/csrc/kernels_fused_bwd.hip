@@ -25,8 +25,8 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-constexpr int FB_LDA = 392;        // LDS row stride of the <=384-wide bf16 dx2 tile
-constexpr int FB_LDH = 520;        // LDS row stride of the <=512-wide bf16 dh tile
+constexpr int FB_LDA = 400;        // LDS row stride of the <=384-wide bf16 dx2 tile
+constexpr int FB_LDH = 528;        // LDS row stride of the <=512-wide bf16 dh tile
 constexpr int FB_SC = 128;         // output columns per weight stage
 
 // d/dx of the exact-erf GELU, Phi(x) + x phi(x), with erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7)
@@ -168,7 +168,7 @@ template <int FM, int GD, int KCD, int GM, int KCM, int KCA, bool HOUT = false>
 __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, float* __restrict__ part) {
   constexpr int KGD = (KCD + 7) / 8, KGM = (KCM + 7) / 8;       // 256-wide k groups
   constexpr int NRT = FM / 16;
-  constexpr int LDAA = KCA * 32 + 8;
+  constexpr int LDAA = KCA * 32 + 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* A1 = reinterpret_cast<__bf16*>(smem);                  // [FM][FB_LDA] dx2
   __bf16* Hs = A1 + FM * FB_LDA;                                 // [FM][FB_LDH] dh
@@ -469,7 +469,7 @@ template <int FM, int GD, int KC, bool YH = false>
 __global__ __launch_bounds__(512) void lin_ln_bwd_kernel(const LinLnBwdParams p, float* __restrict__ part) {
   constexpr int KG = (KC + 7) / 8;                               // KC = exact 32-wide k chunks of K
   constexpr int NRT = FM / 16;
-  constexpr int LDA = KG * 256 + 8;
+  constexpr int LDA = KG * 256 + 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* A1 = reinterpret_cast<__bf16*>(smem);                  // [FM][LDA] dY
   float* v_g = reinterpret_cast<float*>(A1 + FM * LDA);          // [384] gamma
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(512) void lin_ln_bwd_kernel(const LinLnBwdParams p,
 template <int FM, int GD, int KC>
 int launch_lin_fm(const LinLnBwdParams& p, WgradQueue& q, hipStream_t stream) {
   constexpr int KG = (KC + 7) / 8;
-  constexpr size_t lds = (size_t)FM * (KG * 256 + 8) * 2 + (384 + FM * 16) * sizeof(float);
+  constexpr size_t lds = (size_t)FM * (KG * 256 + 16) * 2 + (384 + FM * 16) * sizeof(float);
   auto kern = p.dy_bf16 ? lin_ln_bwd_kernel<FM, GD, KC, true> : lin_ln_bwd_kernel<FM, GD, KC, false>;
   static SradOncePerDevice configured[2];
   if (configured[p.dy_bf16 ? 1 : 0].need()) {
@@ -617,7 +617,7 @@ inline BwdCfg bwd_cfg(int d, int m, int KA) {
 template <int FM, int GD, int KCD, int GM, int KCM, int KCA, bool HOUT = false>
 int launch_bwd_fm(const MlpBwdParams& p, WgradQueue& q, hipStream_t stream) {
   constexpr size_t lds = (size_t)(FM * FB_LDA + FM * FB_LDH) * 2 + (384 + FM * 16) * sizeof(float) +
-                         (KCA > 0 ? (size_t)FM * (KCA * 32 + 8) * 2 : 0);
+                         (KCA > 0 ? (size_t)FM * (KCA * 32 + 16) * 2 : 0);
   auto kern = mlp_bwd_kernel<FM, GD, KCD, GM, KCM, KCA, HOUT>;
   static SradOncePerDevice configured;
   if (configured.need()) {
