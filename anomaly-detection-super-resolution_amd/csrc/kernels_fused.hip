@@ -166,19 +166,7 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
     for (int cc = 0; cc < 8; ++cc) {
       if (cc < nch) {
         const bf16x8 b0 = __builtin_bit_cast(bf16x8, reg[cc]);
-        if constexpr (FULLST) {                                     // W_hi.A_lo, W_lo.A_hi, W_hi.A_hi: each plane read once
-          const bf16x8 bl = __builtin_bit_cast(bf16x8, reg[8 + cc]);
-          const __bf16* al = AL + fr * lda + k0 + 8 * fq;
-#pragma unroll
-          for (int rt = 0; rt < NRT; ++rt) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + rt * 16 * lda + cc * 32);
-            const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(al + rt * 16 * lda + cc * 32);
-            c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a2, c[rt], 0, 0, 0);
-            c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, a, c[rt], 0, 0, 0);
-            c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, c[rt], 0, 0, 0);
-          }
-          continue;
-        }
+        if constexpr (FULLST) continue;                             // (below, with the fragment reads of several chunks in flight)
         if constexpr (SPLIT) {
           if (AL) {
             const __bf16* al = AL + fr * lda + k0 + 8 * fq;
@@ -199,6 +187,37 @@ __global__ __launch_bounds__(512) void mlp_block_kernel(const MlpBlockParams p) 
             c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, c[rt], 0, 0, 0);
           }
         }
+      }
+    }
+    if constexpr (FULLST) {                                         // W_hi.A_lo, W_lo.A_hi, W_hi.A_hi: each plane read once
+      constexpr int G = NRT == 1 ? 4 : (NRT == 2 ? 2 : 1);
+      const __bf16* al = AL + fr * lda + k0 + 8 * fq;
+#pragma unroll
+      for (int cc0 = 0; cc0 < 8; cc0 += G) {
+        bf16x8 af[G][NRT], afl[G][NRT];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          if (cc0 + g < nch) {
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) {
+              af[g][rt] = *reinterpret_cast<const bf16x8*>(ar + rt * 16 * lda + (cc0 + g) * 32);
+              afl[g][rt] = *reinterpret_cast<const bf16x8*>(al + rt * 16 * lda + (cc0 + g) * 32);
+            }
+          }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          if (cc0 + g < nch) {
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, reg[cc0 + g]);
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, reg[8 + cc0 + g]);
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) {
+              c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, afl[g][rt], c[rt], 0, 0, 0);
+              c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, af[g][rt], c[rt], 0, 0, 0);
+              c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, af[g][rt], c[rt], 0, 0, 0);
+            }
+          }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     if constexpr (!SPLIT) {

@@ -281,20 +281,23 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnParams p) {
       const __bf16* ar = XN + fr * QA_LDX + kg * 256 + 8 * fq;
       if constexpr (SPLIT) {
 #pragma unroll
-        for (int cc = 0; cc < nch; ++cc) {
+        for (int cc = 0; cc < nch; ++cc) {                          // one chunk's fragments (both planes with the hi weights) in flight, then its MFMAs
           const bf16x8 b0 = __builtin_bit_cast(bf16x8, reg[cc]);
-          if constexpr (part == 0) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + XN_E + t * 16 * QA_LDX + cc * 32);
-              ac[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, ac[t], 0, 0, 0);
-            }
-          }
+          bf16x8 af[4];
+          [[maybe_unused]] bf16x8 afl[4];
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + t * 16 * QA_LDX + cc * 32);
-            ac[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, ac[t], 0, 0, 0);
+            if constexpr (part == 0) afl[t] = *reinterpret_cast<const bf16x8*>(ar + XN_E + t * 16 * QA_LDX + cc * 32);
+            af[t] = *reinterpret_cast<const bf16x8*>(ar + t * 16 * QA_LDX + cc * 32);
           }
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (part == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ac[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, afl[t], ac[t], 0, 0, 0);
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) ac[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, af[t], ac[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       } else {
         // the window fragments of two chunks are requested together, THEN multiplied (sched_barrier: the scheduler otherwise
