@@ -214,16 +214,26 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdParams p, floa
   };
   auto mma_stage = [&](const __bf16* A, int lda, int k0, int nch, const u32x4 (&reg)[8], f32x4 (&c)[NRT]) {
     const __bf16* ar = A + fr * lda + k0 + 8 * fq;
+    // the fragments of G chunks in flight, THEN their MFMAs (see mlp_block_kernel: the scheduler sinks each read to its use)
+    constexpr int G = NRT == 1 ? 8 : (NRT == 2 ? 4 : 2);
 #pragma unroll
-    for (int cc = 0; cc < 8; ++cc) {
-      if (cc < nch) {
-        const bf16x8 b0 = __builtin_bit_cast(bf16x8, reg[cc]);
+    for (int cc0 = 0; cc0 < 8; cc0 += G) {
+      bf16x8 af[G][NRT];
 #pragma unroll
-        for (int rt = 0; rt < NRT; ++rt) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + rt * 16 * lda + cc * 32);
-          c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, c[rt], 0, 0, 0);
+      for (int g = 0; g < G; ++g)
+        if (cc0 + g < nch) {
+#pragma unroll
+          for (int rt = 0; rt < NRT; ++rt) af[g][rt] = *reinterpret_cast<const bf16x8*>(ar + rt * 16 * lda + (cc0 + g) * 32);
         }
-      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        if (cc0 + g < nch) {
+          const bf16x8 b0 = __builtin_bit_cast(bf16x8, reg[cc0 + g]);
+#pragma unroll
+          for (int rt = 0; rt < NRT; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, af[g][rt], c[rt], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   auto col4_of = [&](int g) { return FB_SC * g + 16 * wave + 4 * fq; };
@@ -563,16 +573,25 @@ __global__ __launch_bounds__(512) void lin_ln_bwd_kernel(const LinLnBwdParams p,
     }
     if ((g * 8 + wave_s) * 16 < d) {
       const __bf16* ar = A1 + fr * LDA + kg * 256 + 8 * fq;
+      constexpr int G = NRT == 1 ? 8 : (NRT == 2 ? 4 : 2);
 #pragma unroll
-      for (int cc = 0; cc < 8; ++cc) {
-        if (cc < nch) {
-          const bf16x8 b0 = __builtin_bit_cast(bf16x8, reg[cc]);
+      for (int cc0 = 0; cc0 < 8; cc0 += G) {
+        bf16x8 af[G][NRT];
 #pragma unroll
-          for (int rt = 0; rt < NRT; ++rt) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + rt * 16 * LDA + cc * 32);
-            c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, c[rt], 0, 0, 0);
+        for (int gg = 0; gg < G; ++gg)
+          if (cc0 + gg < nch) {
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) af[gg][rt] = *reinterpret_cast<const bf16x8*>(ar + rt * 16 * LDA + (cc0 + gg) * 32);
           }
-        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int gg = 0; gg < G; ++gg)
+          if (cc0 + gg < nch) {
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, reg[cc0 + gg]);
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, af[gg][rt], c[rt], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     load_w(std::integral_constant<int, s + NSETS>{}, reg);
