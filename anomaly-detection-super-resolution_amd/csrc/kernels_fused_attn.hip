@@ -585,13 +585,23 @@ __global__ __launch_bounds__(512) void ln_qkv_kernel(const LnQkvParams p) {
     if (live) {
       const __bf16* ar = XN + fr * LDX + kg * 256 + 8 * fq;
 #pragma unroll
-      for (int cc = 0; cc < nch; ++cc) {
-        const bf16x8 b0 = __builtin_bit_cast(bf16x8, reg[cc]);
+      for (int cc0 = 0; cc0 < nch; cc0 += 2) {                     // two chunks' fragments in flight, then their MFMAs (see qkv_attn_kernel)
+        bf16x8 af[2][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(ar + t * 16 * LDX + cc * 32);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, acc[t], 0, 0, 0);
-        }
+        for (int g = 0; g < 2; ++g)
+          if (cc0 + g < nch) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) af[g][t] = *reinterpret_cast<const bf16x8*>(ar + t * 16 * LDX + (cc0 + g) * 32);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+          if (cc0 + g < nch) {
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, reg[cc0 + g]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, af[g][t], acc[t], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     load_w(std::integral_constant<int, sa + NSETS>{}, reg);
