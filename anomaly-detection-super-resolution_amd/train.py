@@ -270,11 +270,13 @@ class GraphedTrainStep:
         return loss.clone()                            # the graph's own output buffer is overwritten by the next replay
 
 
-def drn_loss(sr, lr_list, hr, sr2lr, dual_weight: float = 0.1, loss_fn=None) -> torch.Tensor:
+def drn_loss(sr, lr_list, hr, sr2lr, dual_weight: float = 0.1, loss_fn=None, terms: bool = False):
     """DRN training loss (src/trainer.py:168-185): loss(sr[-1], hr) + sum_j loss(sr[j], lr[j]) over the coarser outputs
     + dual_weight * sum_i loss(dual_i(sr[i - n]), lr[i]).  ``lr_list`` = [LR_x(max), ..., LR_x2] coarse -> fine, as the
     reference loader yields it.  ``loss_fn``: a ``loss.Loss`` (default: the engine's nn.L1Loss reduction); either way the
-    values and the gradients into the SR outputs are the engine's reductions, autograd only chains them."""
+    values and the gradients into the SR outputs are the engine's reductions, autograd only chains them.
+    ``terms=True`` also returns ``loss_primary + loss_dual`` - the sum of every term as the reference's logging ``Loss`` adds them
+    up call by call (the dual terms enter its log unweighted)."""
     if loss_fn is None:
         from .loss import L1Loss
         loss_fn = L1Loss()
@@ -284,11 +286,12 @@ def drn_loss(sr, lr_list, hr, sr2lr, dual_weight: float = 0.1, loss_fn=None) -> 
     loss_dual = loss_fn(sr2lr[0], lr_list[0])
     for i in range(1, len(sr2lr)):
         loss_dual = loss_dual + loss_fn(sr2lr[i], lr_list[i])
-    return loss_primary + dual_weight * loss_dual
+    total = loss_primary + dual_weight * loss_dual
+    return (total, (loss_primary + loss_dual).detach()) if terms else total
 
 
 def drn_train_step(model, dual_models, lr_list, hr, optimizer, dual_optimizers, dual_weight: float = 0.1,
-                   reducer: Optional["GradReducer"] = None, loss_fn=None) -> torch.Tensor:
+                   reducer: Optional["GradReducer"] = None, loss_fn=None, log=None) -> torch.Tensor:
     """One iteration of Trainer.train for DRN-L with its dual regression models (src/trainer.py:161-205): forward of
     the SR net and of every dual model on the matching SR output, the composite loss, backward through the dual models
     into the SR outputs and through the DRN engine, one Adam step for the SR net and one per dual model."""
@@ -297,7 +300,9 @@ def drn_train_step(model, dual_models, lr_list, hr, optimizer, dual_optimizers, 
         o.zero_grad()
     sr = model(lr_list[0])
     sr2lr = [dual_models[i](sr[i - len(dual_models)]) for i in range(len(dual_models))]
-    loss = drn_loss(sr, lr_list, hr, sr2lr, dual_weight, loss_fn)
+    loss, logged = drn_loss(sr, lr_list, hr, sr2lr, dual_weight, loss_fn, terms=True)
+    if log is not None:
+        log.logged = logged                            # (GraphedDrnTrainStep's eager warm-up steps)
     # data parallel: the SR net's buckets (one per level, ``model.grad_buckets``) are all-reduced from the engine's hook while
     # the backward continues (``GradReducer.attach``); a model without buckets is reduced in one piece afterwards
     bucketed = reducer is not None and reducer.world > 1 and bool(getattr(model, "grad_buckets", None))
@@ -331,7 +336,9 @@ class GraphedDrnTrainStep:
     step runs eagerly (collectives are launched from the host inside the backward)."""
 
     def __init__(self, model, dual_models, optimizer: FusedAdam, dual_optimizers, dual_weight: float = 0.1, loss_fn=None,
-                 warmup: int = 2):
+                 warmup: int = 2, reducer: Optional["GradReducer"] = None):
+        self.reducer = reducer if reducer is not None and reducer.world > 1 else None     # data parallel: every step runs eagerly
+        self.logged = None                             # after a call: the value the reference's Loss log adds up for the step
         for o in dual_optimizers:
             if not isinstance(o, TensorAdam):
                 raise TypeError("GraphedDrnTrainStep needs TensorAdam dual optimizers (torch.optim steps read host scalars)")
@@ -351,12 +358,12 @@ class GraphedDrnTrainStep:
             o.zero_grad()
         sr = self.model(lrs[0])
         sr2lr = [self.duals[i](sr[i - len(self.duals)]) for i in range(len(self.duals))]
-        loss = drn_loss(sr, lrs, hr, sr2lr, self.dual_weight, self.loss_fn)
+        loss, logged = drn_loss(sr, lrs, hr, sr2lr, self.dual_weight, self.loss_fn, terms=True)
         loss.backward()
         self.optimizer.step_dev(hypers[0])
         for o, h in zip(self.dual_optimizers, hypers[1:]):
             o.step_dev(h)
-        return loss.detach()
+        return loss.detach(), logged
 
     def __call__(self, lr_list, hr: torch.Tensor) -> torch.Tensor:
         m = self.model
@@ -364,10 +371,11 @@ class GraphedDrnTrainStep:
         entry = self._graphs.get(key)
         if entry is None:
             n = self._eager_calls.get(key, 0)
-            if n < self.warmup or getattr(m, "on_bucket", None) is not None:   # bucket hooks launch collectives from the host: eager
+            if n < self.warmup or self.reducer is not None or getattr(m, "on_bucket", None) is not None:   # bucket hooks launch collectives from the host: eager
                 self._eager_calls[key] = n + 1          # allocates workspaces, configures kernels, creates the side stream
-                return drn_train_step(m, self.duals, lr_list, hr, self.optimizer, self.dual_optimizers, self.dual_weight,
-                                      None, self.loss_fn)
+                value = drn_train_step(m, self.duals, lr_list, hr, self.optimizer, self.dual_optimizers, self.dual_weight,
+                                       self.reducer, self.loss_fn, log=self)
+                return value
             s_lrs = [t.detach().float().contiguous().clone() for t in lr_list]
             s_hr = hr.detach().float().contiguous().clone()
             hypers = [torch.zeros(4, dtype=torch.float32, device=hr.device) for _ in range(1 + len(self.dual_optimizers))]
@@ -375,10 +383,10 @@ class GraphedDrnTrainStep:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                loss = self._body(s_lrs, s_hr, hypers)
-            entry = (g, s_lrs, s_hr, loss, hypers)
+                loss, logged = self._body(s_lrs, s_hr, hypers)
+            entry = (g, s_lrs, s_hr, loss, hypers, logged)
             self._graphs[key] = entry
-        g, s_lrs, s_hr, loss, hypers = entry
+        g, s_lrs, s_hr, loss, hypers, logged = entry
         for a, b in zip(s_lrs, lr_list):
             a.copy_(b, non_blocking=True)
         s_hr.copy_(hr, non_blocking=True)
@@ -389,5 +397,6 @@ class GraphedDrnTrainStep:
         for o in [self.optimizer] + self.dual_optimizers:
             o.step_count += 1
         m.mark_params_dirty()                          # the replayed Adam changed the flat parameters
+        self.logged = logged.clone()                   # what the reference's Loss log adds up for this step (drn_loss, terms=True)
         return loss.clone()
 

@@ -25,7 +25,7 @@ from typing import List
 import torch
 
 from . import metrics as M
-from .train import (FusedAdam, GradReducer, GraphedTrainStep, TensorAdam, cosine_lr, drn_train_step, train_step)
+from .train import (FusedAdam, GradReducer, GraphedDrnTrainStep, GraphedTrainStep, TensorAdam, cosine_lr, drn_train_step, train_step)
 
 
 class timer():
@@ -150,10 +150,14 @@ class Trainer():
             self.reducer = GradReducer().attach(self.net) if self.world > 1 else None
             # one GPU, DRCT, '1*L1': the whole step is one replayed hipGraph per batch shape (opt.train_graph = False keeps the
             # eager launches).  Data-parallel runs stay eager: the bucket hooks launch RCCL all-reduces mid-backward.
-            self.graph_step = (GraphedTrainStep(self.net, self.optimizer) if self.world == 1 and not dual_model
-                               and _plain_l1(my_loss) and getattr(opt, "train_graph", True) else None)
+            graphed = self.world == 1 and _plain_l1(my_loss) and getattr(opt, "train_graph", True)
+            self.graph_step = GraphedTrainStep(self.net, self.optimizer) if graphed and not dual_model else None
+            # DRN-L with its dual models, one GPU, '1*L1': the same, with the composite loss and every Adam inside the graph
+            self.drn_graph_step = (GraphedDrnTrainStep(self.net, self.dual_models, self.optimizer, self.dual_optimizers,
+                                                       getattr(opt, "dual_weight", 0.1))
+                                   if graphed and dual_model and all(isinstance(o, TensorAdam) for o in self.dual_optimizers) else None)
         else:
-            self.optimizer = self.scheduler = self.reducer = self.graph_step = None
+            self.optimizer = self.scheduler = self.reducer = self.graph_step = self.drn_graph_step = None
         self.error_last = 1e8
         self.device = next(self.net.parameters()).device
 
@@ -179,7 +183,11 @@ class Trainer():
             lr, hr = self.prepare(lr, hr)
             timer_data.hold()
             timer_model.tic()
-            if self.dual_model:
+            if self.dual_model and self.drn_graph_step is not None:
+                self.drn_graph_step(lr, hr)
+                if self.loss is not None:
+                    self.loss.note([self.drn_graph_step.logged])     # sum of every term, as the reference's Loss adds them up
+            elif self.dual_model:
                 drn_train_step(self.net, self.dual_models, lr, hr, self.optimizer, self.dual_optimizers,
                                getattr(self.opt, "dual_weight", 0.1), self.reducer, self.loss)
             elif self.graph_step is not None:

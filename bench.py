@@ -443,7 +443,7 @@ def drn_train_leg(args, torch, dev):
     """DRN-L x4 training step at the C3 shape (src/trainer.py:161-205 with dual_model=True): SR net + two dual regression
     models, composite loss, one fused Adam for the SR net and a torch Adam per dual model; batch 8, RGB, 256 px HR."""
     from srad_amd.nets import DRN, DownBlock
-    from srad_amd.train import FusedAdam, TensorAdam, drn_train_step
+    from srad_amd.train import FusedAdam, GraphedDrnTrainStep, TensorAdam, drn_train_step
 
     class DrnOpt:
         n_colors, n_blocks, n_feats, negval, rgb_range, scale = 3, 40, 20, 0.2, 255.0, [2, 4]
@@ -465,11 +465,23 @@ def drn_train_leg(args, torch, dev):
     for _ in range(steps):
         loss = drn_train_step(m, duals, lrs, hr, opt, dopts)
     torch.cuda.synchronize()
+    dt_eager = (time.perf_counter() - t0) / steps
+    # the step as the Trainer runs it on one GPU with '1*L1': one hipGraph per step (train.GraphedDrnTrainStep)
+    gstep = GraphedDrnTrainStep(m, duals, opt, dopts, warmup=1)
+    for _ in range(3):
+        gstep(lrs, hr)
+    torch.cuda.synchronize()
+    steps = 10
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = gstep(lrs, hr)
+    torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     fl = 3.0 * m.flops(B, 64, 64)
     prof = profile_eager(lambda: drn_train_step(m, duals, lrs, hr, opt, dopts), 3)
     out = {"workload": "DRN-L x4 train step (SR net + 2 dual models, composite loss, Adam), RGB, 256 px HR, batch 8",
-           "ms_per_step": round(dt * 1e3, 2), "images_per_s": round(B / dt, 1), "hr_mpixels_per_s": round(B * 256 * 256 / dt / 1e6, 2),
+           "ms_per_step": round(dt * 1e3, 2), "launch": "one hipGraph per step (as the Trainer on one GPU)", "eager_ms_per_step": round(dt_eager * 1e3, 2),
+           "images_per_s": round(B / dt, 1), "hr_mpixels_per_s": round(B * 256 * 256 / dt / 1e6, 2),
            "model_tflops": round(fl / dt / 1e12, 1), "loss": round(float(loss), 4), "kernels": kernel_table(prof, 3),
            "roofline": kernel_roofline(prof, 3, "drn_train", PEAK[args.dtype])}
     del m, duals, opt, dopts
