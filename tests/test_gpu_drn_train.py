@@ -102,7 +102,7 @@ def test_graphed_drn_step_equals_the_eager_steps(prec):
                 else (lambda a, b: drn_train_step(m, dms, a, b, opt, dopts)))
         losses = [float(step([t + 0.5 * i for t in lr_t], hr_t)) for i in range(6)]       # a different batch every step
         if mode == "graph":                 # what the reference's Loss log adds up per step: every term, the dual ones unweighted
-            assert step.logged is not None and float(step.logged) > losses[-1] > 0.9 * float(step.logged) - 1e3
+            assert step.logged is not None and float(step.logged) > losses[-1] > 0
         runs.append((losses, m.flat_params.clone(), [p.detach().clone() for dm in dms for p in dm.parameters()],
                      opt.step_count, [o.step_count for o in dopts]))
     (le, pe, de, se, sde), (lg, pg, dg, sg, sdg) = runs
