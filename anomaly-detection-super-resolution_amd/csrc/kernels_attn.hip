@@ -23,7 +23,10 @@
 namespace {
 
 template <int PREC> struct AT;
-template <> struct AT<SRAD_PREC_BF16> { using type = __bf16; static constexpr int PAD = 8; };
+// PAD (bf16): Q / K / V rows of 16 x odd elements - 2 (mod 4) sixteen-byte units for the lane groups ds_read_b128 is served in
+// (kernels_conv80.hip has the derivation) AND an odd multiple of 32 bytes for the transposing reads of V (two groups of 32
+// lanes, eight consecutive rows x 32 bytes per group = every bank once).  The head tiles are 32 / 64 / 96 / 128 wide: + 16 each.
+template <> struct AT<SRAD_PREC_BF16> { using type = __bf16; static constexpr int PAD = 16; };
 template <> struct AT<SRAD_PREC_F32>  { using type = float;  static constexpr int PAD = 4; };
 
 template <int PREC>
@@ -245,13 +248,15 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
     }
     if constexpr (PREC == SRAD_PREC_BF16) {
 #pragma unroll
-      for (int kk = 0; kk < HDP; kk += 32) {
-        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + (wave * 16 + fr) * HS + kk + 8 * fq);
+      for (int kk = 0; kk < HDP; kk += 32) {                     // a step's five fragments in flight, then its four MFMAs (the scheduler
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + (wave * 16 + fr) * HS + kk + 8 * fq);   // sinks each read to its use otherwise)
+        bf16x8 kf[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (j * 16 + fr) * HS + kk + 8 * fq);
-          s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, s[j], 0, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j) kf[j] = *reinterpret_cast<const bf16x8*>(Ks + (j * 16 + fr) * HS + kk + 8 * fq);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[j], qf, s[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
 #pragma unroll
