@@ -157,6 +157,8 @@ _SIG = {
     "srad_op_layernorm_bwd": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P]),
     "srad_op_window_attn_bwd": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, _P, _P]),
+    "srad_op_conv80_h": (C.c_int, [_P, _P, _P, C.c_int, C.c_float, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_size_t, _P]),
+    "srad_op_wgrad_conv9_h": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "srad_op_wgrad_deferred": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int,
                                          C.c_float, _P, _P, _P, _P]),
     "srad_bench_wgrad_block": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P]),

@@ -39,6 +39,27 @@ int srad_op_gemm(int precision, const float* x, int ldx, int B, int Hi, int Wi, 
   return srad_launch_gemm(precision, p, s);
 }
 
+// The 80 -> 80 channel 3x3 convolution with bf16 operands as DRN's bf16 chains issue it (conv80_kernel<XH, RM>): x_h [B*H*W][80]
+// bf16; output bf16 (y_h) or fp32 (y); residual operand bf16 (r_h) or fp32 (r) or none, rmode as GemmParams (0 add, 2 the
+// LeakyReLU / ReLU mask of a backward); optional per-tile column sums.  Fails if the shape does not take that kernel.
+int srad_op_conv80_h(const void* x_h, const float* w, const float* bias, int act, float slope, const void* r_h, const float* r,
+                     int rmode, int B, int H, int W, void* y_h, float* y, float* pool_part, void* scratch, size_t scratch_bytes,
+                     void* stream) {
+  SRAD_REQUIRE(x_h && w && (y_h || y) && scratch, "op_conv80_h: null argument");
+  const size_t need = srad_packed_bytes(SRAD_PREC_BF16, 80, 80, 9);
+  SRAD_REQUIRE(scratch_bytes >= need, "op_conv80_h: scratch %zu bytes, %zu needed", scratch_bytes, need);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  SRAD_TRY(srad_launch_pack_weight(SRAD_PREC_BF16, w, scratch, 80, 80, 9, s));
+  GemmParams p{};
+  p.Hi = p.Ho = H; p.Wi = p.Wo = W; p.stride = 1;
+  p.Xh = reinterpret_cast<const __bf16*>(x_h); p.ldx = 80; p.M = B * H * W; p.Cin = 80; p.Cp = srad_cp(80); p.ntaps = 9; p.ln_eps = 1e-5f;
+  p.Wp = scratch; p.N = 80; p.bias = bias; p.act = act; p.slope = slope; p.alpha = 1.f;
+  p.R = r; p.Rh = reinterpret_cast<const __bf16*>(r_h); p.ldr = 80; p.rmode = rmode;
+  p.Y = y; p.Yh = reinterpret_cast<__bf16*>(y_h); p.ldy = 80; p.pool_part = pool_part;
+  SRAD_REQUIRE(srad_conv80_supported(SRAD_PREC_BF16, p), "op_conv80_h: this shape does not take the 80-channel conv kernel");
+  return srad_launch_gemm(SRAD_PREC_BF16, p, s);
+}
+
 // Diagnostic: launch the same GEMM `iters` times back to back on `stream` (weights packed once) and
 // return the average device time per launch in microseconds (HIP events; synchronises the stream).
 int srad_bench_gemm(int precision, const float* x, int ldx, int B, int Hi, int Wi, int Cin, const float* w, int N,
@@ -289,6 +310,25 @@ int srad_op_wgrad(int precision, const float* dy, int ldy, const float* x, int l
   q.ws = reinterpret_cast<float*>(workspace);
   q.ws_floats = SRAD_WGRAD_WS_BYTES / sizeof(float);
   SRAD_TRY(srad_launch_wgrad(precision, p, q, reinterpret_cast<hipStream_t>(stream)));
+  return srad_wgrad_flush(q, reinterpret_cast<hipStream_t>(stream));
+}
+
+// Weight / bias gradient of the 80 -> 80 channel 3x3 convolution from bf16 operands (wgrad_conv9_kernel<5, YH, XH>, DRN's bf16
+// chains): dy_h [B*H*W][80] bf16, x either bf16 (x_bf16 = 1) or fp32.  Fails if the shape does not take that kernel.
+int srad_op_wgrad_conv9_h(const void* dy_h, const void* x, int x_bf16, int B, int H, int W, float* dw, float* db, void* workspace,
+                          void* stream) {
+  SRAD_REQUIRE(dy_h && x && dw && workspace, "op_wgrad_conv9_h: null argument");
+  SRAD_REQUIRE(((uintptr_t)workspace & 255) == 0, "op_wgrad_conv9_h: workspace must be 256-byte aligned");
+  WgradParams p{};
+  p.Hi = p.Ho = H; p.Wi = p.Wo = W; p.stride = 1;
+  p.dY = reinterpret_cast<const float*>(dy_h); p.ldy = 80; p.dy_bf16 = 1;
+  p.X = reinterpret_cast<const float*>(x); p.ldx = 80; p.x_bf16 = x_bf16 ? 1 : 0;
+  p.M = B * H * W; p.N = p.Cin = p.n_real = p.cin_real = 80; p.ntaps = 9; p.alpha = 1.f; p.dW = dw; p.db = db;
+  SRAD_REQUIRE(srad_wgrad_conv9_supported(p), "op_wgrad_conv9_h: this shape does not take the nine-tap kernel");
+  WgradQueue q;
+  q.ws = reinterpret_cast<float*>(workspace);
+  q.ws_floats = SRAD_WGRAD_WS_BYTES / sizeof(float);
+  SRAD_TRY(srad_launch_wgrad(SRAD_PREC_BF16, p, q, reinterpret_cast<hipStream_t>(stream)));
   return srad_wgrad_flush(q, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -120,6 +120,42 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, N: int, Cin: int, *, ntaps: int = 1
     return dw, db
 
 
+def conv80_bf16(x_h: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, B: int, H: int, W: int, act: int = 0,
+                slope: float = 0.0, residual: Optional[torch.Tensor] = None, rmode: int = 0, out_bf16: bool = True,
+                pool: bool = False):
+    """The 80 -> 80 channel 3x3 convolution on a bf16 activation array, as DRN's bf16 chains run it (C ABI ``srad_op_conv80_h``):
+    ``x_h`` [B*H*W, 80] bf16 NHWC rows, ``weight`` [80, 80, 3, 3]; ``residual`` bf16 or fp32 [B*H*W, 80] (rmode 0: added; 2: the
+    output is multiplied by (residual > 0 ? 1 : slope)); output bf16 or fp32.  ``pool=True`` also returns the per-tile column
+    sums [B*H*W/128, 80]."""
+    _need_cuda(x_h, weight)
+    assert x_h.dtype == torch.bfloat16 and x_h.is_contiguous() and x_h.shape == (B * H * W, 80)
+    w = weight.detach().reshape(80, 80, 9).float().contiguous()
+    y = torch.empty(B * H * W, 80, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x_h.device)
+    part = torch.empty(B * H * W // 128, 80, dtype=torch.float32, device=x_h.device) if pool else None
+    prec = L.PRECISIONS["bf16"]
+    nbytes = L.lib().srad_op_gemm_scratch_bytes(prec, 80, 80, 9)
+    scratch = torch.empty(nbytes + 256, dtype=torch.uint8, device=x_h.device)
+    sp = C.c_void_p(scratch.data_ptr() + (-scratch.data_ptr()) % 256)
+    r_h = residual if residual is not None and residual.dtype == torch.bfloat16 else None
+    r_f = residual if residual is not None and residual.dtype == torch.float32 else None
+    L.check(L.lib().srad_op_conv80_h(L.dptr(x_h), L.dptr(w), L.dptr(bias), act, slope, L.dptr(r_h), L.dptr(r_f), rmode, B, H, W,
+                                     L.dptr(y) if out_bf16 else None, None if out_bf16 else L.dptr(y), L.dptr(part), sp, nbytes,
+                                     L.current_stream_ptr()), "op_conv80_h")
+    return (y, part) if pool else y
+
+
+def wgrad_conv9_bf16(dy_h: torch.Tensor, x: torch.Tensor, *, B: int, H: int, W: int):
+    """Weight / bias gradient of that convolution from a bf16 dY and a bf16 or fp32 X (C ABI ``srad_op_wgrad_conv9_h``):
+    returns (dW [80, 80, 9], db [80])."""
+    _need_cuda(dy_h, x)
+    assert dy_h.dtype == torch.bfloat16 and dy_h.is_contiguous() and x.is_contiguous() and dy_h.shape == x.shape == (B * H * W, 80)
+    dw = torch.zeros(80, 80, 9, dtype=torch.float32, device=x.device)
+    db = torch.zeros(80, dtype=torch.float32, device=x.device)
+    L.check(L.lib().srad_op_wgrad_conv9_h(L.dptr(dy_h), L.dptr(x), int(x.dtype == torch.bfloat16), B, H, W, L.dptr(dw), L.dptr(db),
+                                          wgrad_workspace(x.device), L.current_stream_ptr()), "op_wgrad_conv9_h")
+    return dw, db
+
+
 def dgrad(dy: torch.Tensor, weight: torch.Tensor, *, B: int = 1, H: int = 0, W: int = 0, r: Optional[torch.Tensor] = None,
           rmode: int = 0, slope: float = 0.0, alpha: float = 1.0, row_scale: Optional[torch.Tensor] = None,
           precision: str = "fp32") -> torch.Tensor:

@@ -279,6 +279,18 @@ int srad_op_window_attn_bf16_in(const void* qkv_h, float* out, const float* tabl
 int srad_op_wgrad(int precision, const float* dy, int ldy, const float* x, int ldx, int B, int Hi, int Wi, int N,
                   int Cin, int ntaps, int stride, const float* row_scale, float alpha, float* dw, float* db,
                   void* workspace, void* stream);
+/* The 80 -> 80 channel 3x3 convolution (src/drn.py:143-158, RCAB) with bf16 operands, as DRN's bf16 chains issue it in the
+ * forward and as the data gradient of the backward: x_h [B*H*W][80] bf16; w [80][80][3][3] fp32; output bf16 (y_h) or fp32 (y);
+ * residual operand bf16 (r_h) or fp32 (r) or neither; rmode 0 = add, 2 = multiply by (r > 0 ? 1 : slope) (backward through
+ * ReLU / LeakyReLU); pool_part (optional): [B*H*W/128][80] column sums per 128-pixel tile.  H % 4 == 0, W % 32 == 0,
+ * B*H*W >= 8192; scratch >= srad_op_gemm_scratch_bytes(SRAD_PRECISION_BF16, 80, 80, 9). */
+int srad_op_conv80_h(const void* x_h, const float* w, const float* bias, int act, float slope, const void* r_h, const float* r,
+                     int rmode, int B, int H, int W, void* y_h, float* y, float* pool_part, void* scratch, size_t scratch_bytes,
+                     void* stream);
+/* Its weight / bias gradient from a bf16 dY and a bf16 (x_bf16 = 1) or fp32 X: dw [80][80][3][3], db [80] accumulated;
+ * workspace as for srad_op_wgrad.  W % 32 == 0, B*H*W >= 8192. */
+int srad_op_wgrad_conv9_h(const void* dy_h, const void* x, int x_bf16, int B, int H, int W, float* dw, float* db, void* workspace,
+                          void* stream);
 /* The same for a Linear layer, issued as the training step issues it (queued, one deferred launch, reduce).  x_bf16 /
  * dy_bf16 = 1: that operand is a bf16 array (ld in elements; a bf16 dY is taken as already multiplied by its per-sample
  * factor, so row_scale must be null with it, and it needs a bf16 X).  precision SRAD_PREC_BF16 for bf16 operands. */

@@ -99,6 +99,65 @@ def test_conv3x3_80_channels_weight_resident_kernel(dev, B, H, W, mode):
     assert _rel(y, ref) < 1e-4
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (8, 128, 128), (3, 64, 96)])
+@pytest.mark.parametrize("mode", ["relu_h", "mask_h", "add_f32", "pool_h"])
+def test_conv80_bf16_operands(dev, B, H, W, mode):
+    """conv80_kernel<XH, RM> as DRN's bf16 chains issue it (round 3): bf16 input array, bf16 or fp32 output, the residual
+    operand none / a bf16 ReLU mask (backward through the ReLU: out * (t > 0)) / an fp32 addend (the skip path of the data
+    gradient), the per-tile column sums taken from the fp32 values - against torch's conv2d on the same bf16 operands.  A bf16
+    output may differ from the rounded reference by one bf16 ulp (the summation order differs): 2^-7 relative."""
+    from srad_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(7 * B + H + W)
+    x_h = torch.randn(B * H * W, 80, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(80, 80, 3, 3, generator=g) / math.sqrt(720)).to(torch.bfloat16).float().to(dev)
+    b = torch.randn(80, generator=g).to(dev)
+    x = x_h.float().reshape(B, H, W, 80).permute(0, 3, 1, 2)
+    conv = F.conv2d(x, w, b, padding=1).permute(0, 2, 3, 1).reshape(-1, 80)
+    if mode == "relu_h":
+        y = ops.conv80_bf16(x_h, w, b, B=B, H=H, W=W, act=3)
+        ref = F.relu(conv)
+    elif mode == "mask_h":
+        t_h = torch.randn(B * H * W, 80, generator=g).to(torch.bfloat16).to(dev)
+        t_h[::7] = 0                                                     # exact zeros: the mask is (t > 0), not (t >= 0)
+        y = ops.conv80_bf16(x_h, w, None, B=B, H=H, W=W, residual=t_h, rmode=2, slope=0.0)
+        ref = (conv - b) * (t_h.float() > 0)
+    elif mode == "add_f32":
+        r = torch.randn(B * H * W, 80, generator=g).to(dev)
+        y = ops.conv80_bf16(x_h, w, None, B=B, H=H, W=W, residual=r, rmode=0, out_bf16=False)
+        ref = conv - b + r
+        assert y.dtype == torch.float32 and _rel(y, ref) < 1e-4
+        return
+    else:
+        y, part = ops.conv80_bf16(x_h, w, b, B=B, H=H, W=W, pool=True)
+        ref = conv
+        tiles = conv.reshape(B, H // 4, 4, W // 32, 32, 80).sum((2, 4)).reshape(-1, 80)    # 4 x 32-pixel tiles, row-major per image
+        assert _rel(part, tiles) < 1e-4
+    assert y.dtype == torch.bfloat16
+    assert float((y.float() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    assert _rel(y.float(), ref) < 4e-3
+
+
+@pytest.mark.parametrize("B,H,W,x_bf16", [(2, 64, 64, True), (8, 128, 128, True), (2, 64, 96, False)])
+def test_wgrad_conv9_bf16_operands(dev, B, H, W, x_bf16):
+    """wgrad_conv9_kernel<5, YH, XH> (round 3): the nine-tap weight gradient of the 80 -> 80 convolution from a bf16 dY and a bf16
+    or fp32 X - the same numbers as the fp32-operand kernel on the bf16-rounded tensors (the MFMA operands are those bf16 values
+    either way), and against torch."""
+    from srad_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(B + H + W)
+    dy_h = torch.randn(B * H * W, 80, generator=g).to(torch.bfloat16).to(dev)
+    xx = torch.randn(B * H * W, 80, generator=g)
+    x = (xx.to(torch.bfloat16) if x_bf16 else xx).to(dev)
+    dw, db = ops.wgrad_conv9_bf16(dy_h, x, B=B, H=H, W=W)
+    dw0, db0 = ops.wgrad(dy_h.float(), x.float().to(torch.bfloat16).float(), 80, 80, ntaps=9, B=B, H=H, W=W, precision="bf16")
+    assert _rel(dw, dw0) < 1e-5 and _rel(db, db0) < 1e-5
+    xt = x.float().to(torch.bfloat16).float().reshape(B, H, W, 80).permute(0, 3, 1, 2).requires_grad_(False)
+    wt = torch.zeros(80, 80, 3, 3, device=dev, requires_grad=True)
+    out = F.conv2d(xt, wt, None, padding=1)
+    out.backward(dy_h.float().reshape(B, H, W, 80).permute(0, 3, 1, 2))
+    assert _rel(dw.reshape(80, 80, 3, 3), wt.grad) < 1e-4
+    assert _rel(db, dy_h.float().sum(0)) < 1e-5
+
+
 def test_conv80_eligible_shape_with_gelu_is_not_sent_to_the_weight_resident_kernel(dev):
     """conv80's epilogue implements none / ReLU / LeakyReLU; an 80 -> 80 3x3 convolution with another activation at a
     conv80-eligible shape must take the tiled GEMM (which applies GELU) instead of silently dropping the activation."""
