@@ -28,6 +28,9 @@ template <int PREC> struct AT;
 // lanes, eight consecutive rows x 32 bytes per group = every bank once).  The head tiles are 32 / 64 / 96 / 128 wide: + 16 each.
 template <> struct AT<SRAD_PREC_BF16> { using type = __bf16; static constexpr int PAD = 16; };
 template <> struct AT<SRAD_PREC_F32>  { using type = float;  static constexpr int PAD = 4; };
+// split-bf16 (SRAD_PREC_BF16X3): Q, K, V tiles as a hi and a lo bf16 plane each (the lo planes behind the three hi tiles), the
+// probabilities split in registers, every product three bf16 MFMAs (hi.hi + hi.lo + lo.hi).  Input fp32 (head-padded), output fp32.
+template <> struct AT<SRAD_PREC_BF16X3> { using type = __bf16; static constexpr int PAD = 16; };
 
 template <int PREC>
 __device__ __forceinline__ void store4(typename AT<PREC>::type* dst, f32x4 v) {
@@ -57,6 +60,7 @@ __device__ __forceinline__ void store4(typename AT<PREC>::type* dst, f32x4 v) {
 template <int PREC, int NT_O, bool TBL_LDS, int NW, bool FULL, bool ROW64 = false, bool QH = false>
 __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p) {
   static_assert(!QH || (ROW64 && PREC == SRAD_PREC_BF16), "bf16 input: the one-row-per-chunk bf16 path only");
+  static_assert(!ROW64 || PREC != SRAD_PREC_F32, "the one-row-per-chunk path stages bf16 tiles");
   using T = typename AT<PREC>::type;
   constexpr int PAD = AT<PREC>::PAD;
   constexpr int HDP = NT_O * 16;
@@ -71,7 +75,9 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
   T* Qs = reinterpret_cast<T*>(smem);
   T* Ks = Qs + BQ * HS;
   T* Vs = Ks + 64 * HS;
-  int* tokq = reinterpret_cast<int*>(Vs + 64 * HS);
+  constexpr bool X3 = PREC == SRAD_PREC_BF16X3;
+  constexpr int LOFF = (BQ + 128) * HS;                  // lo plane of a tile = its hi plane + LOFF elements (split-bf16)
+  int* tokq = reinterpret_cast<int*>(Vs + 64 * HS + (X3 ? LOFF : 0));
   int* infq = tokq + BQ;             // packed (region << 24) | (py * (2 ws - 1) + px)
   int* tokk = infq + BQ;             // [3][64]: key chunks kc, kc + 1 (loads in flight), kc + 2 (being computed)
   int* infk = tokk + 3 * 64;         // [3][64]
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
   const float scale = rsqrtf((float)hd) * (ROW64 ? LOG2E : 1.0f);
   const int tw = 2 * ws - 1;
 
-  auto fexp = [](float x) -> float {     // bf16 mode: v_exp_f32 (2 ulp); fp32 (parity) mode: libm expf
+  auto fexp = [](float x) -> float {     // bf16 mode: v_exp_f32 (2 ulp); fp32 / split-bf16 (parity) modes: libm expf
     if constexpr (PREC == SRAD_PREC_BF16) return __expf(x); else return expf(x);
   };
   auto token_info = [&](int pos, int& tok, int& inf) {
@@ -176,7 +182,14 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
       f32x4 v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = (rok && c + e < hd) ? src[i][e] * mul : ((ones_col && c + e == hd) ? 1.0f : 0.f);
-      store4<PREC>(base + row * HS + c, v);
+      if constexpr (X3) {
+        bf16x4 hh, ll;
+        srad_split4(v, hh, ll);
+        *reinterpret_cast<bf16x4*>(base + row * HS + c) = hh;
+        *reinterpret_cast<bf16x4*>(base + LOFF + row * HS + c) = ll;
+      } else {
+        store4<PREC>(base + row * HS + c, v);
+      }
       }
     }
   };
@@ -246,7 +259,27 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
 #pragma unroll
       for (int j = 0; j < 4; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if constexpr (PREC == SRAD_PREC_BF16) {
+    if constexpr (X3) {
+#pragma unroll
+      for (int kk = 0; kk < HDP; kk += 32) {                     // small terms first: k_hi.q_lo, k_lo.q_hi, then k_hi.q_hi
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + (wave * 16 + fr) * HS + kk + 8 * fq);
+        const bf16x8 ql = *reinterpret_cast<const bf16x8*>(Qs + LOFF + (wave * 16 + fr) * HS + kk + 8 * fq);
+        bf16x8 kf[4], kl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          kf[j] = *reinterpret_cast<const bf16x8*>(Ks + (j * 16 + fr) * HS + kk + 8 * fq);
+          kl[j] = *reinterpret_cast<const bf16x8*>(Ks + LOFF + (j * 16 + fr) * HS + kk + 8 * fq);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[j], ql, s[j], 0, 0, 0);
+          s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl[j], qf, s[j], 0, 0, 0);
+          s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[j], qf, s[j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if constexpr (PREC == SRAD_PREC_BF16) {
 #pragma unroll
       for (int kk = 0; kk < HDP; kk += 32) {                     // a step's five fragments in flight, then its four MFMAs (the scheduler
         const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + (wave * 16 + fr) * HS + kk + 8 * fq);   // sinks each read to its use otherwise)
@@ -322,7 +355,7 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
     for (int j = 0; j < NT_O; ++j) o[j] *= alpha;
 
     // ---- O^T += V^T P^T: o[ct][e] = out(channel 16 ct + 4 fq + e, query wave * 16 + fr) ----
-    if constexpr (PREC == SRAD_PREC_BF16) {
+    if constexpr (PREC != SRAD_PREC_F32) {
       // k slot (fq, t) of a 32-key step stands for key 32 ks + 4 fq + t (t < 4) or 32 ks + 16 + 4 fq + t - 4: exactly the
       // keys whose probabilities this lane holds in s[2 ks] and s[2 ks + 1].  V^T comes from the row-major V tile through
       // two transposing reads: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4x16 block and
@@ -331,8 +364,15 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 pb;
+        [[maybe_unused]] bf16x8 pl;                              // split-bf16: the probabilities' lo terms
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { pb[e] = (__bf16)s[2 * ks][e]; pb[4 + e] = (__bf16)s[2 * ks + 1][e]; }
+        for (int e = 0; e < 4; ++e) {
+          pb[e] = (__bf16)s[2 * ks][e]; pb[4 + e] = (__bf16)s[2 * ks + 1][e];
+          if constexpr (X3) {
+            pl[e] = (__bf16)(s[2 * ks][e] - (float)pb[e]);
+            pl[4 + e] = (__bf16)(s[2 * ks + 1][e] - (float)pb[4 + e]);
+          }
+        }
 #pragma unroll
         for (int j = 0; j < NT_O; ++j) {
           typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -342,6 +382,15 @@ __global__ __launch_bounds__(NW * 64) void window_attn_kernel(const AttnParams p
           bf16x8 vf;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+          if constexpr (X3) {
+            const bf16x4 llo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0 + LOFF));
+            const bf16x4 lhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(r0 + LOFF + 16 * HS));
+            bf16x8 vl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { vl[e] = llo[e]; vl[4 + e] = lhi[e]; }
+            o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, pb, o[j], 0, 0, 0);
+            o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pl, o[j], 0, 0, 0);
+          }
           o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb, o[j], 0, 0, 0);
         }
       }
@@ -406,7 +455,8 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
   constexpr int HDP = NT_O * 16, HS = HDP + PAD, BQ = NW * 16;
   const int N = p.ws * p.ws;
   const int tw = 2 * p.ws - 1;
-  size_t base = (size_t)((BQ + 128) * HS) * sizeof(T) + (2 * BQ + 6 * 64) * sizeof(int);
+  constexpr int PLANES = PREC == SRAD_PREC_BF16X3 ? 2 : 1;
+  size_t base = (size_t)((BQ + 128) * HS) * sizeof(T) * PLANES + (2 * BQ + 6 * 64) * sizeof(int);
   base = srad_align_up(base, 16);
   const int tbl_in_lds = (base + (size_t)tw * tw * 4) <= 150 * 1024 ? 1 : 0;
   size_t lds = base + (tbl_in_lds ? (size_t)tw * tw * 4 : 0);
@@ -414,14 +464,20 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
   auto kern = tbl_in_lds ? (full ? window_attn_kernel<PREC, NT_O, true, NW, true> : window_attn_kernel<PREC, NT_O, true, NW, false>)
                          : (full ? window_attn_kernel<PREC, NT_O, false, NW, true> : window_attn_kernel<PREC, NT_O, false, NW, false>);
   // 64 x 64 windows with a shift of 0 or 32 (what DRCT builds: window_size // 2): the one-row-per-chunk path
-  const bool row64 = PREC == SRAD_PREC_BF16 && NW == 8 && p.ws == 64 && tbl_in_lds && (p.shift == 0 || p.shift == 32) &&
-                     getenv("SRAD_NO_ROW64") == nullptr;
+  const bool row64 = PREC != SRAD_PREC_F32 && NW == 8 && p.ws == 64 && base + (size_t)4 * 128 * 4 <= 158 * 1024 &&
+                     (p.shift == 0 || p.shift == 32) && getenv("SRAD_NO_ROW64") == nullptr;
   SRAD_REQUIRE(!p.qkv_h || (row64 && (p.d / p.heads) % 4 != 0 && ((uintptr_t)p.qkv_h & 7) == 0),
                "window_attn: bf16 q | k | v are for the 64 x 64-window bf16 path (srad_window_attn_bf16_in)");
   if constexpr (PREC == SRAD_PREC_BF16 && NW == 8) {
     if (row64) {
       kern = p.qkv_h ? window_attn_kernel<PREC, NT_O, true, NW, true, true, true> : window_attn_kernel<PREC, NT_O, true, NW, true, true>;
       lds = base + (size_t)4 * 128 * 4;            // a four-row ring of the bias table
+    }
+  }
+  if constexpr (PREC == SRAD_PREC_BF16X3 && NW == 8) {
+    if (row64) {
+      kern = window_attn_kernel<PREC, NT_O, true, NW, true, true>;
+      lds = base + (size_t)4 * 128 * 4;
     }
   }
   static size_t configured_dev[16][6] = {};          // per device (hipFuncSetAttribute applies to the current one)
@@ -444,10 +500,14 @@ template <int PREC, int NT_O>
 int launch_attn_nw(const AttnParams& p, hipStream_t stream) {
   using T = typename AT<PREC>::type;
   constexpr int HS = NT_O * 16 + AT<PREC>::PAD;
+  constexpr int PLANES = PREC == SRAD_PREC_BF16X3 ? 2 : 1;
   // 128-query workgroups when the window has that many tokens and their tiles + the bias table fit in LDS
   const int tw = 2 * p.ws - 1;
-  const size_t lds8 = (size_t)((128 + 128) * HS) * sizeof(T) + (2 * 128 + 6 * 64) * sizeof(int) + 16 + (size_t)tw * tw * 4;
-  if (p.ws * p.ws >= 128 && lds8 <= 150 * 1024) return launch_attn<PREC, NT_O, 8>(p, stream);
+  const size_t base8 = (size_t)((128 + 128) * HS) * sizeof(T) * PLANES + (2 * 128 + 6 * 64) * sizeof(int) + 16;
+  const size_t lds8 = base8 + (size_t)tw * tw * 4;
+  // (64 x 64 windows keep a four-row ring of the table, not the table: launch_attn's one-row-per-chunk path)
+  const bool ring = PREC != SRAD_PREC_F32 && p.ws == 64 && (p.shift == 0 || p.shift == 32) && base8 + 2048 <= 158 * 1024;
+  if (p.ws * p.ws >= 128 && (lds8 <= 150 * 1024 || ring)) return launch_attn<PREC, NT_O, 8>(p, stream);
   return launch_attn<PREC, NT_O, 4>(p, stream);
 }
 
@@ -479,5 +539,9 @@ int srad_launch_window_attn(int prec, const AttnParams& p, hipStream_t stream) {
   SRAD_REQUIRE(p.shift >= 0 && p.shift < p.ws, "window_attn: shift %d must be in [0, ws)", p.shift);
   SRAD_REQUIRE(p.hdp >= p.d / p.heads && p.hdp % 4 == 0 && (p.qkv_h || ((uintptr_t)p.qkv & 15) == 0),
                "window_attn: head-padded layout needs hdp %% 4 == 0 and hdp >= head_dim (hdp=%d)", p.hdp);
+  if (prec == SRAD_PREC_BF16X3) {
+    SRAD_REQUIRE(!p.qkv_h && !p.out_h && p.out, "window_attn (split-bf16): fp32 q | k | v in, fp32 out");
+    return launch_attn_prec<SRAD_PREC_BF16X3>(p, stream);
+  }
   return prec == SRAD_PREC_BF16 ? launch_attn_prec<SRAD_PREC_BF16>(p, stream) : launch_attn_prec<SRAD_PREC_F32>(p, stream);
 }

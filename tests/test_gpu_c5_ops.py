@@ -126,6 +126,37 @@ def test_window64_attention_kernel_matches_oracle(d, heads, shift):
     assert e2e < 6e-3, e2e
 
 
+@pytest.mark.parametrize("d,heads", [(180, 6), (244, 2), (308, 4)])
+@pytest.mark.parametrize("shift", [0, 32])
+def test_window64_attention_split_bf16_matches_the_plain_fp32_oracle(d, heads, shift):
+    """The split-bf16 instance of the window attention kernel (round 3: Q, K, V tiles as hi + lo bf16 planes, probabilities split in
+    registers, three bf16 MFMAs per product, the one-row-per-chunk path with the bias ring) at 64 x 64 windows against the PLAIN
+    fp32 oracle - no rounding hook: bar 2e-4 of the output's max (the bf16 kernel needs the hook and 2e-3)."""
+    ws, H, W = 64, 128, 128
+    hd = d // heads
+    g = torch.Generator().manual_seed(5 * d + shift)
+    qkv = torch.randn(H * W, 3 * d, generator=g)
+    qkv[:, :2 * d] *= 1.3
+    table = torch.randn(127 * 127, heads, generator=g) * 0.5
+    out = ops.window_attention(qkv.cuda(), table.cuda(), 1, H, W, ws, shift, heads, precision="bf16x3").cpu()
+    with torch.no_grad():
+        t = qkv.view(1, H, W, 3 * d)
+        if shift:
+            t = torch.roll(t, (-shift, -shift), (1, 2))
+        tw = R.window_partition(t, ws).view(-1, ws * ws, 3, heads, hd).permute(2, 0, 3, 1, 4)
+        mask = R.calculate_mask(H, W, ws, shift) if shift else None
+        outs = [R.attention_from_qkv(tw[0][i:i + 1] * hd ** -0.5, tw[1][i:i + 1], tw[2][i:i + 1], table, ws,
+                                     None if mask is None else mask[i:i + 1]) for i in range(tw.shape[1])]
+        o = torch.cat(outs).transpose(1, 2).reshape(-1, ws, ws, d)
+        o = R.window_reverse(o, ws, H, W)
+        if shift:
+            o = torch.roll(o, (shift, shift), (1, 2))
+        ref = o.reshape(H * W, d)
+    e = float((out - ref).abs().max() / ref.abs().max())
+    print(f"split-bf16 window-64 attention d={d} heads={heads} shift={shift}: rel err {e:.2e} vs the plain fp32 oracle")
+    assert not torch.isnan(out).any() and e < 2e-4, e
+
+
 def test_window64_attention_check_is_sensitive_to_a_bias_row_and_to_the_mask():
     """One ROW of the 127 x 127 relative-position table off (what a wrong ring slot would read), or the shift mask ignored, must
     fail the same comparison by >= 5x the bar."""
