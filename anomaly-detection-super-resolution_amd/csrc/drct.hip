@@ -118,6 +118,14 @@ int forward_body(srad_drct* h, const float* x, int B, int H, int W, float* y, co
           q.w_qkv = h->pt.frag_ptr(sw.qkv.w); q.b_qkv = h->pt.fptr(sw.qkv.b);
           q.qkv_h = reinterpret_cast<__bf16*>(w.qkv); q.hdp = hdp_of(d, sw.heads); q.qscale = qscale;
           SRAD_TRY(srad_launch_ln_qkv(q, s));
+        } else if (x3 && c.window_size == 64 && h->pt.frag_ptr(sw.qkv.w) && h->pt.frag_lo_ptr(sw.qkv.w) && srad_ln_qkv_supported(prec, T, d, sw.heads) &&
+                   getenv("SRAD_NO_LN_QKV") == nullptr) {
+          // split-bf16: the same launch with hi + lo planes and packs, fp32 q | k | v out (the split attention kernel scales and splits them)
+          LnQkvParams q{};
+          q.x = cur; q.ldx = D; q.M = T; q.d = d; q.heads = sw.heads; q.ln_g = h->pt.fptr(sw.n1g); q.ln_b = h->pt.fptr(sw.n1b);
+          q.w_qkv = h->pt.frag_ptr(sw.qkv.w); q.w_qkv_lo = h->pt.frag_lo_ptr(sw.qkv.w); q.b_qkv = h->pt.fptr(sw.qkv.b);
+          q.qkv_f = w.qkv; q.hdp = hdp_of(d, sw.heads); q.qscale = 1.f;
+          SRAD_TRY(srad_launch_ln_qkv(q, s));
         } else {
           const int hdp = hdp_of(d, sw.heads);
           GemmParams p = base_gemm(h, sw.qkv, cur, D, T, w.qkv, 3 * sw.heads * hdp);

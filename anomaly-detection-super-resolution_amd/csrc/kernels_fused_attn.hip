@@ -475,7 +475,9 @@ int launch_qa(const QkvAttnParams& p, hipStream_t stream) {
 // whole 3 d x d weight, where the tiled GEMM launched one 64 x 64 tile per workgroup, each re-reading and re-normalising
 // its rows for 1.5 MFLOP (130 TFLOP/s at this size).
 // ------------------------------------------------------------------------------------------
-template <int HDT, int KC, int HEADS>
+// SPLIT (split-bf16): the normalised rows as a hi and a lo bf16 plane, the weights streamed twice (hi pack against both planes, lo
+// pack against the hi plane), fp32 output (LnQkvParams::qkv_f).
+template <int HDT, int KC, int HEADS, bool SPLIT = false>
 __global__ __launch_bounds__(512) void ln_qkv_kernel(const LnQkvParams p) {
   constexpr int KG = (KC + 7) / 8;
   constexpr int LDX = KC * 32 + 16;
@@ -484,9 +486,12 @@ __global__ __launch_bounds__(512) void ln_qkv_kernel(const LnQkvParams p) {
   constexpr int NS = (NV + 127) / 128;
   constexpr int n_stages = NS * KG;                              // per head
   constexpr int n_all = HEADS * n_stages;
+  constexpr int NPART = SPLIT ? 2 : 1;                           // weight streams per stage (hi | hi, lo)
+  constexpr int n_vall = n_all * NPART;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* XN = reinterpret_cast<__bf16*>(smem);                 // [64][LDX]
-  float* v_g = reinterpret_cast<float*>(XN + 64 * LDX);         // [320] gamma
+  [[maybe_unused]] __bf16* XNL = XN + 64 * LDX;                 // split-bf16: the lo plane
+  float* v_g = reinterpret_cast<float*>(XN + (SPLIT ? 2 : 1) * 64 * LDX);   // [320] gamma
   float* v_b = v_g + 320;                                       // [320] beta
   float* v_bias = v_b + 320;                                    // [HEADS][3][HDP] bias (0 in padding)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -501,11 +506,12 @@ __global__ __launch_bounds__(512) void ln_qkv_kernel(const LnQkvParams p) {
   constexpr int NSETS = 3;
   u32x4 w_reg[NSETS][8];
   auto load_w = [&](auto S, u32x4 (&reg)[8]) __attribute__((always_inline)) {
-    constexpr int sa = decltype(S)::value < n_all - 1 ? decltype(S)::value : n_all - 1;
+    constexpr int va = decltype(S)::value < n_vall - 1 ? decltype(S)::value : n_vall - 1;
+    constexpr int sa = va / NPART;
     constexpr int hh = sa / n_stages, sc = sa - hh * n_stages;
     constexpr int st = sc / KG, kg = sc - st * KG;
     constexpr int nch = KC - kg * 8 < 8 ? KC - kg * 8 : 8;
-    const char* const Wh = reinterpret_cast<const char*>(p.w_qkv) + (size_t)hh * (NV / 16) * KC * 1024;
+    const char* const Wh = reinterpret_cast<const char*>((va % NPART) == 1 ? p.w_qkv_lo : p.w_qkv) + (size_t)hh * (NV / 16) * KC * 1024;
     const bool live = (st * 8 + wave_s) * 16 < NV;
     const char* base = live ? Wh + ((size_t)(st * 8 + wave) * KC + kg * 8) * 1024 + fr * 64 + fq * 16 : Wh;
     const int step = live ? 1024 : 0;
@@ -561,7 +567,13 @@ __global__ __launch_bounds__(512) void ln_qkv_kernel(const LnQkvParams p) {
       const f32x4 b4 = *reinterpret_cast<const f32x4*>(v_b + min(c, 316));
       const f32x4 v = c < d ? (a_reg[j] - mu) * rstd * g4 + b4 : f32x4{0.f, 0.f, 0.f, 0.f};
       bf16x4 hh;
-      hh[0] = (__bf16)v[0]; hh[1] = (__bf16)v[1]; hh[2] = (__bf16)v[2]; hh[3] = (__bf16)v[3];
+      if constexpr (SPLIT) {
+        bf16x4 ll;
+        srad_split4(v, hh, ll);
+        *reinterpret_cast<bf16x4*>(XNL + xrow * LDX + c) = ll;
+      } else {
+        hh[0] = (__bf16)v[0]; hh[1] = (__bf16)v[1]; hh[2] = (__bf16)v[2]; hh[3] = (__bf16)v[3];
+      }
       *reinterpret_cast<bf16x4*>(XN + xrow * LDX + c) = hh;
     }
   }
@@ -571,14 +583,15 @@ __global__ __launch_bounds__(512) void ln_qkv_kernel(const LnQkvParams p) {
   // q|k|v = xn . W^T, head after head: 128 virtual columns per stage, transposed result (lane: token fr of row tile t, 4 columns)
   f32x4 acc[4];
   const int ldq = 3 * HEADS * hdp;
-  static_for<0, n_all>([&](auto S) {
-    constexpr int sa = decltype(S)::value;
+  static_for<0, n_vall>([&](auto S) {
+    constexpr int va = decltype(S)::value;
+    constexpr int sa = va / NPART, part = va % NPART;               // split-bf16: part 0 = hi weights, 1 = lo weights
     constexpr int hh = sa / n_stages, s = sa - hh * n_stages;
     constexpr int st = s / KG, kg = s - st * KG;
-    u32x4 (&reg)[8] = w_reg[sa % NSETS];
+    u32x4 (&reg)[8] = w_reg[va % NSETS];
     constexpr int nch = KC - kg * 8 < 8 ? KC - kg * 8 : 8;
     const bool live = (st * 8 + wave_s) * 16 < NV;
-    if constexpr (kg == 0) {
+    if constexpr (kg == 0 && part == 0) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -587,25 +600,33 @@ __global__ __launch_bounds__(512) void ln_qkv_kernel(const LnQkvParams p) {
 #pragma unroll
       for (int cc0 = 0; cc0 < nch; cc0 += 2) {                     // two chunks' fragments in flight, then their MFMAs (see qkv_attn_kernel)
         bf16x8 af[2][4];
+        [[maybe_unused]] bf16x8 afl[2][4];
 #pragma unroll
         for (int g = 0; g < 2; ++g)
           if (cc0 + g < nch) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) af[g][t] = *reinterpret_cast<const bf16x8*>(ar + t * 16 * LDX + (cc0 + g) * 32);
+            for (int t = 0; t < 4; ++t) {
+              af[g][t] = *reinterpret_cast<const bf16x8*>(ar + t * 16 * LDX + (cc0 + g) * 32);
+              if constexpr (SPLIT && part == 0) afl[g][t] = *reinterpret_cast<const bf16x8*>(ar + 64 * LDX + t * 16 * LDX + (cc0 + g) * 32);
+            }
           }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 2; ++g)
           if (cc0 + g < nch) {
             const bf16x8 b0 = __builtin_bit_cast(bf16x8, reg[cc0 + g]);
+            if constexpr (SPLIT && part == 0) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, afl[g][t], acc[t], 0, 0, 0);
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, af[g][t], acc[t], 0, 0, 0);
           }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    load_w(std::integral_constant<int, sa + NSETS>{}, reg);
-    if constexpr (kg == KG - 1) {
+    load_w(std::integral_constant<int, va + NSETS>{}, reg);
+    if constexpr (kg == KG - 1 && part == NPART - 1) {
       if (live) {
         const int vc = (st * 8 + wave) * 16 + 4 * fq;             // virtual column of element 0
         const int which = vc / HDP, c = vc - which * HDP;         // HDP % 16 == 0: the wave's 16 columns stay in one slice
@@ -614,6 +635,10 @@ __global__ __launch_bounds__(512) void ln_qkv_kernel(const LnQkvParams p) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             f32x4 v = acc[t] + bias;
+            if constexpr (SPLIT) {                                  // plain fp32 q | k | v: the attention kernel scales and splits while staging
+              *reinterpret_cast<f32x4*>(p.qkv_f + (size_t)(m0 + t * 16 + fr) * ldq + (which * HEADS + hh) * hdp + c) = v;
+              continue;
+            }
             if (which == 0) v = v * p.qscale;
             bf16x4 o;
 #pragma unroll
@@ -626,10 +651,11 @@ __global__ __launch_bounds__(512) void ln_qkv_kernel(const LnQkvParams p) {
   });
 }
 
-template <int HDT, int KC, int HEADS>
+template <int HDT, int KC, int HEADS, bool SPLIT = false>
 int launch_ln_qkv(const LnQkvParams& p, hipStream_t stream) {
-  constexpr size_t lds = (size_t)64 * (KC * 32 + 16) * 2 + (size_t)(640 + HEADS * 3 * 16 * HDT) * sizeof(float);
-  auto kern = ln_qkv_kernel<HDT, KC, HEADS>;
+  constexpr size_t lds = (size_t)64 * (KC * 32 + 16) * 2 * (SPLIT ? 2 : 1) + (size_t)(640 + HEADS * 3 * 16 * HDT) * sizeof(float);
+  static_assert(lds <= 160 * 1024, "ln_qkv: LDS budget");
+  auto kern = ln_qkv_kernel<HDT, KC, HEADS, SPLIT>;
   static SradOncePerDevice configured;
   if (configured.need()) {
     SRAD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -647,7 +673,7 @@ int launch_ln_qkv(const LnQkvParams& p, hipStream_t stream) {
 }  // namespace
 
 bool srad_ln_qkv_supported(int prec, int M, int d, int heads) {
-  if (prec != SRAD_PREC_BF16 || M <= 0 || M % 64 || d % 4 || d > 320 || d < 32 || heads < 1 || d % heads) return false;
+  if ((prec != SRAD_PREC_BF16 && prec != SRAD_PREC_BF16X3) || M <= 0 || M % 64 || d % 4 || d > 320 || d < 32 || heads < 1 || d % heads) return false;
   const int hdt = (d / heads + 15) / 16, kc = (d + 31) / 32;
 #define X(a, b, c) if (hdt == a && kc == b && heads == c) return true;
   SRAD_LQ_CFGS(X)
@@ -657,11 +683,16 @@ bool srad_ln_qkv_supported(int prec, int M, int d, int heads) {
 
 int srad_launch_ln_qkv(const LnQkvParams& p, hipStream_t stream) {
   SRAD_REQUIRE(srad_ln_qkv_supported(SRAD_PREC_BF16, p.M, p.d, p.heads), "ln_qkv: unsupported shape M=%d d=%d heads=%d", p.M, p.d, p.heads);
-  SRAD_REQUIRE(p.x && p.ln_g && p.ln_b && p.w_qkv && p.b_qkv && p.qkv_h, "ln_qkv: null argument");
-  SRAD_REQUIRE((p.ldx & 3) == 0 && ((uintptr_t)p.x & 15) == 0 && ((uintptr_t)p.qkv_h & 7) == 0 && p.hdp % 4 == 0 && p.hdp >= p.d / p.heads &&
+  SRAD_REQUIRE(p.x && p.ln_g && p.ln_b && p.w_qkv && p.b_qkv && (p.qkv_h || (p.qkv_f && p.w_qkv_lo)) && !(p.qkv_h && p.qkv_f), "ln_qkv: null argument");
+  SRAD_REQUIRE((p.ldx & 3) == 0 && ((uintptr_t)p.x & 15) == 0 && ((uintptr_t)p.qkv_h & 7) == 0 && ((uintptr_t)p.qkv_f & 15) == 0 && p.hdp % 4 == 0 && p.hdp >= p.d / p.heads &&
                    p.hdp <= 16 * ((p.d / p.heads + 15) / 16),
                "ln_qkv: x rows must be float4-addressable, the head slots 4-column multiples within the head's 16-column tiles");
   const int hdt = (p.d / p.heads + 15) / 16, kc = (p.d + 31) / 32;
+  if (p.qkv_f) {                                                  // split-bf16
+#define X(a, b, c) if (hdt == a && kc == b && p.heads == c) return launch_ln_qkv<a, b, c, true>(p, stream);
+    SRAD_LQ_CFGS(X)
+#undef X
+  }
 #define X(a, b, c) if (hdt == a && kc == b && p.heads == c) return launch_ln_qkv<a, b, c>(p, stream);
   SRAD_LQ_CFGS(X)
 #undef X

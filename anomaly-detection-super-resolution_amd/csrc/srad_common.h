@@ -279,6 +279,9 @@ struct LnQkvParams {
   const void* w_qkv; const float* b_qkv;   // per-head fragment pack (srad_launch_pack_qkv_frag), bias [3d]
   __bf16* qkv_h; int hdp;                  // out: [M][3][heads][hdp] as the attention's MFMA operands (see AttnParams::qkv_h)
   float qscale;                            // factor of the q slices (srad_window_attn_bf16_in)
+  // split-bf16 (SRAD_PREC_BF16X3): the lo terms of the fragment pack, and the output as fp32 [M][3][heads][hdp] (plain q | k | v +
+  // bias, no factor, pad columns not written) for the split window attention kernel, which splits them again while staging
+  const void* w_qkv_lo = nullptr; float* qkv_f = nullptr;
 };
 bool srad_ln_qkv_supported(int prec, int M, int d, int heads);
 int srad_launch_ln_qkv(const LnQkvParams& p, hipStream_t stream);

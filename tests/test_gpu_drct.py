@@ -180,6 +180,37 @@ def test_c5_bf16_qkv_from_the_gemm_matches_fp32_staging(monkeypatch):
     assert np.abs(new - ref).max() / rng < 6e-3          # measured 3.1e-3 of the range (1 RDG, bf16 whole model vs the fp32 oracle)
 
 
+def test_c5_split_bf16_matches_oracle_and_fp32_mode(monkeypatch):
+    """64 x 64 windows in the split-bf16 (parity-grade) mode, round 3: the split instances of ln_qkv_kernel and of the window
+    attention kernel (hi + lo bf16 planes, three MFMAs per product) in front of the split mlp_block.  1-RDG model on a 64 x 128 LR
+    image against the CPU oracle at the fp32 bar, with and without the fused LayerNorm1 + qkv launch; then the full C5 shape
+    (12 RDG, 65536 tokens) against the engine's fp32 mode: the parity bar of C2 (1e-3 of the range), measured values printed."""
+    from oracle import sr_ref as R
+    from srad_amd import spec as S
+    cfg = S.DRCTConfig(in_chans=1, img_size=256, window_size=64, upscale=4, n_rdg=1)
+    sd = S.synth_state(S.drct_spec(cfg), seed=64, gain=1.0, cfg=cfg)
+    x = S.synth_image("c5", (1, 1, 64, 128), seed=3)
+    with torch.no_grad():
+        ref = R.drct_forward(sd, torch.from_numpy(x), cfg).numpy()
+        m = build(cfg, sd, "bf16x3")
+        out = m(torch.from_numpy(x).cuda()).cpu().numpy()
+        monkeypatch.setenv("SRAD_NO_LN_QKV", "1")              # LayerNorm1 + qkv through the split tiled GEMM instead
+        out_gemm = m(torch.from_numpy(x).cuda()).cpu().numpy()
+        monkeypatch.delenv("SRAD_NO_LN_QKV")
+    print("C5 1-RDG split-bf16 vs oracle:", rel_err(out, ref), "; with the tiled GEMM for qkv:", rel_err(out_gemm, ref))
+    assert rel_err(out, ref) < 2e-4 and rel_err(out_gemm, ref) < 2e-4
+    cfg = S.DRCTConfig(in_chans=1, img_size=256, window_size=64, upscale=4, n_rdg=12)
+    sd = S.synth_state(S.drct_spec(cfg), seed=65, gain=1.0, cfg=cfg)
+    xf = torch.from_numpy(S.synth_image("c5full", (1, 1, 256, 256), seed=4)).cuda()
+    with torch.no_grad():
+        y32 = build(cfg, sd, "fp32")(xf)
+        y3 = build(cfg, sd, "bf16x3")(xf)
+    rng = float(y32.max() - y32.min())
+    e = float((y3 - y32).abs().max()) / rng
+    print("C5 full shape: split-bf16 vs fp32 mode max err / range", e)
+    assert e < 1e-3
+
+
 def test_c5_full_shape_bf16_close_to_fp32_mode():
     """C5 at full size: DRCT-L (12 RDG), one 1024 px HR tile = LR [1, 1, 256, 256], window 64 (65536 tokens, 16
     windows of 4096).  No CPU reference at this size: the bf16 path must stay within the bf16 bar of the exact-fp32
