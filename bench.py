@@ -368,6 +368,27 @@ def c5_leg(args, torch, dev):
            "kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
                        for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
            "roofline": kernel_roofline(prof, 1, "c5", PEAK[args.dtype])}
+    if args.dtype == "bf16":
+        # the same tile in the parity-grade mode (split-bf16: split instances of ln_qkv, the window attention and mlp_block), and how
+        # far the bf16 output is from it
+        with torch.no_grad():
+            y16 = m(x)
+            o.precision = "bf16x3"
+            m3 = DRCT(o).to(dev).eval()
+            m3.load_state_dict(m.state_dict())
+            y3 = m3(x)
+            for _ in range(2):
+                m3(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                m3(x)
+            torch.cuda.synchronize()
+            dt3 = (time.perf_counter() - t0) / 3
+        rng = float(y3.max() - y3.min())
+        out["parity_mode"] = {"dtype": "bf16x3", "ms_per_tile": round(dt3 * 1e3, 2), "hr_mpixels_per_s": round(1024 * 1024 / dt3 / 1e6, 2),
+                              "bf16_max_err_over_range_vs_this_mode": round(float((y16 - y3).abs().max()) / rng, 5)}
+        del m3
     del m
     torch.cuda.empty_cache()
     return out
