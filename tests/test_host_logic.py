@@ -274,6 +274,67 @@ def test_drn_data_parallel_step_and_loss_log_gloo_world2():
     assert abs(out[2][0][4] - one[4]) < 1e-5                                                        # == the one-rank log of the full batch (L1 is a mean)
 
 
+@pytest.mark.parametrize("scale,n_feats", [(2, 40), (4, 20), (8, 10)])
+def test_drn_gradient_buckets_tile_the_flat_buffer(scale, n_feats):
+    """Host-only calls of the C ABI (no GPU): the DRN engine's gradient buckets (srad_drn_bucket_range, the data-parallel
+    all-reduce units of srad_drn_backward's hook) are phase + 2 contiguous ranges that tile the flat gradient buffer, in
+    completion order: tails, the up phases finest first, then everything in front of them; every parameter's offset falls
+    into exactly one bucket.  Incl. the x8 preset, whose padded layers keep their REAL sizes in the flat buffer."""
+    import ctypes as C
+    from srad_amd import _lib as L
+    cfg = L.DrnConfig(1, scale, 2, n_feats, 0.2, 255.0, L.PREC_F32, 0)
+    h = C.c_void_p()
+    L.check(L.lib().srad_drn_create(C.byref(cfg), C.byref(h)), "drn_create")
+    try:
+        total = C.c_int64()
+        L.check(L.lib().srad_drn_train_param_floats(h, C.byref(total)), "train_param_floats")
+        nb = L.lib().srad_drn_num_buckets(h)
+        phase = {2: 1, 4: 2, 8: 3}[scale]
+        assert nb == phase + 2
+        a, n = C.c_int64(), C.c_int64()
+        spans = []
+        for b in range(nb):
+            L.check(L.lib().srad_drn_bucket_range(h, b, C.byref(a), C.byref(n)), "drn_bucket_range")
+            spans.append((a.value, n.value))
+        assert all(n > 0 for _, n in spans)
+        assert spans[-1][0] == 0                                              # the last bucket starts the buffer ...
+        order = [spans[-1]] + spans[-2:0:-1] + [spans[0]]                      # ... then the up phases coarse -> fine, then the tails
+        assert all(x[0] + x[1] == y[0] for x, y in zip(order, order[1:])) and sum(order[-1]) == total.value
+        off, numel = C.c_int64(), C.c_int64()
+        name = C.c_char_p()
+        tails = 0
+        for i in range(L.lib().srad_drn_num_params(h)):
+            L.check(L.lib().srad_drn_param_info(h, i, C.byref(name), C.byref(numel)), "param_info")
+            L.check(L.lib().srad_drn_train_param_offset(h, i, C.byref(off)), "param_offset")
+            inside = [b for b, (s0, n0) in enumerate(spans) if s0 <= off.value and off.value + numel.value <= s0 + n0]
+            assert len(inside) == 1, name.value
+            if name.value.startswith(b"tail."):
+                assert inside == [0]
+                tails += 1
+            if name.value.startswith(b"head") or name.value.startswith(b"sub_mean") or name.value.startswith(b"down."):
+                assert inside == [nb - 1]
+        assert tails == 2 * (phase + 1)
+    finally:
+        L.lib().srad_drn_destroy(h)
+
+
+def test_drn_loss_terms_are_what_the_reference_log_adds_up():
+    """``drn_loss(..., terms=True)``: the optimised value is primary + dual_weight * dual (src/trainer.py:168-185), the logged one
+    primary + dual - every call of the reference's ``Loss`` adds its value to the log, the dual terms unweighted."""
+    from srad_amd.train import drn_loss
+    g = torch.Generator().manual_seed(0)
+    sr = [torch.rand(2, 1, 4 * 2 ** i, 4 * 2 ** i, generator=g) for i in range(3)]
+    lrs = [torch.rand(2, 1, 4, 4, generator=g), torch.rand(2, 1, 8, 8, generator=g)]
+    hr = torch.rand(2, 1, 16, 16, generator=g)
+    sr2lr = [torch.rand(2, 1, 4, 4, generator=g), torch.rand(2, 1, 8, 8, generator=g)]
+    l1 = torch.nn.functional.l1_loss
+    total, logged = drn_loss(sr, lrs, hr, sr2lr, 0.1, l1, terms=True)
+    primary = l1(sr[-1], hr) + l1(sr[0], lrs[0]) + l1(sr[1], lrs[1])
+    dual = l1(sr2lr[0], lrs[0]) + l1(sr2lr[1], lrs[1])
+    assert torch.allclose(total, primary + 0.1 * dual) and torch.allclose(logged, primary + dual)
+    assert torch.equal(drn_loss(sr, lrs, hr, sr2lr, 0.1, l1), total)
+
+
 def test_cosine_schedule_matches_torch():
     from srad_amd.train import cosine_lr
     p = torch.nn.Parameter(torch.zeros(1))
