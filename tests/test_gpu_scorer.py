@@ -96,6 +96,25 @@ def test_large_tile_properties():
     assert torch.equal(ssim2[0], ssim[1]) and torch.equal(ssim2[1], ssim[0]) and torch.equal(mse2[0], mse[1])
 
 
+def test_large_tile_full_sweep_is_symmetric_and_batch_invariant():
+    """The C5 scorer shape in full - 1024 px tiles, all 102 window sizes of the reference's sweep (src/evaluate.py:149-150) - through
+    properties that need no CPU reference: MSE and PSNR are symmetric in their two images bit for bit, SSIM to the last fp32 bits
+    of its per-pixel map (mu1^2 + mu2^2 is contracted into one fma, which rounds the two squares differently: 1e-7, the parity bar
+    is 2e-6), and a pair scores the same alone as inside a batch."""
+    from srad_amd import metrics as M
+    g = torch.Generator(device="cpu").manual_seed(3)
+    hr = (torch.rand(2, 1024, 1024, 1, generator=g) * 255).to(torch.uint8).cuda()
+    sr = (hr.int() + torch.randint(-9, 10, hr.shape, generator=g).cuda()).clamp(0, 255).to(torch.uint8)
+    sizes = M.sweep_window_sizes(1024)
+    assert len(sizes) == 102
+    a = M.score_pairs(sr, hr, sizes)
+    b = M.score_pairs(hr, sr, sizes)
+    assert float((a[0] - b[0]).abs().max()) < 1e-7 and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    one = M.score_pairs(sr[1:2].contiguous(), hr[1:2].contiguous(), sizes)
+    assert torch.equal(one[0][0], a[0][1]) and torch.equal(one[1][0], a[1][1])
+    assert bool(((a[0] > 0) & (a[0] < 1)).all()) and bool((a[0][:, 1:] != a[0][:, :-1]).any())
+
+
 def test_l1_loss():
     from srad_amd import metrics as M
     a, b = torch.randn(3, 1, 37, 41, device="cuda"), torch.randn(3, 1, 37, 41, device="cuda")
