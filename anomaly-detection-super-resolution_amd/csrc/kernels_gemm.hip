@@ -695,6 +695,7 @@ int srad_launch_gemm(int prec, const GemmParams& p, hipStream_t stream) {
   if (p.ntaps == 9 || p.stride != 1 || p.ps)
     SRAD_REQUIRE(p.Ho > 0 && p.Wo > 0 && p.M % (p.Ho * p.Wo) == 0, "gemm: M=%d not a multiple of Ho*Wo=%d*%d", p.M, p.Ho, p.Wo);
   if (srad_conv80_supported(prec, p)) return srad_launch_conv80(p, stream);
+  if (srad_conv_thin_supported(prec, p)) return srad_launch_conv_thin(p, stream);
   SRAD_REQUIRE(!p.Xh && !p.Rh && (!p.Yh || p.hsplit_hd > 0), "gemm: bf16 activations in / out are the 80-channel conv kernel's (srad_conv80_supported)");
   int rc = prec == SRAD_PREC_BF16 ? launch_prec<SRAD_PREC_BF16>(p, stream)
            : prec == SRAD_PREC_BF16X3 ? launch_prec<SRAD_PREC_BF16X3>(p, stream) : launch_prec<SRAD_PREC_F32>(p, stream);

@@ -165,6 +165,10 @@ int srad_gemm_tile_rows(int prec, const GemmParams& p);     // rows per workgrou
 // DRN-L's 80 -> 80 channel 3x3 convolutions: weight-resident persistent kernel (kernels_conv80.hip); srad_launch_gemm routes to it
 bool srad_conv80_supported(int prec, const GemmParams& p);
 int srad_launch_conv80(const GemmParams& p, hipStream_t stream);
+// 3x3 convolutions with <= 8 input or <= 4 output channels at large pixel counts (DRN's head / tails and their data gradients):
+// direct fp32 FMAs, one pixel per thread (kernels_thin.hip); routed from srad_launch_gemm in bf16 mode
+bool srad_conv_thin_supported(int prec, const GemmParams& p);
+int srad_launch_conv_thin(const GemmParams& p, hipStream_t stream);
 
 // Packed weight geometry shared by the packer and the GEMM
 static inline int srad_cp(int cin) { return srad_round_up(cin, 32); }

@@ -158,6 +158,36 @@ def test_wgrad_conv9_bf16_operands(dev, B, H, W, x_bf16):
     assert _rel(db, dy_h.float().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("cin,n,mode", [(3, 20, "bias"), (40, 3, "bias"), (80, 1, "relu"), (4, 40, "residual"), (20, 3, "offset_out"), (4, 80, "bias")])
+def test_thin_convolutions(dev, cin, n, mode):
+    """3x3 stride-1 convolutions with few input or output channels at >= 32768 pixels - DRN's head (3 -> 20), its tails (40 / 80 -> 3
+    or 1) and their data gradients (4 -> 40 / 80).  Those with <= 8 INPUT channels take kernels_thin.hip in bf16 mode (round 3:
+    direct fp32 FMAs, weights = the packed layer's bf16 values, activations fp32: 1e-5 against torch's conv2d on bf16-rounded
+    weights); the others stay on the tiled GEMM (bf16-rounded activations: 4e-3).  Image borders, odd channel counts with
+    element-wise stores, bias / ReLU / residual / column offset into a wider buffer."""
+    from srad_amd import ops
+    B, H, W = 2, 128, 160                                                  # 40960 pixels
+    g = torch.Generator(device="cpu").manual_seed(cin * 100 + n)
+    x = torch.randn(B, cin, H, W, generator=g).to(dev)
+    w = (torch.randn(n, cin, 3, 3, generator=g) / math.sqrt(9 * cin)).to(torch.bfloat16).float().to(dev)
+    b = torch.randn(n, generator=g).to(dev)
+    xn = x.permute(0, 2, 3, 1).reshape(-1, cin).clone(memory_format=torch.contiguous_format)
+    conv = F.conv2d(x, w, b, padding=1).permute(0, 2, 3, 1).reshape(-1, n)
+    if mode == "bias":
+        y, ref = ops.gemm(xn, w, b, B=B, H=H, W=W, precision="bf16"), conv
+    elif mode == "relu":
+        y, ref = ops.gemm(xn, w, b, B=B, H=H, W=W, act=3, precision="bf16"), F.relu(conv)
+    elif mode == "residual":
+        r = torch.randn(B * H * W, n, generator=g).to(dev)
+        y, ref = ops.gemm(xn, w, b, B=B, H=H, W=W, residual=r, precision="bf16"), conv + r
+    else:
+        out = torch.full((B * H * W, 8), float("nan"), device=dev)
+        ops.gemm(xn, w, b, B=B, H=H, W=W, out=out, out_offset=4, precision="bf16")
+        assert torch.isnan(out[:, :4]).all() and torch.isnan(out[:, 4 + n:]).all()
+        y, ref = out[:, 4:4 + n], conv
+    assert _rel(y, ref) < (1e-5 if cin <= 8 else 4e-3), _rel(y, ref)
+
+
 def test_conv80_eligible_shape_with_gelu_is_not_sent_to_the_weight_resident_kernel(dev):
     """conv80's epilogue implements none / ReLU / LeakyReLU; an 80 -> 80 3x3 convolution with another activation at a
     conv80-eligible shape must take the tiled GEMM (which applies GELU) instead of silently dropping the activation."""
