@@ -125,7 +125,8 @@ __global__ __launch_bounds__(C80_NT) void conv80_kernel(const GemmParams p, cons
         const int idx = min(tid + C80_NT * (i0 + i), NP - 1);
         const int n = idx / 92, pc = min(idx - n * 92, 89);
         const int tap = pc / 10, c8 = pc - tap * 10;
-        wr[i] = wg[(n * (9 * 96) + tap * 96 + c8 * 8) / 8];
+        const int nrow = p.sp_q >= 0 ? 4 * n + p.sp_q : n;        // sub-pixel mode: every fourth row of the 320-row pack
+        wr[i] = wg[(nrow * (9 * 96) + tap * 96 + c8 * 8) / 8];
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
@@ -140,7 +141,11 @@ __global__ __launch_bounds__(C80_NT) void conv80_kernel(const GemmParams p, cons
   f32x4 bias_r[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   if (p.bias) {
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt) bias_r[nt] = *reinterpret_cast<const f32x4*>(p.bias + min((nt0w + nt) * 16 + 4 * fq, 76));
+    for (int nt = 0; nt < 3; ++nt) {
+      const int c = min((nt0w + nt) * 16 + 4 * fq, 76);
+      if (p.sp_q >= 0) bias_r[nt] = f32x4{p.bias[4 * c + p.sp_q], p.bias[4 * (c + 1) + p.sp_q], p.bias[4 * (c + 2) + p.sp_q], p.bias[4 * (c + 3) + p.sp_q]};
+      else bias_r[nt] = *reinterpret_cast<const f32x4*>(p.bias + c);
+    }
   }
   store_halo();
   stamp();                                                                  // 2: first halo arrived and stored
@@ -180,6 +185,10 @@ __global__ __launch_bounds__(C80_NT) void conv80_kernel(const GemmParams p, cons
     const int ty = tl / tiles_x, tx = tl - ty * tiles_x;
     const int yy = ty * C80_TH + row;
     const size_t pix0 = (size_t)(b * H + yy) * W + tx * C80_TW + fr;
+    // where the outputs of pixels pix0 / pix0 + 16 go: the same pixels, or (sub-pixel mode) their (dy, dx) position in the 2x image
+    const bool sp = p.sp_q >= 0;
+    const size_t opix0 = sp ? ((size_t)(b * 2 * H + 2 * yy + (p.sp_q >> 1)) * (2 * W) + 2 * (tx * C80_TW + fr) + (p.sp_q & 1)) : pix0;
+    const size_t opix16 = sp ? 32 : 16;                        // output-pixel distance of the tile's second 16-pixel half
     typedef typename std::conditional<RM == 2, u32x2, f32x4>::type rreg_t;
     [[maybe_unused]] rreg_t rres[2][NTW];
     if constexpr (RM != 0) {
@@ -277,11 +286,11 @@ __global__ __launch_bounds__(C80_NT) void conv80_kernel(const GemmParams p, cons
         const u32x2 a = __builtin_bit_cast(u32x2, h0), bq = __builtin_bit_cast(u32x2, h1);
         const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], bq[0], false, false);
         const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], bq[1], false, false);
-        const size_t pix = pix0 + 16 * (fq & 1);
+        const size_t pix = opix0 + opix16 * (fq & 1);
         *reinterpret_cast<u32x4*>(p.Yh + pix * p.ldy + p.yoff + (nt0 + nt) * 16 + 4 * (fq & ~1)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
       } else {
-        *reinterpret_cast<f32x4*>(p.Y + pix0 * p.ldy + p.yoff + c) = vv[0];
-        *reinterpret_cast<f32x4*>(p.Y + (pix0 + 16) * p.ldy + p.yoff + c) = vv[1];
+        *reinterpret_cast<f32x4*>(p.Y + opix0 * p.ldy + p.yoff + c) = vv[0];
+        *reinterpret_cast<f32x4*>(p.Y + (opix0 + opix16) * p.ldy + p.yoff + c) = vv[1];
       }
     }
     if (p.pool_part) {                                        // the tile's column sums: 16 pixels per lane group, then the four rows
@@ -324,6 +333,7 @@ bool srad_conv80_supported(int prec, const GemmParams& p) {
          ((!p.R && !p.Rh) || p.rmode == SRAD_RMODE_ADD || p.rmode == SRAD_RMODE_DLRELU) && !(p.R && p.Rh) && (p.ldx & 3) == 0 && (p.ldy & 3) == 0 &&
          (p.yoff & 3) == 0 && ((!p.R && !p.Rh) || (p.ldr & 3) == 0) && ((uintptr_t)p.Rh & 7) == 0 && (((uintptr_t)p.X | (uintptr_t)p.Y | (uintptr_t)p.R | (uintptr_t)p.bias | (uintptr_t)p.Wp) & 15) == 0 &&
          ((uintptr_t)p.Xh & 7) == 0 && ((uintptr_t)p.Yh & 15) == 0 && (!p.Yh || ((p.ldy & 7) == 0 && (p.yoff & 7) == 0)) &&
+         (p.sp_q < 0 || (p.sp_q <= 3 && !p.R && !p.Rh && !p.pool_part && p.bias)) &&
          p.M >= 128 * 64;                                        // small launches stay on the tiled GEMM (one tile per workgroup anyway)
 }
 

@@ -695,6 +695,17 @@ int srad_launch_gemm(int prec, const GemmParams& p, hipStream_t stream) {
   if (p.ntaps == 9 || p.stride != 1 || p.ps)
     SRAD_REQUIRE(p.Ho > 0 && p.Wo > 0 && p.M % (p.Ho * p.Wo) == 0, "gemm: M=%d not a multiple of Ho*Wo=%d*%d", p.M, p.Ho, p.Wo);
   if (srad_conv80_supported(prec, p)) return srad_launch_conv80(p, stream);
+  if (prec == SRAD_PREC_BF16 && p.ps == 2 && p.N == 320 && p.Cin == 80 && p.bias && getenv("SRAD_NO_UPCONV_SPLIT") == nullptr) {
+    // DRN's Upsampler conv (80 -> 320 channels + PixelShuffle(2)): four 80 -> 80 convolutions through the weight-resident kernel,
+    // one per sub-pixel position (rows 4 c + q of the pack), each writing its quarter of the 2x image - 217 us on this tiled
+    // GEMM at 128 px x 8 against 4 x 26
+    GemmParams q = p;
+    q.ps = 0; q.N = 80; q.sp_q = 0;
+    if (srad_conv80_supported(prec, q)) {
+      for (int k = 0; k < 4; ++k) { q.sp_q = k; SRAD_TRY(srad_launch_conv80(q, stream)); }
+      return SRAD_OK;
+    }
+  }
   if (srad_conv_thin_supported(prec, p)) return srad_launch_conv_thin(p, stream);
   SRAD_REQUIRE(!p.Xh && !p.Rh && (!p.Yh || p.hsplit_hd > 0), "gemm: bf16 activations in / out are the 80-channel conv kernel's (srad_conv80_supported)");
   int rc = prec == SRAD_PREC_BF16 ? launch_prec<SRAD_PREC_BF16>(p, stream)

@@ -151,6 +151,10 @@ struct GemmParams {
   // hsplit - the ReLU output between an RCAB's two convolutions, which only the second one reads
   const __bf16* Xh = nullptr;
   const __bf16* Rh = nullptr;   // conv80 only: R as a bf16 array (ldr in elements) - the saved ReLU output as the backward's mask
+  // conv80 only, sub-pixel mode (sp_q in 0..3): this launch is one of the four 80 -> 80 convolutions an 80 -> 320 convolution +
+  // PixelShuffle(2) (DRN's Upsampler, src/drn.py:55-81) splits into: output channel c of the launch is row 4 c + sp_q of the
+  // packed weight / bias, and lands at pixel (2 y + sp_q / 2, 2 x + sp_q % 2) of the [B][2 Ho][2 Wo][ldy] output
+  int sp_q = -1;
   // ---- training extensions (all off when zero) ----
   int rmode;                 // how R enters: 0 v = act(acc)*alpha*rs + R (residual); 1 v = acc*alpha*rs * gelu'(R);
                              //               2 v = acc*alpha*rs * (R > 0 ? 1 : slope)   (backward through an activation)

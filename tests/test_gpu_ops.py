@@ -218,6 +218,39 @@ def test_conv_pixel_shuffle(dev, prec):
     assert _rel(y, ref) < TOL[prec]
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (3, 64, 96), (2, 128, 128)])
+def test_upsampler_conv_as_four_subpixel_convolutions(dev, B, H, W):
+    """DRN's Upsampler convolution (80 -> 320 channels + PixelShuffle(2), src/drn.py:55-81) at sizes the weight-resident kernel takes
+    (round 3: four 80 -> 80 launches, one per sub-pixel position - rows 4 c + q of the packed weight and bias, outputs at pixel
+    (2 y + q / 2, 2 x + q % 2)): against torch's conv2d + pixel_shuffle on bf16-rounded operands, and against the tiled GEMM's
+    pixel-shuffle epilogue (SRAD_NO_UPCONV_SPLIT is read per call)."""
+    import os
+    from srad_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(B + H + W)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    x = bf(torch.randn(B, 80, H, W, generator=g)).to(dev)
+    w = bf(torch.randn(320, 80, 3, 3, generator=g) / math.sqrt(720)).to(dev)
+    b = torch.randn(320, generator=g).to(dev)
+    xn = x.permute(0, 2, 3, 1).reshape(-1, 80).clone(memory_format=torch.contiguous_format)
+    from srad_amd import _lib as L
+    L.prof_enable(True)
+    y = ops.gemm(xn, w, b, B=B, H=H, W=W, pixel_shuffle=True, precision="bf16")
+    torch.cuda.synchronize()
+    prof = L.prof_collect()
+    os.environ["SRAD_NO_UPCONV_SPLIT"] = "1"
+    try:
+        y0 = ops.gemm(xn, w, b, B=B, H=H, W=W, pixel_shuffle=True, precision="bf16")
+        torch.cuda.synchronize()
+        prof0 = L.prof_collect()
+    finally:
+        del os.environ["SRAD_NO_UPCONV_SPLIT"]
+        L.prof_enable(False)
+    assert prof.get("conv80", {}).get("launches") == 4 and "conv80" not in prof0, (prof, prof0)     # the two paths were taken
+    ref = F.pixel_shuffle(F.conv2d(x, w, b, padding=1), 2).permute(0, 2, 3, 1).reshape(-1, 80)
+    assert y.shape == ref.shape and _rel(y, ref) < 1e-4, _rel(y, ref)
+    assert _rel(y0, ref) < 1e-4 and _rel(y, y0) < 1e-4
+
+
 def _attn_ref(qkv, table, B, H, W, ws, shift, heads):
     from oracle import sr_ref as R
     d = qkv.shape[1] // 3
