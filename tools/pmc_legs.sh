@@ -6,6 +6,7 @@ set -e -o pipefail
 R=${1:-r03}; shift || true
 LEGS=${@:-"c2 c3 c4 c5 drn_train"}
 cd "$(dirname "$0")/.."
+export SRAD_BENCH_NO_STEP_GRAPH=1   # eager launches under the counters (bench.py drn_train_leg says why)
 for leg in $LEGS; do
   if [ "$leg" = c2 ]; then unset PMC_BENCH; else export PMC_BENCH="python3 bench.py --only $leg"; fi
   bash tools/pmc_passes.sh "gpurun_out/pmc_$leg" "${R}_$leg" > "gpurun_out/pmc_$leg.log" 2>&1 || { echo "leg $leg failed"; tail -5 "gpurun_out/pmc_$leg.log"; exit 1; }
