@@ -189,7 +189,9 @@ __global__ void scale_add_kernel(const float* __restrict__ r, const float* __res
 // rows - cheaper than a launch boundary, and the lone one-workgroup-per-image gate kernel took 12 us) and then streams
 // its slice of the image: out = r * gate[b] + x.  grid = (slices per image, B); the slice-0 workgroups also write the gate
 // and the pooled sums when the caller keeps them (training).
-template <bool RH, bool XH = false, bool YH = false>   // RH: r is a bf16 array (the eval path's conv80 wrote it so; half the bytes of this
+// NI > 0: a thread's <= NI items of r and x are requested BEFORE the gate chain and wait in registers (every workgroup of the
+// launch is resident at once, so the kernel lasts as long as one workgroup's chain: gate round trips + stream round trip)
+template <bool RH, bool XH = false, bool YH = false, int NI = 0>   // RH: r is a bf16 array (the eval path's conv80 wrote it so; half the bytes of this
                                                        // bandwidth-bound pass's largest read); XH / YH: so are the chain tensor read / written
 __global__ __launch_bounds__(256) void ca_scale_add_kernel(const float* __restrict__ part, int nchunk, float inv_hw, int C, int Cr,
                                                            const float* __restrict__ w1, const float* __restrict__ b1,
@@ -202,6 +204,25 @@ __global__ __launch_bounds__(256) void ca_scale_add_kernel(const float* __restri
   __shared__ f32x4 red[256];
   const int b = blockIdx.y, tid = threadIdx.x;
   const int c4n = C / 4;
+  const int per = (hw + gridDim.x - 1) / gridDim.x;
+  const int p0 = blockIdx.x * per, p1 = min(hw, p0 + per);
+  const size_t base = (size_t)b * hw;
+  const int items = (p1 - p0) * c4n;
+  typedef typename std::conditional<RH, bf16x4, f32x4>::type rreg_t;
+  typedef typename std::conditional<XH, bf16x4, f32x4>::type xreg_t;
+  constexpr int NR = NI > 0 ? NI : 1;
+  rreg_t r_pre[NR];
+  xreg_t x_pre[NR];
+  if constexpr (NI > 0) {
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      const int i = max(min(tid + 256 * u, items - 1), 0);     // clamped: no load behind a branch
+      const int pl = i / c4n, c = (i - pl * c4n) * 4;
+      const size_t pix = base + min(p0 + pl, hw - 1);         // (a slice past the image's end has no items)
+      r_pre[u] = *reinterpret_cast<const rreg_t*>(reinterpret_cast<const char*>(r) + (pix * C + c) * (RH ? 2 : 4));
+      x_pre[u] = *reinterpret_cast<const xreg_t*>(reinterpret_cast<const char*>(x) + (pix * ldx + c) * (XH ? 2 : 4));
+    }
+  }
   // The gate is a chain of dependent steps (pool sums -> hidden units -> gate) in front of a bandwidth-side pass, in every
   // workgroup: keep its round trips few.  The small weights go to registers before anything else (C <= 96, C / 16 <= 8: every
   // RCAB of the reference's presets); the partial rows are summed by (row class, channel float4) threads with all of a thread's
@@ -224,15 +245,15 @@ __global__ __launch_bounds__(256) void ca_scale_add_kernel(const float* __restri
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     if (pt < nparts) {
       const float* pp = part + (size_t)b * nchunk * C + 4 * c4;
-      int k = pt;
-      for (; k + 7 * nparts < nchunk; k += 8 * nparts) {
-        f32x4 t[8];
+      // twelve rows per trip, clamped and masked: a remainder loop of single rows was one dependent round trip per row (three of
+      // them at 32 rows per image, where the eight-row trip never ran); same order of additions
+      for (int k = pt; k < nchunk; k += 12 * nparts) {
+        f32x4 t[12];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4*>(pp + (size_t)(k + u * nparts) * C);
+        for (int u = 0; u < 12; ++u) t[u] = *reinterpret_cast<const f32x4*>(pp + (size_t)min(k + u * nparts, nchunk - 1) * C);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += t[u];
+        for (int u = 0; u < 12; ++u) if (k + u * nparts < nchunk) acc += t[u];
       }
-      for (; k < nchunk; k += nparts) acc += *reinterpret_cast<const f32x4*>(pp + (size_t)k * C);
       red[tid] = acc;
     }
     __syncthreads();
@@ -277,33 +298,34 @@ __global__ __launch_bounds__(256) void ca_scale_add_kernel(const float* __restri
     if (gate_out && blockIdx.x == 0) gate_out[(size_t)b * C + c] = g;
   }
   __syncthreads();
-  const int per = (hw + gridDim.x - 1) / gridDim.x;
-  const int p0 = blockIdx.x * per, p1 = min(hw, p0 + per);
-  const size_t base = (size_t)b * hw;
-  for (int i = tid; i < (p1 - p0) * c4n; i += 256) {
-    const int pl = i / c4n, c = (i - pl * c4n) * 4;
+  auto widen = [](auto v) {
+    if constexpr (std::is_same<decltype(v), bf16x4>::value) return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    else return v;
+  };
+  auto finish = [&](int pl, int c, rreg_t rr, xreg_t xx) {
     const size_t pix = base + p0 + pl;
-    f32x4 rv;
-    if constexpr (RH) {
-      const bf16x4 rh = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(r) + pix * C + c);
-      rv = f32x4{(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
-    } else {
-      rv = *reinterpret_cast<const f32x4*>(r + pix * C + c);
-    }
-    f32x4 xv;
-    if constexpr (XH) {
-      const bf16x4 xh = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(x) + pix * ldx + c);
-      xv = f32x4{(float)xh[0], (float)xh[1], (float)xh[2], (float)xh[3]};
-    } else {
-      xv = *reinterpret_cast<const f32x4*>(x + pix * ldx + c);
-    }
-    const f32x4 o = rv * *reinterpret_cast<const f32x4*>(gt + c) + xv;
+    const f32x4 o = widen(rr) * *reinterpret_cast<const f32x4*>(gt + c) + widen(xx);
     if constexpr (YH) {
       bf16x4 oh;
       oh[0] = (__bf16)o[0]; oh[1] = (__bf16)o[1]; oh[2] = (__bf16)o[2]; oh[3] = (__bf16)o[3];
       *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(y) + pix * C + c) = oh;
     } else {
       *reinterpret_cast<f32x4*>(y + pix * C + c) = o;
+    }
+  };
+  if constexpr (NI > 0) {
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      const int i = tid + 256 * u;
+      const int pl = i / c4n, c = (i - pl * c4n) * 4;
+      if (i < items) finish(pl, c, r_pre[u], x_pre[u]);
+    }
+  } else {
+    for (int i = tid; i < items; i += 256) {
+      const int pl = i / c4n, c = (i - pl * c4n) * 4;
+      const size_t pix = base + p0 + pl;
+      finish(pl, c, *reinterpret_cast<const rreg_t*>(reinterpret_cast<const char*>(r) + (pix * C + c) * (RH ? 2 : 4)),
+             *reinterpret_cast<const xreg_t*>(reinterpret_cast<const char*>(x) + (pix * ldx + c) * (XH ? 2 : 4)));
     }
   }
 }
@@ -329,6 +351,29 @@ inline bool drn_level_bf16(int prec, int B, int Hl, int Wl, int ch) {
 }
 
 inline int ca_slices(int hw) { return hw >= 128 * 128 ? 128 : (hw >= 1024 ? 64 : (hw >= 64 ? 8 : 1)); }
+
+// ca_scale_add_kernel's instance for the operand storage (r / x / y as bf16) and the slice size: 5 or 10 items per thread wait in
+// registers over the gate chain, larger slices take the loop (SRAD_DRN_CA_NO_PRELOAD: always the loop)
+template <class... A>
+inline void launch_ca_scale_add(bool r_h, bool x_h, bool y_h, int slices, int B, int hw, int C, hipStream_t s, A... args) {
+  static const bool no_pre = getenv("SRAD_DRN_CA_NO_PRELOAD") != nullptr;
+  const int items = ((hw + slices - 1) / slices) * (C / 4);
+  const int ni = no_pre || items > 2560 ? 0 : (items <= 1280 ? 5 : 10);
+  const dim3 grid(slices, B);
+  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, args...); };
+  auto by_ni = [&](auto RH, auto XH, auto YH) {
+    constexpr bool rh = decltype(RH)::value, xh = decltype(XH)::value, yh = decltype(YH)::value;
+    if (ni == 5) go(ca_scale_add_kernel<rh, xh, yh, 5>);
+    else if (ni == 10) go(ca_scale_add_kernel<rh, xh, yh, 10>);
+    else go(ca_scale_add_kernel<rh, xh, yh, 0>);
+  };
+  using T = std::true_type; using F = std::false_type;
+  if (!r_h) by_ni(F{}, F{}, F{});
+  else if (x_h && y_h) by_ni(T{}, T{}, T{});
+  else if (x_h) by_ni(T{}, T{}, F{});
+  else if (y_h) by_ni(T{}, F{}, T{});
+  else by_ni(T{}, F{}, F{});
+}
 
 inline int grid1d(size_t total) {
   size_t b = (total + 255) / 256;
@@ -525,16 +570,9 @@ int forward_body(srad_drn* h, const float* x, int B, int H, int W, float* const*
       const bool y_h = r_h && !chain_f32 && b + 1 < c.n_blocks;   // the next block's conv80 reads it (same shape: supported there too)
       {  // the gate, and res = body(x) * gate + x               (drn.py:128-139, 156-157)
         SradProfScope prof(s, SRAD_K_MISC, 2.0 * T * ch, (double)((r_h ? 2 : 4) + (x_h ? 2 : 4) + (y_h ? 2 : 4)) * T * ch);
-        const dim3 grid(ca_slices(Hl * Wl), B);
-        auto launch = [&](auto kern) {
-          hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, w.pool, nchunk, 1.0f / (float)(Hl * Wl), ch, ch / 16, h->pt.fptr(r.w1),
-                             h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2), (float*)nullptr, (float*)nullptr, w.rr, xin, ldin, cur, Hl * Wl);
-        };
-        if (!r_h) launch(ca_scale_add_kernel<false, false, false>);
-        else if (x_h && y_h) launch(ca_scale_add_kernel<true, true, true>);
-        else if (x_h) launch(ca_scale_add_kernel<true, true, false>);
-        else if (y_h) launch(ca_scale_add_kernel<true, false, true>);
-        else launch(ca_scale_add_kernel<true, false, false>);
+        launch_ca_scale_add(r_h, x_h, y_h, ca_slices(Hl * Wl), B, Hl * Wl, ch, s, (const float*)w.pool, nchunk, 1.0f / (float)(Hl * Wl), ch, ch / 16,
+                            (const float*)h->pt.fptr(r.w1), (const float*)h->pt.fptr(r.b1), (const float*)h->pt.fptr(r.w2), (const float*)h->pt.fptr(r.b2),
+                            (float*)nullptr, (float*)nullptr, (const float*)w.rr, (const float*)xin, ldin, (float*)cur, Hl * Wl);
       }
       SRAD_CHECK_HIP(hipGetLastError());
       xin = cur; ldin = ch; x_h = y_h;
@@ -897,7 +935,8 @@ __global__ __launch_bounds__(256) void ca_bwd_kernel(const float* __restrict__ p
 // channel attention's data gradient - sigmoid, the two 1x1 convs, the ReLU, back to the mean - is C * C/16 * 3 MACs per image,
 // while the one-workgroup ca_bwd_kernel that used to hand it over sat on the critical path of every block (16 us x 80 per
 // step); that kernel now only produces the weight gradients, on the side stream.  grid = (slices per image, B).
-template <bool YH = false>   // YH: dr is written as a bf16 array (only MFMA operands read it: the conv's data and weight gradients)
+template <bool YH = false, int NI = 0>   // YH: dr is written as a bf16 array (only MFMA operands read it: the conv's data and weight gradients)
+                                         // NI > 0: a thread's <= NI float4 of g wait in registers over the chain (see ca_scale_add_kernel)
 __global__ __launch_bounds__(256) void ca_apply_bwd_kernel(const float* __restrict__ g, const float* __restrict__ gate,
                                                            const float* __restrict__ part, int nchunk, const float* __restrict__ pool,
                                                            float inv_hw, int C, int Cr, const float* __restrict__ w1,
@@ -909,20 +948,49 @@ __global__ __launch_bounds__(256) void ca_apply_bwd_kernel(const float* __restri
   const int b = blockIdx.y, tid = threadIdx.x;
   const int c4n = C / 4;
   const int hj = tid >> 5, hl = tid & 31;
+  const int per = (hw + gridDim.x - 1) / gridDim.x;
+  const int p0 = blockIdx.x * per, p1 = min(hw, p0 + per);
+  const size_t base = (size_t)b * hw;
+  const int items = (p1 - p0) * c4n;
+  f32x4 g_pre[NI > 0 ? NI : 1];
+  if constexpr (NI > 0) {
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      const int i = max(min(tid + 256 * u, items - 1), 0);
+      const int pl = i / c4n, c = (i - pl * c4n) * 4;
+      g_pre[u] = *reinterpret_cast<const f32x4*>(g + (base + min(p0 + pl, hw - 1)) * C + c);
+    }
+  }
+  // the small weights first, into registers (C <= 96, C / 16 <= 8: every RCAB of the reference's presets), so that the chain
+  // below is one memory round trip and not one per step
+  const bool small = C <= 96 && Cr <= 8;
+  float w1h[3] = {0.f, 0.f, 0.f}, w2h[3] = {0.f, 0.f, 0.f}, w1c[8], b1h = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) w1c[j] = 0.f;
+  if (small) {
+    const int j = min(hj, Cr - 1);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int c = min(hl + 32 * u, C - 1);
+      w1h[u] = w1[j * C + c];
+      w2h[u] = w2[c * Cr + j];
+    }
+    b1h = b1[j];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w1c[q] = w1[min(q, Cr - 1) * C + min(tid, C - 1)];
+  }
   {  // dgate = sum of the partial rows, all of a thread's rows in flight (see ca_scale_add_kernel)
     const int nparts = 256 / c4n, pt = tid / c4n, c4 = tid - pt * c4n;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     if (pt < nparts) {
       const float* pp = part + (size_t)b * nchunk * C + 4 * c4;
-      int k = pt;
-      for (; k + 3 * nparts < nchunk; k += 4 * nparts) {
+      for (int k = pt; k < nchunk; k += 4 * nparts) {          // four rows per trip, clamped and masked (see ca_scale_add_kernel)
         f32x4 t[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const f32x4*>(pp + (size_t)(k + u * nparts) * C);
+        for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const f32x4*>(pp + (size_t)min(k + u * nparts, nchunk - 1) * C);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc += t[u];
+        for (int u = 0; u < 4; ++u) if (k + u * nparts < nchunk) acc += t[u];
       }
-      for (; k < nchunk; k += nparts) acc += *reinterpret_cast<const f32x4*>(pp + (size_t)k * C);
       red[tid] = acc;
     }
     for (int c = tid; c < C; c += 256) {
@@ -937,39 +1005,64 @@ __global__ __launch_bounds__(256) void ca_apply_bwd_kernel(const float* __restri
     }
   }
   __syncthreads();
-  for (int j0 = 0; j0 < Cr; j0 += 8) {                     // hidden units: pre-activation (its sign is the ReLU's mask) and gradient
-    const int j = j0 + hj;
+  if (small) {                                             // hidden units: pre-activation (its sign is the ReLU's mask) and gradient
     float acc = 0.f, dh = 0.f;
-    if (j < Cr)
-      for (int c = hl; c < C; c += 32) {
-        acc += w1[j * C + c] * mean[c];
-        dh += sg[c] * w2[c * Cr + j];
-      }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int c = hl + 32 * u;
+      if (c < C) { acc += w1h[u] * mean[c]; dh += sg[c] * w2h[u]; }
+    }
 #pragma unroll
     for (int o = 16; o >= 1; o >>= 1) { acc += __shfl_xor(acc, o); dh += __shfl_xor(dh, o); }
-    if (j < Cr && hl == 0) dhid[j] = acc + b1[j] > 0.f ? dh : 0.f;
+    if (hj < Cr && hl == 0) dhid[hj] = acc + b1h > 0.f ? dh : 0.f;
+  } else {
+    for (int j0 = 0; j0 < Cr; j0 += 8) {
+      const int j = j0 + hj;
+      float acc = 0.f, dh = 0.f;
+      if (j < Cr)
+        for (int c = hl; c < C; c += 32) {
+          acc += w1[j * C + c] * mean[c];
+          dh += sg[c] * w2[c * Cr + j];
+        }
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1) { acc += __shfl_xor(acc, o); dh += __shfl_xor(dh, o); }
+      if (j < Cr && hl == 0) dhid[j] = acc + b1[j] > 0.f ? dh : 0.f;
+    }
   }
   __syncthreads();
   for (int c = tid; c < C; c += 256) {                     // back to the pooled mean
     float dm = 0.f;
-    for (int j = 0; j < Cr; ++j) dm += dhid[j] * w1[j * C + c];
+    if (small) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dm += j < Cr ? dhid[j] * w1c[j] : 0.f;
+    } else {
+      for (int j = 0; j < Cr; ++j) dm += dhid[j] * w1[j * C + c];
+    }
     dpl[c] = dm * inv_hw;
   }
   __syncthreads();
-  const int per = (hw + gridDim.x - 1) / gridDim.x;
-  const int p0 = blockIdx.x * per, p1 = min(hw, p0 + per);
-  const size_t base = (size_t)b * hw;
-  for (int i = tid; i < (p1 - p0) * c4n; i += 256) {
-    const int pl = i / c4n, c = (i - pl * c4n) * 4;
+  auto finish = [&](int pl, int c, f32x4 gv) {
     const size_t pix = base + p0 + pl;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(g + pix * C + c) * *reinterpret_cast<const f32x4*>(gt + c) +
-                    *reinterpret_cast<const f32x4*>(dpl + c);
+    const f32x4 v = gv * *reinterpret_cast<const f32x4*>(gt + c) + *reinterpret_cast<const f32x4*>(dpl + c);
     if constexpr (YH) {
       bf16x4 h;
       h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
       *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dr) + pix * C + c) = h;
     } else {
       *reinterpret_cast<f32x4*>(dr + pix * C + c) = v;
+    }
+  };
+  if constexpr (NI > 0) {
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      const int i = tid + 256 * u;
+      const int pl = i / c4n, c = (i - pl * c4n) * 4;
+      if (i < items) finish(pl, c, g_pre[u]);
+    }
+  } else {
+    for (int i = tid; i < items; i += 256) {
+      const int pl = i / c4n, c = (i - pl * c4n) * 4;
+      finish(pl, c, *reinterpret_cast<const f32x4*>(g + (base + p0 + pl) * C + c));
     }
   }
 }
@@ -1262,16 +1355,9 @@ int srad_drn_forward_train(srad_drn_t* h, const float* x, int B, int H, int W, f
       }
       const bool y_h = lh && b + 1 < c.n_blocks;
       {
-        const dim3 grid(ca_slices(Hl * Wl), B);
-        auto launch = [&](auto kern) {
-          hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, w.ppart, nchunk, 1.0f / (float)(Hl * Wl), ch, ch / 16, h->pt.fptr(r.w1),
-                             h->pt.fptr(r.b1), h->pt.fptr(r.w2), h->pt.fptr(r.b2), sv.gate, sv.pool, sv.r, xin, ldin, sv.xo, Hl * Wl);
-        };
-        if (!lh) launch(ca_scale_add_kernel<false, false, false>);
-        else if (x_h && y_h) launch(ca_scale_add_kernel<true, true, true>);
-        else if (x_h) launch(ca_scale_add_kernel<true, true, false>);
-        else if (y_h) launch(ca_scale_add_kernel<true, false, true>);
-        else launch(ca_scale_add_kernel<true, false, false>);
+        launch_ca_scale_add(lh, x_h, y_h, ca_slices(Hl * Wl), B, Hl * Wl, ch, s, (const float*)w.ppart, nchunk, 1.0f / (float)(Hl * Wl), ch, ch / 16,
+                            (const float*)h->pt.fptr(r.w1), (const float*)h->pt.fptr(r.b1), (const float*)h->pt.fptr(r.w2), (const float*)h->pt.fptr(r.b2),
+                            (float*)sv.gate, (float*)sv.pool, (const float*)sv.r, (const float*)xin, ldin, (float*)sv.xo, Hl * Wl);
       }
       SRAD_CHECK_HIP(hipGetLastError());
       xin = sv.xo; ldin = ch; x_h = y_h;
@@ -1421,13 +1507,17 @@ int srad_drn_backward(srad_drn_t* h, const float* const* dys, int n_out, int B, 
       if (lh) hipLaunchKernelGGL(pool_dot_kernel<true>, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, ga, sv.r, pp, Hl * Wl, ch, DRN_POOL_CHUNKS);
       else hipLaunchKernelGGL(pool_dot_kernel<false>, dim3(DRN_POOL_CHUNKS, B), dim3(256), 0, s, ga, sv.r, pp, Hl * Wl, ch, DRN_POOL_CHUNKS);
       {
-        const dim3 grid(ca_slices(Hl * Wl), B);
+        static const bool no_pre = getenv("SRAD_DRN_CA_NO_PRELOAD") != nullptr;
+        const int slices = ca_slices(Hl * Wl);
+        const int items = ((Hl * Wl + slices - 1) / slices) * (ch / 4);
+        const int ni = no_pre || items > 2560 ? 0 : (items <= 1280 ? 5 : 10);
+        const dim3 grid(slices, B);
         auto launch = [&](auto kern) {
           hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, ga, sv.gate, pp, DRN_POOL_CHUNKS, sv.pool, 1.0f / (float)(Hl * Wl), ch, ch / 16,
                              h->pt.fptr(r.w1), h->pt.fptr(r.b1), h->pt.fptr(r.w2), dr, Hl * Wl);
         };
-        if (lh) launch(ca_apply_bwd_kernel<true>);
-        else launch(ca_apply_bwd_kernel<false>);
+        if (lh) { if (ni == 5) launch(ca_apply_bwd_kernel<true, 5>); else if (ni == 10) launch(ca_apply_bwd_kernel<true, 10>); else launch(ca_apply_bwd_kernel<true, 0>); }
+        else { if (ni == 5) launch(ca_apply_bwd_kernel<false, 5>); else if (ni == 10) launch(ca_apply_bwd_kernel<false, 10>); else launch(ca_apply_bwd_kernel<false, 0>); }
       }
       SRAD_CHECK_HIP(hipGetLastError());
       {
