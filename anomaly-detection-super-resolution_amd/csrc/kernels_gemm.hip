@@ -707,6 +707,7 @@ int srad_launch_gemm(int prec, const GemmParams& p, hipStream_t stream) {
     }
   }
   if (srad_conv_thin_supported(prec, p)) return srad_launch_conv_thin(p, stream);
+  if (srad_conv_tail_supported(prec, p)) return srad_launch_conv_tail(p, stream);
   SRAD_REQUIRE(!p.Xh && !p.Rh && (!p.Yh || p.hsplit_hd > 0), "gemm: bf16 activations in / out are the 80-channel conv kernel's (srad_conv80_supported)");
   int rc = prec == SRAD_PREC_BF16 ? launch_prec<SRAD_PREC_BF16>(p, stream)
            : prec == SRAD_PREC_BF16X3 ? launch_prec<SRAD_PREC_BF16X3>(p, stream) : launch_prec<SRAD_PREC_F32>(p, stream);

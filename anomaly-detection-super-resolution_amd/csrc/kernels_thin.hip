@@ -73,7 +73,117 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const GemmParams p) {
   }
 }
 
+// ---- the tails: 40 / 80 input channels -> <= 4 outputs (RGB) at the model's largest pixel counts.  On the tiled GEMM the im2col
+// through LDS made these 120 / 45 / 16 us launches (256 / 128 / 64 px x 8 images) for 84 / 42 / 10 MB of input; here 65 / 34 / 12.
+// (What is left is instruction issue - ~25 vector instructions per MFMA for addresses, zero selects and bf16 conversion - not
+// bytes: 1.4 TB/s.)  Here a wave owns 16 consecutive
+// pixels of an image row and runs one 16x16x32 MFMA per (tap, 32-channel chunk) with BOTH operands straight from registers: the
+// weight fragments of all 9 x ceil(Cin / 32) chunks stay in the wave's registers for its lifetime (rows >= N of the pack are
+// zeros), a pixel fragment is the lane's own 8 channels of pixel (y + dy, x + dx) loaded from global memory (two float4, rounded
+// to bf16 as the GEMM's staging rounds them, zeros outside the image) - no LDS, no barrier.  Results land transposed: the lanes
+// 0 .. 15 hold outputs 0 .. 3 of their pixel.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_tail_kernel(const GemmParams p, int tiles) {
+  constexpr int CPT = (CIN + 31) / 32, CP = CPT * 32;
+  const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+  // k slots of a 32-channel chunk: lane group fq holds channels [4 fq, 4 fq + 4) and [16 + 4 fq, 16 + 4 fq + 4) - for BOTH operands,
+  // so the product is unchanged - and each of the two float4 loads of a pixel fragment reads 64 contiguous bytes per pixel
+  // across its four lane groups (the natural 8 fq .. 8 fq + 7 slots read 16-byte pieces at a 32-byte stride: 72.7 -> 65.2 us at 256 px x 8)
+  bf16x8 wf[9][CPT];
+  {
+    const __bf16* const Wp = reinterpret_cast<const __bf16*>(p.Wp) + (size_t)fr * 9 * CP + 4 * fq;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) {
+        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(Wp + tap * CP + 32 * j);
+        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(Wp + tap * CP + 32 * j + 16);
+        wf[tap][j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+  }
+  f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias4[r] = (p.bias && fq == 0) ? p.bias[min(r, p.N - 1)] : 0.f;
+  const int H = p.Hi, W = p.Wi, tpr = W >> 4;
+  typedef f32x4 pix_t[CPT][2];
+  for (int t = gw; t < tiles; t += nw) {
+    const int row = t / tpr, x = ((t - row * tpr) << 4) + fr;
+    const int b = row / H, y = row - b * H;
+    auto load_tap = [&](int tap, pix_t& v) __attribute__((always_inline)) {
+      const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+      const float* const src = p.X + ((size_t)(b * H + min(max(yy, 0), H - 1)) * W + min(max(xx, 0), W - 1)) * p.ldx;   // clamped: no load behind a branch
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) {
+        v[j][0] = *reinterpret_cast<const f32x4*>(src + min(32 * j + 4 * fq, CIN - 4));
+        v[j][1] = *reinterpret_cast<const f32x4*>(src + min(32 * j + 16 + 4 * fq, CIN - 4));
+      }
+    };
+    auto mul_tap = [&](int tap, const pix_t& v, f32x4 acc) __attribute__((always_inline)) {
+      const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+      const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) {
+        const bool live0 = in && 32 * j + 4 * fq < CIN;      // (the weight's pad columns are zeros, but 0 * garbage need not be)
+        const bool live1 = in && 32 * j + 16 + 4 * fq < CIN;
+        bf16x8 a;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[e] = (__bf16)(live0 ? v[j][0][e] : 0.f);
+          a[4 + e] = (__bf16)(live1 ? v[j][1][e] : 0.f);
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tap][j], a, acc, 0, 0, 0);
+      }
+      return acc;
+    };
+    f32x4 acc = bias4;
+    pix_t va, vb;
+    load_tap(0, va);
+#pragma unroll
+    for (int tap = 0; tap < 9; tap += 2) {                   // the next tap's pixels in flight under this tap's conversions + MFMAs
+      if (tap + 1 < 9) load_tap(tap + 1, vb);
+      acc = mul_tap(tap, va, acc);
+      if (tap + 2 < 9) load_tap(tap + 2, va);
+      if (tap + 1 < 9) acc = mul_tap(tap + 1, vb, acc);
+    }
+    if (fq == 0) {
+      const size_t pix = (size_t)row * W + x;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float o = acc[r];
+        if (p.act == SRAD_ACT_RELU) o = fmaxf(o, 0.f);
+        else if (p.act == SRAD_ACT_LRELU) o = o > 0.f ? o : o * p.slope;
+        o *= p.alpha;
+        if (r < p.N) p.Y[pix * p.ldy + p.yoff + r] = o + (p.R ? p.R[pix * p.ldr + r] : 0.f);
+      }
+    }
+  }
+}
+
 }  // namespace
+
+bool srad_conv_tail_supported(int prec, const GemmParams& p) {
+  static const bool off = getenv("SRAD_NO_CONV_TAIL") != nullptr;
+  return !off && prec == SRAD_PREC_BF16 && p.ntaps == 9 && p.stride == 1 && p.Hi == p.Ho && p.Wi == p.Wo && !p.ln_g && p.ps == 0 &&
+         p.hsplit_hd == 0 && !p.row_scale && !p.Ypre && !p.pool_part && !p.Xh && !p.Yh && !p.Rh && p.sp_q < 0 &&
+         (p.act == SRAD_ACT_NONE || p.act == SRAD_ACT_RELU || p.act == SRAD_ACT_LRELU) && (!p.R || p.rmode == SRAD_RMODE_ADD) &&
+         p.N >= 1 && p.N <= 4 && (p.Cin == 40 || p.Cin == 80) && p.Cp == srad_cp(p.Cin) && (p.Wi & 15) == 0 && (p.ldx & 3) == 0 &&
+         ((uintptr_t)p.X & 15) == 0 && p.M >= 32768;
+}
+
+int srad_launch_conv_tail(const GemmParams& p, hipStream_t stream) {
+  SRAD_REQUIRE(srad_conv_tail_supported(SRAD_PREC_BF16, p), "conv_tail: unsupported problem");
+  const int tiles = p.M / 16;
+  // every wave keeps the whole weight in registers: few, long-lived waves.  Measured (us, 256 / 512 / 768 / 1024 workgroups):
+  // 40 -> 3 at 256 px x 8: 81 / 65 / 67 / 70;  80 -> 3 at 128 px x 8: 33.9 / 34.7 / 38 / 39;  at 64 px x 8: 11.8 / 14.8 / 14.8 / 14.5
+  const int cap = tiles >= 16384 ? 512 : 256;
+  const int wgs = tiles / 4 < cap ? tiles / 4 : cap;
+  SradProfScope prof(stream, SRAD_K_GEMM_BN16, 2.0 * p.M * p.N * 9.0 * p.Cin, 4.0 * p.M * ((double)p.Cin + p.N * (p.R ? 2 : 1)));
+  if (p.Cin == 40) hipLaunchKernelGGL(conv_tail_kernel<40>, dim3(wgs), dim3(256), 0, stream, p, tiles);
+  else hipLaunchKernelGGL(conv_tail_kernel<80>, dim3(wgs), dim3(256), 0, stream, p, tiles);
+  SRAD_CHECK_HIP(hipGetLastError());
+  return SRAD_OK;
+}
 
 bool srad_conv_thin_supported(int prec, const GemmParams& p) {
   static const bool off = getenv("SRAD_NO_CONV_THIN") != nullptr;

@@ -173,6 +173,9 @@ int srad_launch_conv80(const GemmParams& p, hipStream_t stream);
 // direct fp32 FMAs, one pixel per thread (kernels_thin.hip); routed from srad_launch_gemm in bf16 mode
 bool srad_conv_thin_supported(int prec, const GemmParams& p);
 int srad_launch_conv_thin(const GemmParams& p, hipStream_t stream);
+// DRN's tail convolutions (40 / 80 -> <= 4 channels): MFMA with both operands from registers, no LDS (kernels_thin.hip)
+bool srad_conv_tail_supported(int prec, const GemmParams& p);
+int srad_launch_conv_tail(const GemmParams& p, hipStream_t stream);
 
 // Packed weight geometry shared by the packer and the GEMM
 static inline int srad_cp(int cin) { return srad_round_up(cin, 32); }

@@ -163,7 +163,8 @@ def test_thin_convolutions(dev, cin, n, mode):
     """3x3 stride-1 convolutions with few input or output channels at >= 32768 pixels - DRN's head (3 -> 20), its tails (40 / 80 -> 3
     or 1) and their data gradients (4 -> 40 / 80).  Those with <= 8 INPUT channels take kernels_thin.hip in bf16 mode (round 3:
     direct fp32 FMAs, weights = the packed layer's bf16 values, activations fp32: 1e-5 against torch's conv2d on bf16-rounded
-    weights); the others stay on the tiled GEMM (bf16-rounded activations: 4e-3).  Image borders, odd channel counts with
+    weights); 40 / 80 -> <= 4 channels take `conv_tail_kernel` (MFMA with both operands from registers) and the rest the tiled GEMM
+    (bf16-rounded activations either way: 4e-3).  Image borders, odd channel counts with
     element-wise stores, bias / ReLU / residual / column offset into a wider buffer."""
     from srad_amd import ops
     B, H, W = 2, 128, 160                                                  # 40960 pixels
