@@ -74,9 +74,11 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const GemmParams p) {
 }
 
 // ---- the tails: 40 / 80 input channels -> <= 4 outputs (RGB) at the model's largest pixel counts.  On the tiled GEMM the im2col
-// through LDS made these 120 / 45 / 16 us launches (256 / 128 / 64 px x 8 images) for 84 / 42 / 10 MB of input; here 65 / 34 / 12.
-// (What is left is instruction issue - ~25 vector instructions per MFMA for addresses, zero selects and bf16 conversion - not
-// bytes: 1.4 TB/s.)  Here a wave owns 16 consecutive
+// through LDS made these 120 / 45 / 16 us launches (256 / 128 / 64 px x 8 images) for 84 / 42 / 10 MB of input; here 62 / 33 / 12.
+// (What is left is the texture path: every pixel's channels are loaded nine times, 27 / 45 load instructions per 16 pixels.
+// Trimming the vector instructions per chunk - one clamped index per tap, selects on packed words - bought 5 %, a third wave
+// per SIMD nothing.  A wave walking down a column strip with three input rows held as fragments would load each pixel three
+// times; at 80 channels that does not fit the registers next to the weights.)  Here a wave owns 16 consecutive
 // pixels of an image row and runs one 16x16x32 MFMA per (tap, 32-channel chunk) with BOTH operands straight from registers: the
 // weight fragments of all 9 x ceil(Cin / 32) chunks stay in the wave's registers for its lifetime (rows >= N of the pack are
 // zeros), a pixel fragment is the lane's own 8 channels of pixel (y + dy, x + dx) loaded from global memory (two float4, rounded
@@ -110,28 +112,39 @@ __global__ __launch_bounds__(256) void conv_tail_kernel(const GemmParams p, int 
   for (int t = gw; t < tiles; t += nw) {
     const int row = t / tpr, x = ((t - row * tpr) << 4) + fr;
     const int b = row / H, y = row - b * H;
+    // per tile, not per tap: the pixel index (a tap adds a constant; clamped into the tensor with one med3 - a tap outside the
+    // image then reads some other pixel, which its mask drops) and the four border masks
+    const int pix0 = row * W + x;
+    const bool up = y > 0, dn = y < H - 1, lf = x > 0, rt = x < W - 1;
     auto load_tap = [&](int tap, pix_t& v) __attribute__((always_inline)) {
-      const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-      const float* const src = p.X + ((size_t)(b * H + min(max(yy, 0), H - 1)) * W + min(max(xx, 0), W - 1)) * p.ldx;   // clamped: no load behind a branch
+      const int pidx = min(max(pix0 + (tap / 3 - 1) * W + (tap % 3 - 1), 0), p.M - 1);
+      const float* const src = p.X + (size_t)pidx * p.ldx;
 #pragma unroll
       for (int j = 0; j < CPT; ++j) {
         v[j][0] = *reinterpret_cast<const f32x4*>(src + min(32 * j + 4 * fq, CIN - 4));
-        v[j][1] = *reinterpret_cast<const f32x4*>(src + min(32 * j + 16 + 4 * fq, CIN - 4));
+        if (32 * j + 16 < CIN) v[j][1] = *reinterpret_cast<const f32x4*>(src + min(32 * j + 16 + 4 * fq, CIN - 4));   // (else: no lane's slot is a channel)
       }
     };
     auto mul_tap = [&](int tap, const pix_t& v, f32x4 acc) __attribute__((always_inline)) {
-      const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-      const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const bool in = (tap / 3 == 0 ? up : (tap / 3 == 2 ? dn : true)) && (tap % 3 == 0 ? lf : (tap % 3 == 2 ? rt : true));
 #pragma unroll
       for (int j = 0; j < CPT; ++j) {
         const bool live0 = in && 32 * j + 4 * fq < CIN;      // (the weight's pad columns are zeros, but 0 * garbage need not be)
         const bool live1 = in && 32 * j + 16 + 4 * fq < CIN;
-        bf16x8 a;
+        // round first, then select on the packed words (4 selects per chunk instead of 8)
+        bf16x4 lo;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          a[e] = (__bf16)(live0 ? v[j][0][e] : 0.f);
-          a[4 + e] = (__bf16)(live1 ? v[j][1][e] : 0.f);
+        for (int e = 0; e < 4; ++e) lo[e] = (__bf16)v[j][0][e];
+        u32x2 l = __builtin_bit_cast(u32x2, lo), h = u32x2{0u, 0u};
+        l[0] = live0 ? l[0] : 0u; l[1] = live0 ? l[1] : 0u;
+        if (32 * j + 16 < CIN) {
+          bf16x4 hi;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hi[e] = (__bf16)v[j][1][e];
+          h = __builtin_bit_cast(u32x2, hi);
+          h[0] = live1 ? h[0] : 0u; h[1] = live1 ? h[1] : 0u;
         }
+        const bf16x8 a = __builtin_bit_cast(bf16x8, u32x4{l[0], l[1], h[0], h[1]});
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tap][j], a, acc, 0, 0, 0);
       }
       return acc;
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(256) void conv_tail_kernel(const GemmParams p, int 
       if (tap + 1 < 9) acc = mul_tap(tap + 1, vb, acc);
     }
     if (fq == 0) {
-      const size_t pix = (size_t)row * W + x;
+      const size_t pix = (size_t)pix0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float o = acc[r];
@@ -175,7 +188,7 @@ int srad_launch_conv_tail(const GemmParams& p, hipStream_t stream) {
   SRAD_REQUIRE(srad_conv_tail_supported(SRAD_PREC_BF16, p), "conv_tail: unsupported problem");
   const int tiles = p.M / 16;
   // every wave keeps the whole weight in registers: few, long-lived waves.  Measured (us, 256 / 512 / 768 / 1024 workgroups):
-  // 40 -> 3 at 256 px x 8: 81 / 65 / 67 / 70;  80 -> 3 at 128 px x 8: 33.9 / 34.7 / 38 / 39;  at 64 px x 8: 11.8 / 14.8 / 14.8 / 14.5
+  // 40 -> 3 at 256 px x 8: 81 / 65 / 67 / 70 (62 after the instruction trim);  80 -> 3 at 128 px x 8: 33.9 / 34.7 / 38 / 39;  at 64 px x 8: 11.8 / 14.8 / 14.8 / 14.5
   const int cap = tiles >= 16384 ? 512 : 256;
   const int wgs = tiles / 4 < cap ? tiles / 4 : cap;
   SradProfScope prof(stream, SRAD_K_GEMM_BN16, 2.0 * p.M * p.N * 9.0 * p.Cin, 4.0 * p.M * ((double)p.Cin + p.N * (p.R ? 2 : 1)));

@@ -158,7 +158,8 @@ def test_wgrad_conv9_bf16_operands(dev, B, H, W, x_bf16):
     assert _rel(db, dy_h.float().sum(0)) < 1e-5
 
 
-@pytest.mark.parametrize("cin,n,mode", [(3, 20, "bias"), (40, 3, "bias"), (80, 1, "relu"), (4, 40, "residual"), (20, 3, "offset_out"), (4, 80, "bias")])
+@pytest.mark.parametrize("cin,n,mode", [(3, 20, "bias"), (40, 3, "bias"), (80, 1, "relu"), (4, 40, "residual"), (20, 3, "offset_out"), (4, 80, "bias"),
+                                        (40, 3, "offset_out"), (80, 3, "residual"), (80, 4, "bias")])
 def test_thin_convolutions(dev, cin, n, mode):
     """3x3 stride-1 convolutions with few input or output channels at >= 32768 pixels - DRN's head (3 -> 20), its tails (40 / 80 -> 3
     or 1) and their data gradients (4 -> 40 / 80).  Those with <= 8 INPUT channels take kernels_thin.hip in bf16 mode (round 3:
@@ -320,3 +321,19 @@ def test_window_attention_ignores_pad_columns(dev):
         a = ops.window_attention(qkv, table, B, H, W, ws, 4, heads, precision=prec)
         b = ops.window_attention(qkv, table, B, H, W, ws, 4, heads, precision=prec, pad_value=float("nan"))
         assert bool(torch.isfinite(b).all()) and torch.equal(a, b)
+
+
+def test_tail_convolution_at_the_c3_shape(dev):
+    """DRN-L's last tail (40 -> 3 channels at 256 px x 8 images, src/drn.py:265-267) on `conv_tail_kernel`'s 512-workgroup
+    instance (16 tiles per wave): against torch's conv2d on bf16-rounded operands at 1e-5 (only the summation order differs)."""
+    from srad_amd import ops
+    B, H, W, cin, n = 8, 256, 256, 40, 3
+    g = torch.Generator(device="cpu").manual_seed(77)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    x = bf(torch.randn(B, cin, H, W, generator=g)).to(dev)
+    w = bf(torch.randn(n, cin, 3, 3, generator=g) / math.sqrt(9 * cin)).to(dev)
+    b = torch.randn(n, generator=g).to(dev)
+    xn = x.permute(0, 2, 3, 1).reshape(-1, cin).clone(memory_format=torch.contiguous_format)
+    y = ops.gemm(xn, w, b, B=B, H=H, W=W, precision="bf16")
+    ref = F.conv2d(x, w, b, padding=1).permute(0, 2, 3, 1).reshape(-1, n)
+    assert _rel(y, ref) < 1e-5, _rel(y, ref)
