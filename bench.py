@@ -694,11 +694,29 @@ def run_rank(args):
     }
 
     if not args.no_train:
+        guard = None
+        if world > 1:
+            # the one leg with collectives on its data path: if a rank dies or hangs in it, the others wait in an all-reduce
+            # forever and the headline line above would never be printed.  A timer prints it (rank 0) and ends the process.
+            import threading
+            limit = float(os.environ.get("SRAD_BENCH_TRAIN_LIMIT_S", "420"))
+
+            def give_up():
+                if rank == 0:
+                    result["train"] = {"error": f"timeout: the data-parallel training leg did not finish within {limit:.0f} s "
+                                                "(a rank hung or died in it); line printed by the watchdog"}
+                    print(json.dumps(result), flush=True)
+                os._exit(3)
+            guard = threading.Timer(limit, give_up)
+            guard.daemon = True
+            guard.start()
         try:
             torch.manual_seed(1)                           # the replica's weights: same seed on every rank ...
             result["train"] = train_leg(args, torch, dist, dev, world, rank)
         except Exception as e:          # the headline line must survive a failure of this extra leg
             result["train"] = {"error": f"{type(e).__name__}: {e}"}
+        if guard is not None:
+            guard.cancel()
 
     if rank == 0:
         flops = model.flops(B, H, W)
