@@ -6,6 +6,7 @@
 // input straight from global memory (each pixel is read by nine neighbouring threads: L1 / L2 hits).  Weights are the bf16
 // values of the packed layer (what the MFMA path multiplies by), activations stay fp32.
 #include "srad_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -77,8 +78,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const GemmParams p) {
 // through LDS made these 120 / 45 / 16 us launches (256 / 128 / 64 px x 8 images) for 84 / 42 / 10 MB of input; here 62 / 33 / 12.
 // (What is left is the texture path: every pixel's channels are loaded nine times, 27 / 45 load instructions per 16 pixels.
 // Trimming the vector instructions per chunk - one clamped index per tap, selects on packed words - bought 5 %, a third wave
-// per SIMD nothing.  A wave walking down a column strip with three input rows held as fragments would load each pixel three
-// times; at 80 channels that does not fit the registers next to the weights.)  Here a wave owns 16 consecutive
+// per SIMD nothing.  conv_tail40_strip_kernel below loads each pixel three times instead: 62 -> 34 us at 40 channels.)  Here a wave owns 16 consecutive
 // pixels of an image row and runs one 16x16x32 MFMA per (tap, 32-channel chunk) with BOTH operands straight from registers: the
 // weight fragments of all 9 x ceil(Cin / 32) chunks stay in the wave's registers for its lifetime (rows >= N of the pack are
 // zeros), a pixel fragment is the lane's own 8 channels of pixel (y + dy, x + dx) loaded from global memory (two float4, rounded
@@ -173,6 +173,97 @@ __global__ __launch_bounds__(256) void conv_tail_kernel(const GemmParams p, int 
   }
 }
 
+// The 40-channel tail as a column strip: a wave owns 16 columns x 16 rows and walks down, holding the three input rows an output
+// row needs as bf16 fragments (three x-shifts each), so every pixel's channels are loaded three times instead of nine
+// (conv_tail_kernel is bound by its load instructions, not by bytes or MFMAs).  Same k-slot permutation, same weights in
+// registers; the next input row's nine loads are in flight under the current row's 18 MFMAs.  (At 80 channels three rows of
+// fragments do not fit next to the weights.)
+constexpr int CT_RS = 16;
+__global__ __launch_bounds__(256) void conv_tail40_strip_kernel(const GemmParams p, int nstrips) {
+  constexpr int CIN = 40, CP = 64;
+  const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+  bf16x8 wf[9][2];
+  {
+    const __bf16* const Wp = reinterpret_cast<const __bf16*>(p.Wp) + (size_t)fr * 9 * CP + 4 * fq;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(Wp + tap * CP + 32 * j);
+        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(Wp + tap * CP + 32 * j + 16);
+        wf[tap][j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+  }
+  f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias4[r] = (p.bias && fq == 0) ? p.bias[min(r, p.N - 1)] : 0.f;
+  const int H = p.Hi, W = p.Wi, spr = W >> 4, spi = (H / CT_RS) * spr;      // strips per row of strips / per image
+  const bool c1live = 32 + 4 * fq < CIN;                                     // chunk 1: channels 32 .. 39 in the lo slots of fq < 2
+  struct Frag { u32x4 c0; u32x2 c1; };                                       // one pixel fragment: chunk 0 (8 slots), chunk 1 (lo 4 slots)
+  struct Stage { f32x4 a, b, c; };                                           // the three float4 it is made from
+  for (int st = gw; st < nstrips; st += nw) {
+    const int b = st / spi, rem = st - b * spi, sy = rem / spr, x = ((rem - sy * spr) << 4) + fr;
+    const int y0 = sy * CT_RS;
+    const bool lf = x > 0, rt = x < W - 1;
+    auto load_row = [&](int r, Stage (&sg)[3]) __attribute__((always_inline)) {
+      const int base = (b * H + r) * W + x;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const float* const src = p.X + (size_t)min(max(base + dx - 1, 0), p.M - 1) * p.ldx;      // (rows -1 / H, columns -1 / W: masked below)
+        sg[dx].a = *reinterpret_cast<const f32x4*>(src + 4 * fq);
+        sg[dx].b = *reinterpret_cast<const f32x4*>(src + 16 + 4 * fq);
+        sg[dx].c = *reinterpret_cast<const f32x4*>(src + min(32 + 4 * fq, CIN - 4));
+      }
+    };
+    auto convert_row = [&](int r, const Stage (&sg)[3], Frag (&f)[3]) __attribute__((always_inline)) {
+      const bool rowin = r >= 0 && r < H;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const bool in = rowin && (dx == 0 ? lf : (dx == 2 ? rt : true));
+        bf16x4 a, bq, c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = (__bf16)sg[dx].a[e]; bq[e] = (__bf16)sg[dx].b[e]; c[e] = (__bf16)sg[dx].c[e]; }
+        const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, bq), uc = __builtin_bit_cast(u32x2, c);
+        f[dx].c0 = u32x4{in ? ua[0] : 0u, in ? ua[1] : 0u, in ? ub[0] : 0u, in ? ub[1] : 0u};
+        f[dx].c1 = u32x2{(in && c1live) ? uc[0] : 0u, (in && c1live) ? uc[1] : 0u};
+      }
+    };
+    Frag F[3][3];
+    Stage sg[3];
+    load_row(y0 - 1, sg);
+    convert_row(y0 - 1, sg, F[0]);
+    load_row(y0, sg);
+    convert_row(y0, sg, F[1]);
+    load_row(y0 + 1, sg);
+#pragma unroll
+    for (int i = 0; i < CT_RS; ++i) {
+      convert_row(y0 + i + 1, sg, F[(i + 2) % 3]);
+      if (i + 1 < CT_RS) load_row(y0 + i + 2, sg);             // in flight under this row's MFMAs
+      f32x4 acc = bias4;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const Frag& f = F[(i + dy) % 3][dx];
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[dy * 3 + dx][0], __builtin_bit_cast(bf16x8, f.c0), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[dy * 3 + dx][1], __builtin_bit_cast(bf16x8, u32x4{f.c1[0], f.c1[1], 0u, 0u}), acc, 0, 0, 0);
+        }
+      if (fq == 0) {
+        const size_t pix = (size_t)(b * H + y0 + i) * W + x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float o = acc[r];
+          if (p.act == SRAD_ACT_RELU) o = fmaxf(o, 0.f);
+          else if (p.act == SRAD_ACT_LRELU) o = o > 0.f ? o : o * p.slope;
+          o *= p.alpha;
+          if (r < p.N) p.Y[pix * p.ldy + p.yoff + r] = o + (p.R ? p.R[pix * p.ldr + r] : 0.f);
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 bool srad_conv_tail_supported(int prec, const GemmParams& p) {
@@ -192,7 +283,12 @@ int srad_launch_conv_tail(const GemmParams& p, hipStream_t stream) {
   const int cap = tiles >= 16384 ? 512 : 256;
   const int wgs = tiles / 4 < cap ? tiles / 4 : cap;
   SradProfScope prof(stream, SRAD_K_GEMM_BN16, 2.0 * p.M * p.N * 9.0 * p.Cin, 4.0 * p.M * ((double)p.Cin + p.N * (p.R ? 2 : 1)));
-  if (p.Cin == 40) hipLaunchKernelGGL(conv_tail_kernel<40>, dim3(wgs), dim3(256), 0, stream, p, tiles);
+  static const bool no_strip = getenv("SRAD_TAIL_NO_STRIP") != nullptr;
+  if (p.Cin == 40 && p.Hi % CT_RS == 0 && !no_strip) {
+    const int nstrips = tiles / CT_RS;
+    const int swgs = std::max(1, std::min(nstrips / 4, 512));
+    hipLaunchKernelGGL(conv_tail40_strip_kernel, dim3(swgs), dim3(256), 0, stream, p, nstrips);
+  } else if (p.Cin == 40) hipLaunchKernelGGL(conv_tail_kernel<40>, dim3(wgs), dim3(256), 0, stream, p, tiles);
   else hipLaunchKernelGGL(conv_tail_kernel<80>, dim3(wgs), dim3(256), 0, stream, p, tiles);
   SRAD_CHECK_HIP(hipGetLastError());
   return SRAD_OK;
