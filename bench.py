@@ -706,6 +706,8 @@ def run_rank(args):
                     result["train"] = {"error": f"timeout: the data-parallel training leg did not finish within {limit:.0f} s "
                                                 "(a rank hung or died in it); line printed by the watchdog"}
                     print(json.dumps(result), flush=True)
+                else:
+                    time.sleep(5)        # rank 0 prints before the launcher sees a rank exit and ends the others
                 os._exit(3)
             guard = threading.Timer(limit, give_up)
             guard.daemon = True
