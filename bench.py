@@ -619,6 +619,28 @@ def run_only(args):
     print(json.dumps({args.only: out}), flush=True)
 
 
+def arm_train_watchdog(result, rank, limit_s, linger_s=5.0):
+    """The data-parallel training leg is the one leg with collectives on its data path: if a rank dies or hangs in it, the
+    others wait in an all-reduce forever and the headline line (already measured, in `result`) would never be printed.  This
+    timer prints it from rank 0 with the leg marked as timed out and ends the process (exit code 3); the other ranks leave
+    `linger_s` later, so that the launcher does not end rank 0 before it has printed.  cancel() the returned timer when the
+    leg is through."""
+    import threading
+
+    def give_up():
+        if rank == 0:
+            result["train"] = {"error": f"timeout: the data-parallel training leg did not finish within {limit_s:.0f} s "
+                                        "(a rank hung or died in it); line printed by the watchdog"}
+            print(json.dumps(result), flush=True)
+        else:
+            time.sleep(linger_s)
+        os._exit(3)
+    guard = threading.Timer(limit_s, give_up)
+    guard.daemon = True
+    guard.start()
+    return guard
+
+
 def run_rank(args):
     import torch
     import torch.distributed as dist
@@ -696,22 +718,7 @@ def run_rank(args):
     if not args.no_train:
         guard = None
         if world > 1:
-            # the one leg with collectives on its data path: if a rank dies or hangs in it, the others wait in an all-reduce
-            # forever and the headline line above would never be printed.  A timer prints it (rank 0) and ends the process.
-            import threading
-            limit = float(os.environ.get("SRAD_BENCH_TRAIN_LIMIT_S", "420"))
-
-            def give_up():
-                if rank == 0:
-                    result["train"] = {"error": f"timeout: the data-parallel training leg did not finish within {limit:.0f} s "
-                                                "(a rank hung or died in it); line printed by the watchdog"}
-                    print(json.dumps(result), flush=True)
-                else:
-                    time.sleep(5)        # rank 0 prints before the launcher sees a rank exit and ends the others
-                os._exit(3)
-            guard = threading.Timer(limit, give_up)
-            guard.daemon = True
-            guard.start()
+            guard = arm_train_watchdog(result, rank, float(os.environ.get("SRAD_BENCH_TRAIN_LIMIT_S", "420")))
         try:
             torch.manual_seed(1)                           # the replica's weights: same seed on every rank ...
             result["train"] = train_leg(args, torch, dist, dev, world, rank)

@@ -415,3 +415,27 @@ def test_checkpoint_writes_what_the_evaluator_parses(tmp_path):
     ck2 = Checkpoint(o)                                                  # an existing run dir is appended to
     ck2.done()
     assert (tmp_path / "renamed" / "config.txt").read_text().count("model_name: drn-l") == 2
+
+
+def test_bench_watchdog_prints_the_headline_line_and_ends_a_hung_rank():
+    """bench.py at N > 1: a rank stuck in the training leg's all-reduce must not take the (already measured) headline line
+    with it - the watchdog prints it from rank 0 with the leg marked as timed out and exits with code 3; a cancelled watchdog
+    does nothing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = ("import sys, time, json; sys.path.insert(0, %r); import bench\n"
+            "r = {'metric': 'm', 'value': 1.0}\n"
+            "g = bench.arm_train_watchdog(r, 0, 30.0); g.cancel()\n"
+            "bench.arm_train_watchdog(r, int(sys.argv[1]), 0.3, linger_s=0.2)\n"
+            "time.sleep(20)\nprint('not reached')\n") % root
+    for rank in (0, 1):
+        out = subprocess.run([sys.executable, "-c", prog, str(rank)], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 3, (out.returncode, out.stderr[-500:])
+        assert "not reached" not in out.stdout
+        if rank == 0:
+            line = json.loads(out.stdout.strip().splitlines()[-1])
+            assert line["value"] == 1.0 and "timeout" in line["train"]["error"]
+        else:
+            assert out.stdout.strip() == ""
